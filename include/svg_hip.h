@@ -1,0 +1,156 @@
+/*
+ * svg_hip.h — C ABI of libsvg_hip.so: the MI355X (gfx950) implementation of the
+ * sd-video-gen sampling path.  Plain pointers and sizes only; no torch types.
+ *
+ * The reference has no FFI: this boundary replaces the third-party numerics its Python
+ * calls into.  Each entry point names the reference call site it stands in for
+ * (paths relative to the reference repo root):
+ *
+ *   svg_transformer_forward   models/transformer.py:47-68 (Transformer.forward: embedding*sqrt(d),
+ *                             PositionalEncoding by batch index positional_encoding.py:33-35,
+ *                             nn.Transformer, out Linear); called from prediction/predict.py:16-42
+ *   svg_vae_encode            utils/sd_utils.py:128-145 (encode_img: /255, NHWC->NCHW, 2(x-.5),
+ *                             vae.encode(...).sample(), *0.18215) incl. the uint8 nearest resize
+ *                             of prediction/predict.py:158,178
+ *   svg_vae_decode            utils/sd_utils.py:156-169 (decode_img_latents: /0.18215, vae.decode,
+ *                             (x/2+.5).clamp(0,1), *255 round -> uint8 NHWC)
+ *   svg_unet_forward          utils/sd_utils.py:253 (self.unet(latent_model_input, t,
+ *                             encoder_hidden_states=...)['sample'])
+ *   svg_ddim_loop             utils/sd_utils.py:222-267 (gen_i2i_latents: DDIMScheduler(0.00085,
+ *                             0.012,'scaled_linear',1000), set_timesteps, add_noise, CFG combine,
+ *                             scheduler.step) — the hot loop
+ *   svg_resize_nearest_u8     prediction/predict.py:158,178 (F.interpolate on uint8, mode nearest)
+ *   svg_load_weight/finalize  utils/sd_utils.py:52-66 + prediction/predict.py:50-51 (from_pretrained /
+ *                             load_state_dict: tensors are handed over by their state_dict names)
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; svg_last_error() gives the message.
+ *   - all device pointers are caller-owned HBM (e.g. torch tensors); the library owns packed
+ *     weights and one workspace arena per context, sized at svg_finalize()/first call; no
+ *     allocation in steady state.  The library never frees caller memory.
+ *   - `stream` is a hipStream_t (NULL = the null stream); every launch is asynchronous on it;
+ *     no entry point synchronises the device except svg_load_weight/svg_finalize/svg_prof_*.
+ *   - one context per (process, GPU); calls on a context are serialised by the caller.
+ *   - boundary dtypes: f32 latents / embeddings / masks / noise, u8 images (NHWC).
+ *     Internal compute dtype of the SD networks is bf16 with f32 accumulation; the latent
+ *     Transformer computes in f32 (f32-input MFMA).
+ */
+#ifndef SVG_HIP_H
+#define SVG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct svg_ctx svg_ctx;
+
+enum svg_model { SVG_TRANSFORMER = 0, SVG_VAE = 1, SVG_UNET = 2 };
+
+/* ---- context ------------------------------------------------------------------------------ */
+int svg_create(int device_id, svg_ctx** out);
+void svg_destroy(svg_ctx* ctx);
+const char* svg_last_error(svg_ctx* ctx);            /* ctx may be NULL (creation errors) */
+const char* svg_version(void);
+
+/* ---- models: configure -> load every tensor by state_dict name -> finalize ------------------ */
+/* `kv`: "key=v[,v...];key=v" e.g. "block_out=320,640,1280,1280;layers=2;heads=8;ctx_dim=768".
+ * Transformer keys: d_lat, d_model, heads, enc_layers, dec_layers, ffn (default 2048).
+ * VAE keys: block_out (128,256,512,512), layers (2), groups (32), latent (4).
+ * UNet keys: block_out (320,640,1280,1280), layers (2), heads (8), ctx_dim (768), groups (32),
+ *            in_ch (4), out_ch (4), attn (1,1,1,0: cross-attention per down block). */
+int svg_model_configure(svg_ctx* ctx, int model, const char* kv);
+/* data: f32, host or device memory (hipMemcpyDefault); shape/ndim as in the state_dict. */
+int svg_load_weight(svg_ctx* ctx, int model, const char* name, const float* data,
+                    const int64_t* shape, int ndim);
+/* packs fused layouts, checks that every expected tensor arrived (error names the first
+ * missing key), returns the model's parameter count through *n_params if non-NULL. */
+int svg_finalize(svg_ctx* ctx, int model, int64_t* n_params);
+
+/* ---- latent Transformer -------------------------------------------------------------------- */
+/* src (B,Ts,D_lat), tgt (B,Tt,D_lat) batch-first f32; mask (Tt,Tt) additive f32 or NULL;
+ * out (Tt,B,D_lat) sequence-first like the reference.  pe_row: NULL -> reference quirk (row b of
+ * the batch gets PE(b)); else int32[B] giving the PE row used for each batch row (clip-batched
+ * sampling passes zeros so every clip sees PE(0) exactly as at batch 1). */
+int svg_transformer_forward(svg_ctx* ctx, const float* src, const float* tgt, int B, int Ts, int Tt,
+                            const float* mask, const int32_t* pe_row, float* out, void* stream);
+
+/* ---- VAE ------------------------------------------------------------------------------------ */
+/* img: u8 NHWC (N,srcH,srcW,3); nearest-resized to (H,W) on the fly when they differ.
+ * eps: f32 (N,4,H/8,W/8) standard-normal draws for .sample(), or NULL for the distribution mean.
+ * z_out: f32 (N,4,H/8,W/8), already multiplied by 0.18215.  moments_out (optional, may be NULL):
+ * f32 (N,8,H/8,W/8) = [mean; logvar] before sampling. */
+int svg_vae_encode(svg_ctx* ctx, const uint8_t* img, int N, int srcH, int srcW, int H, int W,
+                   const float* eps, float* z_out, float* moments_out, void* stream);
+/* z: f32 (N,4,h,w) scaled latents (divided by 0.18215 inside).  img_out: u8 NHWC (N,outH,outW,3),
+ * nearest-resized from (8h,8w) when they differ.  float_out (optional): f32 NCHW (N,3,8h,8w),
+ * the decoder output before the clamp/quantise. */
+int svg_vae_decode(svg_ctx* ctx, const float* z, int N, int h, int w, uint8_t* img_out, int outH,
+                   int outW, float* float_out, void* stream);
+
+/* ---- UNet / DDIM ---------------------------------------------------------------------------- */
+/* x (N,4,h,w) f32; timesteps f32[N]; ctx_emb (N,ctx_len,ctx_dim) f32; eps_out (N,4,h,w) f32. */
+int svg_unet_forward(svg_ctx* ctx, const float* x, int N, int h, int w, const float* timesteps,
+                     const float* ctx_emb, int ctx_len, float* eps_out, void* stream);
+/* DDIM img2img over timesteps[start_step:] of a `num_steps` schedule (1000 train steps,
+ * scaled_linear 0.00085..0.012, clip_sample, set_alpha_to_one, eta 0).
+ * z (N,4,h,w) f32 in/out.  text_emb (2N,ctx_len,ctx_dim) = [uncond; cond] like encode_text().
+ * noise: f32 (N,4,h,w) for add_noise when start_step>0 (required then), else ignored.
+ * guidance==0 runs the UNet on the uncond half only (exact: u + 0*(c-u) == u).
+ * hist (optional): f32 ((num_steps-start_step+1)*N,4,h,w) latent history incl. the start. */
+int svg_ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const float* text_emb, int ctx_len,
+                  int num_steps, int start_step, float guidance, const float* noise, float* hist,
+                  void* stream);
+/* one scheduler step on caller data (x, eps -> prev); t = timestep value, t_prev = t - 1000/num_steps */
+int svg_ddim_step(svg_ctx* ctx, const float* x, const float* eps, float* prev, int64_t n, int t,
+                  int t_prev, void* stream);
+
+int svg_resize_nearest_u8(svg_ctx* ctx, const uint8_t* src, int N, int sh, int sw, int C,
+                          uint8_t* dst, int dh, int dw, void* stream);
+
+/* ---- operator level (the kernels the graphs are made of; used by the parity tests) ---------- */
+/* bf16 buffers are passed as uint16_t bit patterns. NHWC activations, weights [N][K] K-contiguous. */
+/* C[M,N] = act(A[M,K] * W[N,K]^T + bias[N] + residual[M,N]);  out_f32: C is f32 instead of bf16.
+ * act: 0 none, 1 SiLU, 2 GELU(erf), 3 GEGLU (W rows = [h;gate] halves of 2*N_out, C is [M,N/2]). */
+int svg_op_gemm(svg_ctx* ctx, const uint16_t* A, const uint16_t* W, const float* bias,
+                const uint16_t* residual, void* C, int M, int N, int K, int act, int out_f32,
+                void* stream);
+/* 3x3 convolution on NHWC bf16: x (B,H,W,Cin), w f32 OIHW (packed inside, cached by pointer is NOT
+ * done: the packed copy is rebuilt per call — test hook).  mode: 0 stride1 pad1, 1 stride2 pad1,
+ * 2 stride2 pad (0,1,0,1), 3 nearest-2x upsample then stride1 pad1.  out (B,Ho,Wo,Cout) bf16. */
+int svg_op_conv3x3(svg_ctx* ctx, const uint16_t* x, const float* w_oihw, const float* bias,
+                   uint16_t* out, int B, int H, int W, int Cin, int Cout, int mode, void* stream);
+/* GroupNorm (+SiLU) on NHWC bf16. */
+int svg_op_groupnorm(svg_ctx* ctx, const uint16_t* x, const float* gamma, const float* beta,
+                     uint16_t* out, int B, int HW, int C, int groups, float eps, int silu,
+                     void* stream);
+/* LayerNorm over the last dim of (M,C) bf16. */
+int svg_op_layernorm(svg_ctx* ctx, const uint16_t* x, const float* gamma, const float* beta,
+                     uint16_t* out, int M, int C, float eps, void* stream);
+/* softmax(Q K^T * scale) V per (batch, head).  q (B,Sq,heads*d) bf16 row stride ldq; k (B,Skv,·)
+ * row stride ldk; vt (B,heads*d,SkvPad) = V transposed, row stride ldvt (kv contiguous);
+ * out (B,Sq,heads*d) row stride ldo.  Skv valid keys (columns >= Skv are masked). */
+int svg_op_attention(svg_ctx* ctx, const uint16_t* q, const uint16_t* k, const uint16_t* vt,
+                     uint16_t* out, int B, int heads, int Sq, int Skv, int d, int ldq, int ldk,
+                     int ldvt, int ldo, int64_t q_bstride, int64_t k_bstride, int64_t vt_bstride,
+                     int64_t o_bstride, float scale, void* stream);
+/* f32 skinny GEMM of the latent Transformer: Y[M,N] = X[M,K] * W[N,K]^T + bias (relu_in: X:=max(X,0)). */
+int svg_op_xf_gemm(svg_ctx* ctx, const float* X, const float* W, const float* bias, float* Y,
+                   int M, int N, int K, int relu_in, void* stream);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+/* When enabled, every launch of each kernel family is bracketed by hipEvents on its stream;
+ * svg_prof_report synchronises and writes "name calls total_ms flops bytes\n" lines into buf. */
+int svg_prof_enable(svg_ctx* ctx, int on);
+int svg_prof_reset(svg_ctx* ctx);
+int svg_prof_report(svg_ctx* ctx, char* buf, int buflen);
+/* workspace bytes currently reserved by the context */
+int64_t svg_workspace_bytes(svg_ctx* ctx);
+/* capture the DDIM loop body into a hipGraph and replay it (1) or launch eagerly (0, default) */
+int svg_set_graph_mode(svg_ctx* ctx, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVG_HIP_H */

@@ -1,0 +1,245 @@
+"""ctypes binding of libsvg_hip.so (include/svg_hip.h).
+
+There is no CPU fallback: if the shared library is missing or cannot be loaded the import of any
+product entry point raises.  PyTorch is used only for device memory and streams
+(``tensor.data_ptr()``, ``torch.cuda.current_stream().cuda_stream``).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvg_hip.so")
+
+SVG_TRANSFORMER, SVG_VAE, SVG_UNET = 0, 1, 2
+
+_lib = None
+
+_vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/svg_hip.h
+SIGNATURES = {
+    "svg_create": [_i, C.POINTER(_vp)],
+    "svg_destroy": [_vp],
+    "svg_last_error": [_vp],
+    "svg_version": [],
+    "svg_model_configure": [_vp, _i, C.c_char_p],
+    "svg_load_weight": [_vp, _i, C.c_char_p, _vp, C.POINTER(_i64), _i],
+    "svg_finalize": [_vp, _i, C.POINTER(_i64)],
+    "svg_transformer_forward": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "svg_vae_encode": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "svg_vae_decode": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp],
+    "svg_unet_forward": [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp],
+    "svg_ddim_loop": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _f, _vp, _vp, _vp],
+    "svg_ddim_step": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+    "svg_resize_nearest_u8": [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp],
+    "svg_op_gemm": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "svg_op_conv3x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "svg_op_groupnorm": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
+    "svg_op_layernorm": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "svg_op_attention": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _f, _vp],
+    "svg_op_xf_gemm": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "svg_prof_enable": [_vp, _i],
+    "svg_prof_reset": [_vp],
+    "svg_prof_report": [_vp, C.c_char_p, _i],
+    "svg_workspace_bytes": [_vp],
+    "svg_set_graph_mode": [_vp, _i],
+}
+_RESTYPES = {"svg_destroy": None, "svg_last_error": C.c_char_p, "svg_version": C.c_char_p,
+             "svg_workspace_bytes": _i64}
+
+
+def load():
+    """dlopen the library and declare every symbol of the header; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libsvg_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C sd-video-gen_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, _i)
+    _lib = lib
+    return lib
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, torch.Tensor):
+        assert t.is_contiguous(), "tensor handed to the HIP library must be contiguous"
+        return t.data_ptr()
+    return t
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Context:
+    """One svg_ctx per (process, GPU)."""
+
+    def __init__(self, device_index=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("the sd-video-gen HIP path needs a GPU (gfx950); no CPU fallback exists")
+        self.lib = load()
+        if device_index is None:
+            device_index = torch.cuda.current_device()
+        self.device = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.device)
+        h = _vp()
+        if self.lib.svg_create(device_index, C.byref(h)) != 0:
+            raise RuntimeError("svg_create: " + self.lib.svg_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.svg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.svg_last_error(self.h).decode()
+            if "shape" in msg or "missing weight" in msg or "unsupported" in msg or "must be" in msg:
+                raise ValueError("%s: %s" % (what, msg))
+            raise RuntimeError("%s: %s" % (what, msg))
+
+    # ---- models ------------------------------------------------------------------------------
+    def configure(self, model, **kv):
+        s = ";".join("%s=%s" % (k, ",".join(str(int(x)) for x in (v if isinstance(v, (list, tuple)) else [v])))
+                     for k, v in kv.items())
+        self.check(self.lib.svg_model_configure(self.h, model, s.encode()), "svg_model_configure")
+
+    def load_state_dict(self, model, sd):
+        for name, t in sd.items():
+            if not torch.is_floating_point(t):
+                continue
+            t = t.detach().to(torch.float32).contiguous()
+            shape = (_i64 * max(t.dim(), 1))(*(list(t.shape) if t.dim() else [1]))
+            self.check(self.lib.svg_load_weight(self.h, model, name.encode(), t.data_ptr(), shape, max(t.dim(), 1)),
+                       "svg_load_weight(%s)" % name)
+
+    def finalize(self, model):
+        n = _i64(0)
+        self.check(self.lib.svg_finalize(self.h, model, C.byref(n)), "svg_finalize")
+        return n.value
+
+    # ---- hot path ----------------------------------------------------------------------------
+    def transformer_forward(self, src, tgt, mask=None, pe_row=None):
+        B, Ts, D = src.shape
+        Tt = tgt.shape[1]
+        src = src.contiguous().float()
+        tgt_c = src if tgt is src else tgt.contiguous().float()
+        out = torch.empty((Tt, B, D), device=src.device, dtype=torch.float32)
+        mask = mask.contiguous().float() if mask is not None else None
+        pe_row = pe_row.to(device=src.device, dtype=torch.int32).contiguous() if pe_row is not None else None
+        self.check(self.lib.svg_transformer_forward(self.h, _ptr(src), _ptr(tgt_c), B, Ts, Tt, _ptr(mask), _ptr(pe_row),
+                                                    _ptr(out), _stream()), "svg_transformer_forward")
+        return out
+
+    def vae_encode(self, img_u8, H=None, W=None, eps=None, return_moments=False):
+        """img_u8: (N,h,w,3) uint8 on device; nearest-resized to (H,W) when given."""
+        N, sh, sw, c = img_u8.shape
+        assert c == 3 and img_u8.dtype == torch.uint8
+        H = H or sh
+        W = W or sw
+        img_u8 = img_u8.contiguous()
+        z = torch.empty((N, 4, H // 8, W // 8), device=img_u8.device, dtype=torch.float32)
+        mom = torch.empty((N, 8, H // 8, W // 8), device=img_u8.device, dtype=torch.float32) if return_moments else None
+        eps = eps.contiguous().float() if eps is not None else None
+        self.check(self.lib.svg_vae_encode(self.h, _ptr(img_u8), N, sh, sw, H, W, _ptr(eps), _ptr(z), _ptr(mom), _stream()),
+                   "svg_vae_encode")
+        return (z, mom) if return_moments else z
+
+    def vae_decode(self, z, out_hw=None, return_float=False):
+        N, c, h, w = z.shape
+        assert c == 4
+        z = z.contiguous().float()
+        oh, ow = out_hw if out_hw else (8 * h, 8 * w)
+        img = torch.empty((N, oh, ow, 3), device=z.device, dtype=torch.uint8)
+        fo = torch.empty((N, 3, 8 * h, 8 * w), device=z.device, dtype=torch.float32) if return_float else None
+        self.check(self.lib.svg_vae_decode(self.h, _ptr(z), N, h, w, _ptr(img), oh, ow, _ptr(fo), _stream()), "svg_vae_decode")
+        return (img, fo) if return_float else img
+
+    def unet_forward(self, x, timesteps, ctx_emb):
+        N, c, h, w = x.shape
+        x = x.contiguous().float()
+        t = torch.as_tensor(timesteps, dtype=torch.float32, device=x.device).reshape(-1)
+        if t.numel() == 1:
+            t = t.repeat(N)
+        t = t.contiguous()
+        ctx_emb = ctx_emb.contiguous().float()
+        out = torch.empty_like(x)
+        self.check(self.lib.svg_unet_forward(self.h, _ptr(x), N, h, w, _ptr(t), _ptr(ctx_emb), ctx_emb.shape[1], _ptr(out),
+                                             _stream()), "svg_unet_forward")
+        return out
+
+    def ddim_loop(self, z, text_emb, num_steps=50, start_step=0, guidance=7.5, noise=None, return_hist=False):
+        N, c, h, w = z.shape
+        z = z.contiguous().float().clone()
+        text_emb = text_emb.contiguous().float()
+        assert text_emb.shape[0] == 2 * N, "text embeddings must be [uncond; cond] (2N rows)"
+        noise = noise.contiguous().float() if noise is not None else None
+        hist = torch.empty(((num_steps - start_step + 1) * N, c, h, w), device=z.device, dtype=torch.float32) if return_hist else None
+        self.check(self.lib.svg_ddim_loop(self.h, _ptr(z), N, h, w, _ptr(text_emb), text_emb.shape[1], num_steps, start_step,
+                                          float(guidance), _ptr(noise), _ptr(hist), _stream()), "svg_ddim_loop")
+        return hist if return_hist else z
+
+    def ddim_step(self, x, eps, t, t_prev):
+        x = x.contiguous().float()
+        eps = eps.contiguous().float()
+        out = torch.empty_like(x)
+        self.check(self.lib.svg_ddim_step(self.h, _ptr(x), _ptr(eps), _ptr(out), x.numel(), int(t), int(t_prev), _stream()),
+                   "svg_ddim_step")
+        return out
+
+    def resize_nearest_u8(self, img, oh, ow):
+        N, h, w, c = img.shape
+        img = img.contiguous()
+        out = torch.empty((N, oh, ow, c), device=img.device, dtype=torch.uint8)
+        self.check(self.lib.svg_resize_nearest_u8(self.h, _ptr(img), N, h, w, c, _ptr(out), oh, ow, _stream()), "svg_resize")
+        return out
+
+    # ---- profiling -----------------------------------------------------------------------------
+    def prof_enable(self, on=True):
+        self.lib.svg_prof_enable(self.h, 1 if on else 0)
+
+    def prof_reset(self):
+        self.check(self.lib.svg_prof_reset(self.h), "svg_prof_reset")
+
+    def prof_report(self):
+        buf = C.create_string_buffer(1 << 16)
+        self.check(self.lib.svg_prof_report(self.h, buf, len(buf)), "svg_prof_report")
+        out = {}
+        for line in buf.value.decode().strip().splitlines():
+            name, calls, ms, flops, nbytes = line.split()
+            out[name] = dict(calls=int(calls), ms=float(ms), flops=float(flops), bytes=float(nbytes))
+        return out
+
+    def workspace_bytes(self):
+        return int(self.lib.svg_workspace_bytes(self.h))
+
+    def set_graph_mode(self, on):
+        self.lib.svg_set_graph_mode(self.h, 1 if on else 0)
+
+
+_default_ctx = {}
+
+
+def default_context():
+    """Process-wide context for the current GPU."""
+    idx = torch.cuda.current_device() if torch.cuda.is_available() else -1
+    if idx not in _default_ctx:
+        _default_ctx[idx] = Context(idx if idx >= 0 else None)
+    return _default_ctx[idx]

@@ -1,0 +1,127 @@
+// Internal runtime types of libsvg_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include <stdexcept>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+
+typedef __bf16 bf16;
+typedef uint16_t u16;
+
+struct SvgError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+#define SVG_CHECK(cond, ...)                                   \
+  do {                                                         \
+    if (!(cond)) {                                             \
+      char _b[512];                                            \
+      snprintf(_b, sizeof(_b), __VA_ARGS__);                   \
+      throw SvgError(std::string(_b));                         \
+    }                                                          \
+  } while (0)
+
+#define HIP_OK(expr)                                                                   \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      char _b[512];                                                                    \
+      snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),  \
+               __FILE__, __LINE__);                                                    \
+      throw SvgError(std::string(_b));                                                 \
+    }                                                                                  \
+  } while (0)
+
+static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- device memory owned by the library (weights) ---------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  int64_t bytes = 0;
+};
+
+// A weight as handed over (f32, original shape) and/or its packed forms.
+struct Weight {
+  std::vector<int64_t> shape;
+  float* f32 = nullptr;   // device, original layout (kept for 1-D params / f32 models)
+  int64_t numel = 0;
+};
+
+// ---- workspace arena: bump allocator with scopes; "dry" mode measures the high-water mark ----
+struct Arena {
+  char* base = nullptr;
+  int64_t cap = 0;
+  int64_t top = 0;
+  int64_t high = 0;
+  bool dry = false;
+  std::vector<int64_t> marks;
+  void* alloc(int64_t bytes) {
+    int64_t off = align_up(top, 256);
+    top = off + bytes;
+    if (top > high) high = top;
+    if (dry) return (void*)(uintptr_t)(0x1000 + off);   // never dereferenced: launches are skipped
+    SVG_CHECK(top <= cap, "workspace arena overflow: need %lld, have %lld", (long long)top, (long long)cap);
+    return base + off;
+  }
+  template <typename T> T* get(int64_t n) { return (T*)alloc(n * (int64_t)sizeof(T)); }
+  void push() { marks.push_back(top); }
+  void pop() { top = marks.back(); marks.pop_back(); }
+  void reset() { top = 0; marks.clear(); }
+};
+
+// ---- profiling: hipEvent brackets per kernel family -------------------------------------------
+struct ProfEntry {
+  std::string name;
+  int64_t calls = 0;
+  double flops = 0, bytes = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+};
+
+struct svg_ctx {
+  int device = 0;
+  std::string err;
+  Arena arena;
+  DevBuf arena_buf;
+  bool prof = false;
+  bool graph_mode = false;
+  std::vector<ProfEntry> prof_entries;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  // models (opaque here; defined in their own translation units)
+  struct XfModel* xf = nullptr;
+  struct VaeModel* vae = nullptr;
+  struct UnetModel* unet = nullptr;
+  std::vector<void*> owned;   // device allocations to free at destroy
+  void* dalloc(int64_t bytes);
+  void ensure_arena(int64_t bytes);
+};
+
+// Kernel families for the profiler (index into prof_entries)
+enum ProfKind {
+  PK_GEMM = 0, PK_CONV3, PK_ATTN, PK_GNORM, PK_LNORM, PK_ELT, PK_XF_GEMM, PK_XF_MISC, PK_SOFTMAX, PK_COUNT
+};
+extern const char* kProfNames[PK_COUNT];
+
+struct ProfScope {
+  svg_ctx* c; int kind; hipStream_t s; hipEvent_t e0 = nullptr, e1 = nullptr;
+  ProfScope(svg_ctx* c_, int kind_, hipStream_t s_, double flops, double bytes);
+  ~ProfScope();
+};
+
+// Launch guard: in arena-dry mode nothing is launched.
+#define SVG_LAUNCHING(ctx) (!(ctx)->arena.dry)
+
+static inline void check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    char b[256];
+    snprintf(b, sizeof(b), "launch of %s failed: %s", what, hipGetErrorString(e));
+    throw SvgError(std::string(b));
+  }
+}

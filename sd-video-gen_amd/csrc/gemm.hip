@@ -1,0 +1,466 @@
+// MFMA implicit GEMM for gfx950 (CDNA4): dense NT GEMM and 3x3 convolution on NHWC bf16.
+//
+//   C[M,N] = epilogue( A[M,K] * Wt[N,K]^T ),  f32 accumulate on v_mfma_f32_16x16x32_bf16.
+//
+// Tile 128 x BN x 64 per 256-thread workgroup (4 waves as 2x2, each 64 x BN/2), two LDS stages.
+// Global -> registers -> LDS staging with the loads of K-step t+1 issued before the MFMAs of
+// K-step t and written to the other LDS stage after them (one barrier per K-step).
+// LDS rows are 128 B (64 bf16); 16-B chunk c of row r is stored at chunk c ^ ((r>>1)&7) so the
+// ds_read_b128 fragment reads (16 rows x 2 k-chunks per lane group) are bank-conflict free.
+// The MFMA is issued with the WEIGHT fragment as the A operand and the activation fragment as
+// the B operand, so D[i][j] has i = output column n (4 consecutive n per lane in registers) and
+// j = output row m: the epilogue stores 4 contiguous outputs per lane (8 B bf16 / 16 B f32).
+// 3x3 conv = same GEMM with the A tile gathered from NHWC: K index = (tap, cin), cin contiguous.
+#include "kernels.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 64;
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+// bias / per-sample bias / residual / activation / store for 4 consecutive columns n..n+3 of row m
+__device__ __forceinline__ void epi_store(const GemmArgs& g, int z, int m, int n, f32x4 v) {
+  if (g.bias) {
+    if (g.bias_row) {
+      float b = g.bias[m];
+      v += b;
+    } else {
+      f32x4 b = *(const f32x4*)(g.bias + n);
+      v += b;
+    }
+  }
+  if (g.bias_bn) {
+    f32x4 b = *(const f32x4*)(g.bias_bn + (int64_t)(m / g.rows_per_batch) * (g.bias_bn_ld ? g.bias_bn_ld : g.N) + n);
+    v += b;
+  }
+  if (g.residual) {
+    bf16x4 r = *(const bf16x4*)(g.residual + (int64_t)z * g.sC + (int64_t)m * g.ldr + n);
+    v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+  }
+  if (g.act == ACT_SILU) {
+    for (int i = 0; i < 4; ++i) v[i] = silu_f(v[i]);
+  } else if (g.act == ACT_GELU) {
+    for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
+  }
+  int64_t o = (int64_t)z * g.sC + (int64_t)m * g.ldc + n;
+  if (g.out_f32) {
+    *(f32x4*)((float*)g.C + o) = v;
+  } else {
+    bf16x4 w;
+    w[0] = (bf16)v[0]; w[1] = (bf16)v[1]; w[2] = (bf16)v[2]; w[3] = (bf16)v[3];
+    *(bf16x4*)((bf16*)g.C + o) = w;
+  }
+}
+
+// GEGLU: h and gate are 4 consecutive packed columns nh.. / nh+16..; output column oc..oc+3
+__device__ __forceinline__ void epi_store_geglu(const GemmArgs& g, int z, int m, int nh, int oc, f32x4 h, f32x4 gt) {
+  if (g.bias) {
+    h += *(const f32x4*)(g.bias + nh);
+    gt += *(const f32x4*)(g.bias + nh + 16);
+  }
+  f32x4 v;
+  for (int i = 0; i < 4; ++i) v[i] = h[i] * gelu_erf(gt[i]);
+  int64_t o = (int64_t)z * g.sC + (int64_t)m * g.ldc + oc;
+  bf16x4 w;
+  w[0] = (bf16)v[0]; w[1] = (bf16)v[1]; w[2] = (bf16)v[2]; w[3] = (bf16)v[3];
+  *(bf16x4*)((bf16*)g.C + o) = w;
+}
+
+template <int BN, int AMODE>
+__global__ void __launch_bounds__(256, 2) igemm_kernel(const GemmArgs g) {
+  constexpr int NT = BN / 32;       // 16-wide n tiles per wave
+  constexpr int MT = 4;             // 16-high m tiles per wave
+  constexpr int BIT = BN / 32;      // B-tile rows per thread
+  constexpr int A_BYTES = BM * 128;
+  constexpr int B_BYTES = BN * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int z = blockIdx.y, ks = blockIdx.z;
+
+  // XCD-aware tile order: blocks that share an XCD (bid % 8) get a contiguous run of tiles,
+  // consecutive tiles share the A row panel (same tm) so its re-reads hit that XCD's L2.
+  const int tiles_n = (g.N + BN - 1) / BN;
+  int tile;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int KT = (g.K + BK - 1) / BK;
+  const int kt_per = (KT + g.splitk - 1) / g.splitk;
+  const int kt_begin = ks * kt_per;
+  const int kt_end = min(KT, kt_begin + kt_per);
+
+  const bf16* __restrict__ Ap = g.A + (int64_t)z * g.sA;
+  const bf16* __restrict__ Bp = g.Wt + (int64_t)z * g.sB;
+
+  // ---- loader state ---------------------------------------------------------------------------
+  const int c = tid & 7;         // 16-B chunk within the 64-wide K slab
+  const int r0 = tid >> 3;       // 0..31
+  const int cswz = (c ^ ((r0 >> 1) & 7)) << 4;
+
+  // A rows
+  int a_base[4];                 // dense: element offset of the row; conv: element offset of (b,0,0,0)
+  int a_yx[4];                   // conv: (y<<16)|x of the output pixel, -1 = row out of range
+  int a_off[4];                  // conv: element offset of the current tap's pixel, -1 = padding
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + r0 + 32 * i;
+    if (AMODE == A_DENSE) {
+      a_base[i] = (m < g.M) ? m * g.lda : -1;
+      a_yx[i] = 0; a_off[i] = 0;
+    } else {
+      if (m < g.M) {
+        int hw = g.Ho * g.Wo;
+        int b = m / hw;
+        int rem = m - b * hw;
+        int y = rem / g.Wo;
+        int x = rem - y * g.Wo;
+        a_yx[i] = (y << 16) | x;
+        a_base[i] = b * g.H * g.W * g.Cin;
+      } else {
+        a_yx[i] = -1; a_base[i] = 0;
+      }
+      a_off[i] = -1;
+    }
+  }
+  // B rows
+  int b_base[BIT];
+#pragma unroll
+  for (int i = 0; i < BIT; ++i) {
+    int n = n0 + r0 + 32 * i;
+    b_base[i] = (n < g.n_valid) ? n * g.ldb : -1;
+  }
+
+  auto tap_offset = [&](int i, int tap) -> int {
+    if (a_yx[i] < 0 || tap >= 9) return -1;
+    int y = a_yx[i] >> 16, x = a_yx[i] & 0xffff;
+    int ky = tap / 3, kx = tap - ky * 3;
+    int yy, xx;
+    if (AMODE == A_CONV_S1 || AMODE == A_CONV_SMALLC) {
+      yy = y + ky - 1; xx = x + kx - 1;
+    } else if (AMODE == A_CONV_S2P1) {
+      yy = 2 * y + ky - 1; xx = 2 * x + kx - 1;
+    } else if (AMODE == A_CONV_S2ASYM) {
+      yy = 2 * y + ky; xx = 2 * x + kx;
+    } else {  // A_CONV_UP2: conv over the nearest-2x upsampled image, read the source pixel
+      int uy = y + ky - 1, ux = x + kx - 1;
+      if ((unsigned)uy >= (unsigned)(2 * g.H) || (unsigned)ux >= (unsigned)(2 * g.W)) return -1;
+      yy = uy >> 1; xx = ux >> 1;
+    }
+    if ((unsigned)yy >= (unsigned)g.H || (unsigned)xx >= (unsigned)g.W) return -1;
+    return a_base[i] + (yy * g.W + xx) * g.Cin;
+  };
+
+  // incremental (tap, cin0) of the K slab being loaded (conv modes with Cin % 64 == 0)
+  int ld_tap = 0, ld_cin0 = 0;
+  if (AMODE != A_DENSE && AMODE != A_CONV_SMALLC) {
+    int k0 = kt_begin * BK;
+    ld_tap = k0 / g.Cin;
+    ld_cin0 = k0 - ld_tap * g.Cin;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_off[i] = tap_offset(i, ld_tap);
+  }
+
+  uint4 ra[4], rb[BIT];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+  auto load_tiles = [&](int kt) {
+    const int k = kt * BK + c * 8;
+    if (AMODE == A_DENSE) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        ra[i] = (a_base[i] >= 0 && k < g.K) ? *(const uint4*)(Ap + a_base[i] + k) : zero4;
+    } else if (AMODE == A_CONV_SMALLC) {
+      // Cin == 8: one 16-B chunk per tap
+      const int tap = kt * 8 + c;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int off = tap_offset(i, tap);
+        ra[i] = (off >= 0) ? *(const uint4*)(Ap + off) : zero4;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        ra[i] = (a_off[i] >= 0) ? *(const uint4*)(Ap + a_off[i] + ld_cin0 + c * 8) : zero4;
+      ld_cin0 += BK;
+      if (ld_cin0 >= g.Cin) {
+        ld_cin0 = 0;
+        ++ld_tap;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_off[i] = tap_offset(i, ld_tap);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BIT; ++i)
+      rb[i] = (b_base[i] >= 0 && k < g.K) ? *(const uint4*)(Bp + b_base[i] + k) : zero4;
+  };
+
+  auto store_tiles = [&](int buf) {
+    char* sa = smem + buf * (A_BYTES + B_BYTES);
+    char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(uint4*)(sa + (r0 + 32 * i) * 128 + cswz) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BIT; ++i) *(uint4*)(sb + (r0 + 32 * i) * 128 + cswz) = rb[i];
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  auto compute = [&](int buf) {
+    const char* sa = smem + buf * (A_BYTES + B_BYTES);
+    const char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[MT], bfr[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(sa + lds_off(wm * 64 + i * 16 + l15, kk * 4 + lq));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(sb + lds_off(wn * (BN / 2) + j * 16 + l15, kk * 4 + lq));
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if (kt_begin < kt_end) {
+    load_tiles(kt_begin);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const int buf = (kt - kt_begin) & 1;
+      const bool more = (kt + 1 < kt_end);
+      if (more) load_tiles(kt + 1);
+      compute(buf);
+      if (more) store_tiles(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue --------------------------------------------------------------------------------
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + l15;
+    if (m >= g.M) continue;
+    if (g.splitk > 1) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 16 + lq * 4;
+        if (n >= g.N) continue;
+        float* sl = g.slabs + ((int64_t)(ks * g.batch + z) * g.M + m) * g.N + n;
+        *(f32x4*)sl = acc[i][j];
+      }
+    } else if (g.act == ACT_GEGLU) {
+      if constexpr ((NT & 1) == 0) {
+#pragma unroll
+        for (int j = 0; j < NT; j += 2) {
+          const int nh = n0 + wn * (BN / 2) + j * 16 + lq * 4;
+          if (nh >= g.N) continue;
+          const int oc = (n0 >> 1) + wn * (BN / 4) + (j >> 1) * 16 + lq * 4;
+          epi_store_geglu(g, z, m, nh, oc, acc[i][j] * g.alpha, acc[i][j + 1] * g.alpha);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 16 + lq * 4;
+        if (n >= g.N) continue;
+        epi_store(g, z, m, n, acc[i][j] * g.alpha);
+      }
+    }
+  }
+}
+
+// sums the split-K slabs and applies the epilogue
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmArgs g) {
+  const int z = blockIdx.y;
+  const int n4 = g.N >> 2;
+  const int64_t total = (int64_t)g.M * n4;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(idx / n4);
+    const int n = (int)(idx - (int64_t)m * n4) * 4;
+    if (g.act == ACT_GEGLU) {
+      // packed columns: 16-wide tiles alternate h / gate.  Visit only h tiles.
+      if ((n >> 4) & 1) continue;
+      f32x4 h = {0, 0, 0, 0}, gt = {0, 0, 0, 0};
+      for (int s = 0; s < g.splitk; ++s) {
+        const float* sl = g.slabs + ((int64_t)(s * g.batch + z) * g.M + m) * g.N + n;
+        h += *(const f32x4*)sl;
+        gt += *(const f32x4*)(sl + 16);
+      }
+      const int oc = (n >> 5) * 16 + (n & 15);
+      epi_store_geglu(g, z, m, n, oc, h * g.alpha, gt * g.alpha);
+    } else {
+      f32x4 v = {0, 0, 0, 0};
+      for (int s = 0; s < g.splitk; ++s)
+        v += *(const f32x4*)(g.slabs + ((int64_t)(s * g.batch + z) * g.M + m) * g.N + n);
+      epi_store(g, z, m, n, v * g.alpha);
+    }
+  }
+}
+
+// ---- packing -------------------------------------------------------------------------------------
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, bf16* __restrict__ out, int O, int I, int Opad, int Ipad) {
+  int64_t total = (int64_t)Opad * 9 * Ipad;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int ci = (int)(idx % Ipad);
+    int t = (int)((idx / Ipad) % 9);
+    int o = (int)(idx / ((int64_t)Ipad * 9));
+    float v = (o < O && ci < I) ? w[((int64_t)o * I + ci) * 9 + t] : 0.f;
+    out[idx] = (bf16)v;
+  }
+}
+__global__ void pack_linear_kernel(const float* __restrict__ w, bf16* __restrict__ out, int N, int K, int Npad) {
+  int64_t total = (int64_t)Npad * K;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int n = (int)(idx / K);
+    out[idx] = (bf16)((n < N) ? w[idx] : 0.f);
+  }
+}
+__global__ void pack_geglu_kernel(const float* __restrict__ w, const float* __restrict__ b, bf16* __restrict__ wout,
+                                  float* __restrict__ bout, int F, int K) {
+  // packed row p: tile = p/16; pair = tile/2; which = tile&1 (0 h, 1 gate); src row = which*F + pair*16 + p%16
+  int64_t total = (int64_t)2 * F * K;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int p = (int)(idx / K), k = (int)(idx - (int64_t)p * K);
+    int tile = p >> 4, pair = tile >> 1, which = tile & 1;
+    int src = which * F + pair * 16 + (p & 15);
+    wout[idx] = (bf16)w[(int64_t)src * K + k];
+    if (k == 0 && b) bout[p] = b[src];
+  }
+}
+
+template <int BN, int AMODE>
+void launch_inst(const GemmArgs& g, dim3 grid, hipStream_t s) {
+  constexpr int smem = 2 * (BM * 128 + BN * 128);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_OK(hipFuncSetAttribute((const void*)igemm_kernel<BN, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((igemm_kernel<BN, AMODE>), grid, dim3(256), smem, s, g);
+}
+
+template <int BN>
+void launch_bn(const GemmArgs& g, dim3 grid, hipStream_t s) {
+  switch (g.amode) {
+    case A_DENSE: launch_inst<BN, A_DENSE>(g, grid, s); break;
+    case A_CONV_S1: launch_inst<BN, A_CONV_S1>(g, grid, s); break;
+    case A_CONV_S2P1: launch_inst<BN, A_CONV_S2P1>(g, grid, s); break;
+    case A_CONV_S2ASYM: launch_inst<BN, A_CONV_S2ASYM>(g, grid, s); break;
+    case A_CONV_UP2: launch_inst<BN, A_CONV_UP2>(g, grid, s); break;
+    case A_CONV_SMALLC: launch_inst<BN, A_CONV_SMALLC>(g, grid, s); break;
+    default: throw SvgError("bad amode");
+  }
+}
+
+int pick_bn(const GemmArgs& g) {
+  if (g.act == ACT_GEGLU) return 128;
+  if (g.N <= 32) return 32;
+  if (g.N <= 64) return 64;
+  if (g.N % 160 == 0 && g.N % 128 != 0) return 160;
+  if (g.N % 128 == 0) return 128;
+  // fewest wasted columns
+  int w128 = (g.N + 127) / 128 * 128 - g.N, w160 = (g.N + 159) / 160 * 160 - g.N;
+  return (w160 < w128) ? 160 : 128;
+}
+
+}  // namespace
+
+void launch_gemm(svg_ctx* ctx, const GemmArgs& g, hipStream_t s, int prof_kind) {
+  SVG_CHECK(g.N % 4 == 0 && g.K % 8 == 0, "gemm: N (%d) must be a multiple of 4 and K (%d) of 8", g.N, g.K);
+  SVG_CHECK(g.M > 0 && g.N > 0 && g.K > 0, "gemm: empty problem %d %d %d", g.M, g.N, g.K);
+  if (g.amode != A_DENSE) {
+    SVG_CHECK(g.amode == A_CONV_SMALLC ? (g.Cin == 8 && g.K == 72) : (g.Cin % 64 == 0 && g.K == 9 * g.Cin),
+              "conv: unsupported Cin %d / K %d for mode %d", g.Cin, g.K, g.amode);
+    SVG_CHECK((int64_t)g.M / (g.Ho * g.Wo) * g.H * g.W * g.Cin < (1LL << 31), "conv: input too large for 32-bit offsets");
+    SVG_CHECK(g.Ho < 32768 && g.Wo < 32768, "conv: spatial dims too large");
+    SVG_CHECK(g.batch == 1, "conv: batch must be folded into M");
+  } else {
+    SVG_CHECK((int64_t)g.M * g.lda < (1LL << 31) && g.lda % 8 == 0, "gemm: lda %d / M %d unsupported", g.lda, g.M);
+  }
+  SVG_CHECK((int64_t)g.N * g.ldb < (1LL << 31) && g.ldb % 8 == 0, "gemm: ldb %d unsupported", g.ldb);
+  if (g.act == ACT_GEGLU) SVG_CHECK(g.N % 128 == 0, "geglu: packed N must be a multiple of 128");
+  if (!SVG_LAUNCHING(ctx)) return;
+  const int bn = pick_bn(g);
+  const int tiles = cdiv(g.M, BM) * cdiv(g.N, bn);
+  dim3 grid(tiles, g.batch, g.splitk > 1 ? g.splitk : 1);
+  ProfScope ps(ctx, prof_kind, s, 2.0 * g.M * (double)g.N * g.K * g.batch,
+               2.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N) * g.batch);
+  GemmArgs a = g;
+  if (a.splitk < 1) a.splitk = 1;
+  if (a.n_valid <= 0) a.n_valid = a.N;
+  switch (bn) {
+    case 32: launch_bn<32>(a, grid, s); break;
+    case 64: launch_bn<64>(a, grid, s); break;
+    case 128: launch_bn<128>(a, grid, s); break;
+    default: launch_bn<160>(a, grid, s); break;
+  }
+  check_launch("igemm");
+  if (a.splitk > 1) {
+    int64_t total = (int64_t)a.M * (a.N / 4);
+    dim3 rg((unsigned)std::min<int64_t>((total + 255) / 256, 2048), a.batch);
+    hipLaunchKernelGGL(splitk_reduce_kernel, rg, dim3(256), 0, s, a);
+    check_launch("splitk_reduce");
+  }
+}
+
+void gemm_auto(svg_ctx* ctx, GemmArgs g, hipStream_t s, int prof_kind) {
+  const int bn = pick_bn(g);
+  const int64_t blocks = (int64_t)cdiv(g.M, BM) * cdiv(g.N, bn) * g.batch;
+  const int KT = cdiv(g.K, BK);
+  int sk = 1;
+  if (blocks < 192 && KT >= 8) {
+    sk = (int)std::min<int64_t>((384 + blocks - 1) / blocks, KT / 4);
+    sk = std::max(1, std::min(sk, 16));
+  }
+  g.splitk = sk;
+  if (sk > 1) {
+    ctx->arena.push();
+    g.slabs = ctx->arena.get<float>((int64_t)sk * g.batch * g.M * g.N);
+    launch_gemm(ctx, g, s, prof_kind);
+    ctx->arena.pop();   // stream order protects the slabs until the reduce has run
+  } else {
+    launch_gemm(ctx, g, s, prof_kind);
+  }
+}
+
+void pack_conv3x3(const float* w, bf16* out, int O, int I, int Opad, int Ipad, hipStream_t s) {
+  int64_t total = (int64_t)Opad * 9 * Ipad;
+  hipLaunchKernelGGL(pack_conv3x3_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, w, out, O, I, Opad, Ipad);
+  check_launch("pack_conv3x3");
+}
+void pack_linear(const float* w, bf16* out, int N, int K, int Npad, hipStream_t s) {
+  int64_t total = (int64_t)Npad * K;
+  hipLaunchKernelGGL(pack_linear_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, w, out, N, K, Npad);
+  check_launch("pack_linear");
+}
+void pack_geglu(const float* w, const float* b, bf16* wout, float* bout, int F, int K, hipStream_t s) {
+  int64_t total = (int64_t)2 * F * K;
+  hipLaunchKernelGGL(pack_geglu_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, w, b, wout, bout, F, K);
+  check_launch("pack_geglu");
+}

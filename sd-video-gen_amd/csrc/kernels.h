@@ -1,0 +1,131 @@
+// Host-callable launchers of every HIP kernel family (gfx950).
+#pragma once
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// MFMA implicit GEMM:  C[M,N] = epi( A[M,K] * Wt[N,K]^T )
+//   A is either a dense row-major bf16 matrix or a gathered 3x3-conv window of an NHWC tensor.
+// ------------------------------------------------------------------------------------------------
+enum AMode { A_DENSE = 0, A_CONV_S1 = 1, A_CONV_S2P1 = 2, A_CONV_S2ASYM = 3, A_CONV_UP2 = 4, A_CONV_SMALLC = 5 };
+enum Act { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2, ACT_GEGLU = 3 };
+
+struct GemmArgs {
+  // A operand
+  const bf16* A = nullptr;
+  int amode = A_DENSE;
+  int lda = 0;                   // dense: row stride (elements)
+  int H = 0, W = 0, Cin = 0;     // conv: input dims (NHWC)
+  int Ho = 0, Wo = 0;            // conv: output dims
+  // B operand (weights [N][K], K contiguous)
+  const bf16* Wt = nullptr;
+  int ldb = 0;
+  int n_valid = 0;               // rows of Wt that exist (<= N); rows beyond read as zero
+  // C
+  void* C = nullptr;
+  int ldc = 0;
+  int M = 0, N = 0, K = 0;       // N multiple of 4, K multiple of 8
+  // batch (grid.y)
+  int batch = 1;
+  int64_t sA = 0, sB = 0, sC = 0;
+  // epilogue
+  float alpha = 1.f;
+  const float* bias = nullptr;       // [N] (or [M] when bias_row)
+  int bias_row = 0;
+  const float* bias_bn = nullptr;    // [M/rows_per_batch][N] per-sample column bias (time embedding)
+  int rows_per_batch = 1;
+  int bias_bn_ld = 0;                // row stride of bias_bn (0 = N)
+  const bf16* residual = nullptr;    // [M][ldr]
+  int ldr = 0;
+  int act = ACT_NONE;
+  int out_f32 = 0;
+  // split-K (0/1 = off). slabs: f32 [splitk][M][N] workspace
+  int splitk = 1;
+  float* slabs = nullptr;
+};
+
+void launch_gemm(svg_ctx* ctx, const GemmArgs& g, hipStream_t s, int prof_kind);
+// picks split-K from the shape, allocates slabs from the arena, launches
+void gemm_auto(svg_ctx* ctx, GemmArgs g, hipStream_t s, int prof_kind);
+
+// weight packing (device): f32 OIHW -> bf16 [Opad][ky][kx][Ipad]; f32 [N][K] -> bf16 [Npad][K]
+void pack_conv3x3(const float* w_oihw, bf16* out, int O, int I, int Opad, int Ipad, hipStream_t s);
+void pack_linear(const float* w, bf16* out, int N, int K, int Npad, hipStream_t s);
+// GEGLU: rows [h(0..F-1); gate(0..F-1)] -> 16-row tiles alternating h / gate; bias likewise
+void pack_geglu(const float* w, const float* b, bf16* wout, float* bout, int F, int K, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// normalisation / softmax
+// ------------------------------------------------------------------------------------------------
+// x (B,HW,C) bf16 NHWC; optional second source for channel concat [x | x2] (C = C1 + C2)
+void groupnorm(svg_ctx* ctx, const bf16* x, int C1, const bf16* x2, int C2, const float* gamma,
+               const float* beta, bf16* out, int B, int HW, int groups, float eps, int silu,
+               hipStream_t s);
+void layernorm(svg_ctx* ctx, const bf16* x, const float* gamma, const float* beta, bf16* out, int M,
+               int C, float eps, hipStream_t s);
+// rows of f32 scores -> bf16 probabilities; cols valid < n_valid, row stride ld (elements)
+void softmax_rows(svg_ctx* ctx, const float* s_in, bf16* p_out, int64_t rows, int cols, int ld_in,
+                  int ld_out, float scale, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// fused attention
+// ------------------------------------------------------------------------------------------------
+struct AttnArgs {
+  const bf16 *q, *k, *vt;
+  bf16* out;
+  int B, heads, Sq, Skv, d;
+  int ldq, ldk, ldvt, ldo;
+  int64_t qb, kb, vtb, ob;       // batch strides (elements)
+  float scale;
+};
+void attention(svg_ctx* ctx, const AttnArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// element-wise / layout
+// ------------------------------------------------------------------------------------------------
+// u8 NHWC (N,sh,sw,3) -> bf16 NHWC (N,H,W,8) with nearest resize, x/255*2-1, channels 3..7 zero
+void img_to_act(const uint8_t* img, bf16* out, int N, int sh, int sw, int H, int W, hipStream_t s);
+// f32 NHWC (N,h,w,ldc) first 3 channels -> optional f32 NCHW + u8 NHWC (N,oh,ow,3) nearest resized:
+// (x/2+.5).clamp(0,1)*255 round-half-even
+void act_to_img(const float* x, int ldc, uint8_t* img, float* fout, int N, int h, int w, int oh, int ow,
+                hipStream_t s);
+// f32 NCHW (N,C,h,w) * scale -> bf16 NHWC (N,h,w,Cpad)
+void nchw_to_act(const float* x, bf16* out, int N, int C, int h, int w, int Cpad, float scale, hipStream_t s);
+// f32 NCHW -> f32 NHWC (scaled); f32 NHWC (P,C) -> bf16 (P,Cpad) zero padded
+void nchw_to_actf32(const float* x, float* out, int N, int C, int h, int w, float scale, hipStream_t s);
+void actf32_pad_bf16(const float* x, int C, bf16* out, int Cpad, int64_t P, hipStream_t s);
+// f32 NHWC-ish source (N,h,w,ld) f32 -> f32 NCHW (N,C,h,w)
+void actf32_to_nchw(const float* x, int ld, float* out, int N, int C, int h, int w, hipStream_t s);
+// per-pixel 1x1 conv with tiny channel counts, f32: y[p][o] = sum_i w[o][i] x[p][i] + b[o]
+void pixel_linear_f32(const float* x, int ldx, const float* w, const float* b, float* y, int ldy,
+                      int64_t P, int Cin, int Cout, hipStream_t s);
+// VAE posterior sample: moments f32 (P,8) [mean(4); logvar(4)] -> z NCHW f32 = (mean + exp(.5*clamp(lv))*eps)*0.18215
+void vae_sample(const float* mom, int ldm, const float* eps_nchw, float* z_nchw, float* mom_nchw, int N,
+                int h, int w, hipStream_t s);
+void concat_channels(const bf16* a, int Ca, const bf16* b, int Cb, bf16* out, int64_t P, hipStream_t s);
+void resize_nearest_u8(const uint8_t* src, uint8_t* dst, int N, int sh, int sw, int C, int dh, int dw,
+                       hipStream_t s);
+void f32_to_bf16(const float* x, bf16* y, int64_t n, hipStream_t s);
+void bf16_to_f32(const bf16* x, float* y, int64_t n, hipStream_t s);
+// timestep sinusoid (flip_sin_to_cos, shift 0): t f32[N] -> bf16 (N,dim) = [cos | sin]
+void timestep_embed(const float* t, bf16* out, int N, int dim, hipStream_t s);
+void silu_bf16(const bf16* x, bf16* y, int64_t n, hipStream_t s);
+// DDIM: z <- step(z, eps) with clip_sample; coefficients from the device table `coef` row `*step_idx`
+void ddim_step(const float* z, const float* eps_u, const float* eps_c, float guidance, float* z_out,
+               int64_t n, float sqrt_at, float sqrt_1mat, float sqrt_ap, float sqrt_1map, hipStream_t s);
+void add_noise(const float* x0, const float* noise, float* out, int64_t n, float sa, float s1a, hipStream_t s);
+void fill_f32(float* p, int64_t n, float v, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// latent Transformer (f32, f32-input MFMA)
+// ------------------------------------------------------------------------------------------------
+void xf_gemm(svg_ctx* ctx, const float* X, const float* W, const float* bias, float* Y, int M, int N,
+             int K, int relu_in, hipStream_t s);
+// y = LayerNorm(x + r) rows of d
+void xf_add_ln(const float* x, const float* r, const float* g, const float* b, float* y, int M, int d,
+               float eps, hipStream_t s);
+// emb (B*T,d) -> (T,B,d): y[t][b] = emb[b][t]*sqrt(d) + pe[pe_row[b]]
+void xf_embed_post(const float* emb, const float* pe, const int32_t* pe_row, float* y, int B, int T, int d,
+                   float scale, hipStream_t s);
+// seq-first MHA core on packed projections: q (Tq,B,ldq) k,v (Tk,B,ldk) -> o (Tq,B,d); mask (Tq,Tk) or null
+void xf_attention(const float* q, int ldq, const float* k, const float* v, int ldk, const float* mask,
+                  float* o, int Tq, int Tk, int B, int heads, int hd, hipStream_t s);

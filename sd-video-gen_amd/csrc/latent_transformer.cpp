@@ -1,0 +1,195 @@
+// Latent-sequence Transformer graph (reference: models/transformer.py:47-68 over torch.nn.Transformer
+// defaults — post-norm, ReLU, final encoder/decoder LayerNorm, sequence-first).  f32 throughout.
+#include "models.h"
+#include "../../include/svg_hip.h"
+
+void XfModel::configure(const char* kv) {
+  auto m = parse_kv(kv);
+  auto geti = [&](const char* k, int& dst) { if (m.count(k)) dst = (int)m[k][0]; };
+  geti("d_lat", d_lat); geti("d_model", d_model); geti("heads", heads);
+  geti("enc_layers", enc_layers); geti("dec_layers", dec_layers); geti("ffn", ffn);
+  ready = false;
+}
+
+void XfModel::finalize(svg_ctx* ctx, int64_t* n_params) {
+  SVG_CHECK(d_lat > 0 && d_model > 0 && heads > 0, "transformer: configure d_lat/d_model/heads first");
+  SVG_CHECK(d_model % heads == 0 && d_model % 16 == 0 && d_lat % 16 == 0 && ffn % 16 == 0,
+            "transformer: d_model %d / d_lat %d / ffn %d must be multiples of 16 (and d_model of heads)", d_model, d_lat, ffn);
+  const int64_t d = d_model;
+  ws.get("embedding.weight", {d, d_lat}); ws.get("embedding.bias", {d});
+  ws.get("out.weight", {d_lat, d}); ws.get("out.bias", {d_lat});
+  auto check_mha = [&](const std::string& p) {
+    ws.get(p + "in_proj_weight", {3 * d, d}); ws.get(p + "in_proj_bias", {3 * d});
+    ws.get(p + "out_proj.weight", {d, d}); ws.get(p + "out_proj.bias", {d});
+  };
+  auto check_ffn_norms = [&](const std::string& p, int nnorm) {
+    ws.get(p + "linear1.weight", {ffn, d}); ws.get(p + "linear1.bias", {ffn});
+    ws.get(p + "linear2.weight", {d, ffn}); ws.get(p + "linear2.bias", {d});
+    for (int i = 1; i <= nnorm; ++i) {
+      ws.get(p + "norm" + std::to_string(i) + ".weight", {d});
+      ws.get(p + "norm" + std::to_string(i) + ".bias", {d});
+    }
+  };
+  for (int i = 0; i < enc_layers; ++i) {
+    std::string p = "transformer.encoder.layers." + std::to_string(i) + ".";
+    check_mha(p + "self_attn."); check_ffn_norms(p, 2);
+  }
+  for (int i = 0; i < dec_layers; ++i) {
+    std::string p = "transformer.decoder.layers." + std::to_string(i) + ".";
+    check_mha(p + "self_attn."); check_mha(p + "multihead_attn."); check_ffn_norms(p, 3);
+  }
+  ws.get("transformer.encoder.norm.weight", {d}); ws.get("transformer.encoder.norm.bias", {d});
+  ws.get("transformer.decoder.norm.weight", {d}); ws.get("transformer.decoder.norm.bias", {d});
+  // positional table (models/positional_encoding.py:16-30): use the state_dict buffer when it was handed
+  // over, else build it — sin/cos in double, rounded to f32.
+  if (!pe) pe = (float*)ctx->dalloc(64 * d * sizeof(float));
+  if (ws.has("positional_encoder.pos_encoding")) {
+    const Weight& w = ws.get("positional_encoder.pos_encoding");
+    SVG_CHECK(w.numel == 64 * d, "positional_encoder.pos_encoding has %lld elements", (long long)w.numel);
+    HIP_OK(hipMemcpy(pe, w.f32, 64 * d * sizeof(float), hipMemcpyDeviceToDevice));
+  } else {
+    std::vector<float> h(64 * d);
+    for (int pos = 0; pos < 64; ++pos)
+      for (int i = 0; i < d; i += 2) {
+        float div = expf((float)i * (-logf(10000.0f)) / (float)d);
+        h[pos * d + i] = sinf((float)pos * div);
+        if (i + 1 < d) h[pos * d + i + 1] = cosf((float)pos * div);
+      }
+    HIP_OK(hipMemcpy(pe, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  if (!iota) {
+    iota = (int32_t*)ctx->dalloc(64 * sizeof(int32_t));
+    int32_t h[64];
+    for (int i = 0; i < 64; ++i) h[i] = i;
+    HIP_OK(hipMemcpy(iota, h, sizeof(h), hipMemcpyHostToDevice));
+  }
+  int64_t n = 0;
+  for (auto& kv : ws.map)
+    if (kv.first != "positional_encoder.pos_encoding") n += kv.second.numel;
+  if (n_params) *n_params = n;
+  ready = true;
+}
+
+namespace {
+struct XfRun {
+  svg_ctx* ctx; XfModel* m; hipStream_t s; int B;
+  const float* W(const std::string& n) { return m->ws.get(n).f32; }
+  float* gemm(const float* X, const std::string& w, const std::string& b, int M, int N, int K, int relu_in = 0,
+              int64_t woff = 0, int64_t boff = 0) {
+    float* Y = ctx->arena.get<float>((int64_t)M * N);
+    if (SVG_LAUNCHING(ctx)) xf_gemm(ctx, X, W(w) + woff, W(b) + boff, Y, M, N, K, relu_in, s);
+    return Y;
+  }
+  float* add_ln(const float* x, const float* r, const std::string& p, int M) {
+    float* y = ctx->arena.get<float>((int64_t)M * m->d_model);
+    if (SVG_LAUNCHING(ctx)) {
+      ProfScope ps(ctx, PK_XF_MISC, s, 0, 12.0 * M * m->d_model);
+      xf_add_ln(x, r, W(p + "weight"), W(p + "bias"), y, M, m->d_model, 1e-5f, s);
+    }
+    return y;
+  }
+  float* mha(const std::string& p, const float* xq, int Tq, const float* xkv, int Tk, const float* mask, bool self) {
+    const int d = m->d_model, hd = d / m->heads;
+    float* o = ctx->arena.get<float>((int64_t)Tq * B * d);
+    if (self) {
+      float* qkv = gemm(xq, p + "in_proj_weight", p + "in_proj_bias", Tq * B, 3 * d, d);
+      if (SVG_LAUNCHING(ctx)) {
+        ProfScope ps(ctx, PK_XF_MISC, s, 0, 0);
+        xf_attention(qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, mask, o, Tq, Tk, B, m->heads, hd, s);
+      }
+    } else {
+      float* q = gemm(xq, p + "in_proj_weight", p + "in_proj_bias", Tq * B, d, d);
+      float* kv = gemm(xkv, p + "in_proj_weight", p + "in_proj_bias", Tk * B, 2 * d, d, 0, (int64_t)d * d, d);
+      if (SVG_LAUNCHING(ctx)) {
+        ProfScope ps(ctx, PK_XF_MISC, s, 0, 0);
+        xf_attention(q, d, kv, kv + d, 2 * d, mask, o, Tq, Tk, B, m->heads, hd, s);
+      }
+    }
+    return gemm(o, p + "out_proj.weight", p + "out_proj.bias", Tq * B, d, d);
+  }
+  float* ffn(const std::string& p, const float* x, int M) {
+    float* h = gemm(x, p + "linear1.weight", p + "linear1.bias", M, m->ffn, m->d_model);
+    return gemm(h, p + "linear2.weight", p + "linear2.bias", M, m->d_model, m->ffn, /*relu_in=*/1);
+  }
+  float* embed(const float* x, int T, const int32_t* pe_row) {
+    const int d = m->d_model;
+    float* e = gemm(x, "embedding.weight", "embedding.bias", B * T, d, m->d_lat);
+    float* y = ctx->arena.get<float>((int64_t)B * T * d);
+    if (SVG_LAUNCHING(ctx)) {
+      ProfScope ps(ctx, PK_XF_MISC, s, 0, 8.0 * B * T * d);
+      xf_embed_post(e, m->pe, pe_row, y, B, T, d, sqrtf((float)d), s);
+    }
+    return y;
+  }
+};
+}  // namespace
+
+// One chunk of batch rows (B*max(Ts,Tt) <= 64).  pe_row must be non-null here.
+static void xf_forward_chunk(svg_ctx* ctx, XfModel* m, const float* src, const float* tgt, int B, int Ts, int Tt,
+                             const float* mask, const int32_t* pe_row, float* out_tb, hipStream_t s) {
+  XfRun r{ctx, m, s, B};
+  float* xs = r.embed(src, Ts, pe_row);
+  float* xt = (tgt == src && Ts == Tt) ? xs : r.embed(tgt, Tt, pe_row);
+  const int Ms = Ts * B, Mt = Tt * B;
+  for (int i = 0; i < m->enc_layers; ++i) {
+    std::string p = "transformer.encoder.layers." + std::to_string(i) + ".";
+    xs = r.add_ln(xs, r.mha(p + "self_attn.", xs, Ts, xs, Ts, nullptr, true), p + "norm1.", Ms);
+    xs = r.add_ln(xs, r.ffn(p, xs, Ms), p + "norm2.", Ms);
+  }
+  float* mem = r.add_ln(xs, nullptr, "transformer.encoder.norm.", Ms);
+  for (int i = 0; i < m->dec_layers; ++i) {
+    std::string p = "transformer.decoder.layers." + std::to_string(i) + ".";
+    xt = r.add_ln(xt, r.mha(p + "self_attn.", xt, Tt, xt, Tt, mask, true), p + "norm1.", Mt);
+    xt = r.add_ln(xt, r.mha(p + "multihead_attn.", xt, Tt, mem, Ts, nullptr, false), p + "norm2.", Mt);
+    xt = r.add_ln(xt, r.ffn(p, xt, Mt), p + "norm3.", Mt);
+  }
+  xt = r.add_ln(xt, nullptr, "transformer.decoder.norm.", Mt);
+  if (SVG_LAUNCHING(ctx)) xf_gemm(ctx, xt, r.W("out.weight"), r.W("out.bias"), out_tb, Mt, m->d_lat, m->d_model, 0, s);
+}
+
+void XfModel::forward(svg_ctx* ctx, const float* src, const float* tgt, int B, int Ts, int Tt, const float* mask,
+                      const int32_t* pe_row, float* out, hipStream_t s) {
+  SVG_CHECK(ready, "transformer: svg_finalize has not been called");
+  SVG_CHECK(B >= 1 && Ts >= 1 && Tt >= 1 && Ts <= 16 && Tt <= 16, "transformer: B=%d Ts=%d Tt=%d unsupported", B, Ts, Tt);
+  SVG_CHECK(pe_row || B <= 64, "transformer: batch %d > max_len 64 of the positional table", B);
+  const int Tmax = std::max(Ts, Tt);
+  const int Bc = std::max(1, 64 / Tmax);
+  run_planned(ctx, [&]() {
+    // PE rows: the reference indexes the table by batch row (positional_encoding.py:33-35)
+    const int32_t* rows = iota;
+    if (pe_row) {
+      int32_t* r = ctx->arena.get<int32_t>(B);
+      if (SVG_LAUNCHING(ctx)) HIP_OK(hipMemcpyAsync(r, pe_row, B * sizeof(int32_t), hipMemcpyDefault, s));
+      rows = r;
+    }
+    if (B <= Bc) {
+      xf_forward_chunk(ctx, this, src, tgt, B, Ts, Tt, mask, rows, out, s);
+    } else {
+      for (int b0 = 0; b0 < B; b0 += Bc) {
+        const int bc = std::min(Bc, B - b0);
+        ctx->arena.push();
+        float* tmp = ctx->arena.get<float>((int64_t)Tt * bc * d_lat);
+        const float* srcc = src + (int64_t)b0 * Ts * d_lat;
+        const float* tgtc = (tgt == src) ? srcc : tgt + (int64_t)b0 * Tt * d_lat;
+        xf_forward_chunk(ctx, this, srcc, tgtc, bc, Ts, Tt, mask, rows + b0, tmp, s);
+        if (SVG_LAUNCHING(ctx))
+          HIP_OK(hipMemcpy2DAsync(out + (int64_t)b0 * d_lat, (size_t)B * d_lat * sizeof(float), tmp,
+                                  (size_t)bc * d_lat * sizeof(float), (size_t)bc * d_lat * sizeof(float), Tt,
+                                  hipMemcpyDeviceToDevice, s));
+        ctx->arena.pop();
+      }
+    }
+  });
+}
+
+extern "C" int svg_transformer_forward(svg_ctx* ctx, const float* src, const float* tgt, int B, int Ts, int Tt, const float* mask,
+                                       const int32_t* pe_row, float* out, void* stream) {
+  try {
+    SVG_CHECK(ctx && ctx->xf, "transformer: model not configured");
+    ctx->xf->forward(ctx, src, tgt, B, Ts, Tt, mask, pe_row, out, (hipStream_t)stream);
+    return 0;
+  } catch (const std::exception& e) {
+    if (ctx) ctx->err = e.what();
+    return -1;
+  }
+}

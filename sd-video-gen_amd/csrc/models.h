@@ -1,0 +1,122 @@
+// Model graphs executed by the library: latent Transformer, SD VAE, SD UNet, DDIM loop.
+#pragma once
+#include "kernels.h"
+#include <initializer_list>
+#include <memory>
+
+struct WeightStore {
+  std::unordered_map<std::string, Weight> map;
+  void put(svg_ctx* ctx, const std::string& name, const float* data, const int64_t* shape, int ndim);
+  const Weight& get(const std::string& name) const;
+  const Weight& get(const std::string& name, std::initializer_list<int64_t> shape) const;
+  bool has(const std::string& name) const { return map.count(name) != 0; }
+  void release(const std::string& name);   // frees the f32 copy (after packing)
+  void clear();
+  int64_t total_params() const;
+};
+
+std::unordered_map<std::string, std::vector<int64_t>> parse_kv(const char* kv);
+
+// Plans a call twice: a dry pass measures the arena high-water mark, then the real pass launches.
+template <typename F>
+inline void run_planned(svg_ctx* ctx, F&& body) {
+  ctx->arena.reset();
+  ctx->arena.dry = true;
+  ctx->arena.high = 0;
+  try { body(); } catch (...) { ctx->arena.dry = false; throw; }
+  ctx->arena.dry = false;
+  ctx->ensure_arena(ctx->arena.high);
+  ctx->arena.reset();
+  body();
+}
+
+// packed bf16 weight matrix [N][K] (+ f32 bias)
+struct PackedLinear {
+  bf16* w = nullptr;
+  float* b = nullptr;
+  int N = 0, K = 0, n_valid = 0;
+};
+
+// ---- latent Transformer ------------------------------------------------------------------------------
+struct XfModel {
+  WeightStore ws;
+  int d_lat = 0, d_model = 0, heads = 8, enc_layers = 0, dec_layers = 0, ffn = 2048;
+  bool ready = false;
+  float* pe = nullptr;   // (64, d_model)
+  int32_t* iota = nullptr;
+  void configure(const char* kv);
+  void finalize(svg_ctx* ctx, int64_t* n_params);
+  void forward(svg_ctx* ctx, const float* src, const float* tgt, int B, int Ts, int Tt, const float* mask,
+               const int32_t* pe_row, float* out, hipStream_t s);
+};
+
+// ---- SD VAE -------------------------------------------------------------------------------------------
+struct ConvW { bf16* w = nullptr; float* b = nullptr; int Cin = 0, Cout = 0, Opad = 0; };
+struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
+struct ResW { NormW n1, n2; ConvW c1, c2; PackedLinear sc; bool has_sc = false; int temb_off = -1; };
+struct VaeAttnW { NormW gn; PackedLinear qk, v, proj; int C = 0; };
+
+struct VaeModel {
+  WeightStore ws;
+  std::vector<int> block_out{128, 256, 512, 512};
+  int layers = 2, groups = 32, latent = 4;
+  bool ready = false;
+  // encoder
+  ConvW e_conv_in, e_conv_out;
+  std::vector<std::vector<ResW>> e_down; std::vector<ConvW> e_downs;
+  ResW e_mid0, e_mid1; VaeAttnW e_attn; NormW e_norm_out;
+  float *quant_w = nullptr, *quant_b = nullptr, *pquant_w = nullptr, *pquant_b = nullptr;
+  // decoder
+  ConvW d_conv_in, d_conv_out;
+  std::vector<std::vector<ResW>> d_up; std::vector<ConvW> d_ups;
+  ResW d_mid0, d_mid1; VaeAttnW d_attn; NormW d_norm_out;
+  void configure(const char* kv);
+  void finalize(svg_ctx* ctx, int64_t* n_params);
+  void encode(svg_ctx* ctx, const uint8_t* img, int N, int srcH, int srcW, int H, int W, const float* eps, float* z_out,
+              float* moments_out, hipStream_t s);
+  void decode(svg_ctx* ctx, const float* z, int N, int h, int w, uint8_t* img_out, int outH, int outW, float* float_out,
+              hipStream_t s);
+};
+
+// ---- SD UNet --------------------------------------------------------------------------------------------
+struct XfBlockW {   // SpatialTransformer with one BasicTransformerBlock
+  NormW gn, ln1, ln2, ln3;
+  PackedLinear proj_in, proj_out, qk1, v1, o1, q2, k2, v2, o2, ff1, ff2;
+  int C = 0;
+};
+struct UnetModel {
+  WeightStore ws;
+  std::vector<int> block_out{320, 640, 1280, 1280};
+  std::vector<int> attn{1, 1, 1, 0};
+  int layers = 2, heads = 8, ctx_dim = 768, groups = 32, in_ch = 4, out_ch = 4;
+  bool ready = false;
+  int temb_dim = 0;
+  PackedLinear time1, time2, temb_all;     // temb_all: every resnet's time_emb_proj stacked [sum Cout][temb_dim]
+  ConvW conv_in, conv_out; NormW norm_out;
+  std::vector<std::vector<ResW>> down_res; std::vector<std::vector<XfBlockW>> down_attn; std::vector<ConvW> down_s;
+  ResW mid0, mid1; XfBlockW mid_attn;
+  std::vector<std::vector<ResW>> up_res; std::vector<std::vector<XfBlockW>> up_attn; std::vector<ConvW> up_s;
+  // DDIM tables (scaled_linear 0.00085..0.012, 1000 train steps)
+  std::vector<float> alphas_cumprod;
+  void configure(const char* kv);
+  void finalize(svg_ctx* ctx, int64_t* n_params);
+  void forward(svg_ctx* ctx, const float* x, int N, int h, int w, const float* timesteps, const float* ctx_emb, int ctx_len,
+               float* eps_out, hipStream_t s);
+  void ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const float* text_emb, int ctx_len, int num_steps,
+                 int start_step, float guidance, const float* noise, float* hist, hipStream_t s);
+  void ddim_coefs(int t, int t_prev, float* sa, float* s1a, float* sap, float* s1ap) const;
+};
+
+void destroy_models(svg_ctx* ctx);
+
+// shared graph pieces (sdnet.cpp)
+ConvW load_conv3x3(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int Cin, int Cout, hipStream_t s);
+PackedLinear load_linear(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int N, int K, bool bias, hipStream_t s);
+NormW load_norm(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int C);
+float* keep_f32(svg_ctx* ctx, WeightStore& ws, const std::string& name, int64_t numel);
+// out (B,Ho,Wo,Cout) = conv3x3(x) + bias [+ per-sample bias] [+ residual]
+void conv3x3(svg_ctx* ctx, const bf16* x, const ConvW& cw, void* out, int B, int H, int W, int amode, const float* bias_bn,
+             int bias_bn_ld, const bf16* residual, int out_f32, hipStream_t s);
+// C[M,N] = act(A[M,K] W^T + b) [+ residual]
+void linear(svg_ctx* ctx, const bf16* A, int lda, const PackedLinear& pl, void* C, int ldc, int M, int act, const bf16* residual,
+            int ldr, int out_f32, hipStream_t s);

@@ -1,0 +1,234 @@
+// GroupNorm (+SiLU) on NHWC bf16, LayerNorm over rows, row softmax.  HBM-bound: 16-B vector
+// loads/stores, f32 statistics, wave-shuffle reductions.
+#include "kernels.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// ---- GroupNorm stage 1: per (sample, pixel-chunk) partial sums per channel-group ----------------
+// grid (nchunk, B); block = CV*PL threads where CV = C/8 channel vectors, PL pixel lanes.
+// partial[b][chunk][group][2]
+__global__ void gn_stats_kernel(const bf16* __restrict__ x, int C1, const bf16* __restrict__ x2, int C2,
+                                float* __restrict__ partial, int HW, int groups, int nchunk, int CV, int PL) {
+  extern __shared__ float sh[];   // [PL][C][2] then reused
+  const int C = C1 + C2;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int pix_per_chunk = (HW + nchunk - 1) / nchunk;
+  const int p_begin = chunk * pix_per_chunk;
+  const int p_end = min(HW, p_begin + pix_per_chunk);
+  float s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+  const int nthr = CV * PL;
+  if (tid < nthr) {
+    const int cv = tid % CV, pl = tid / CV;
+    const int c0 = cv * 8;
+    const bf16* src; int ld, coff;
+    if (c0 < C1) { src = x; ld = C1; coff = c0; } else { src = x2; ld = C2; coff = c0 - C1; }
+    for (int p = p_begin + pl; p < p_end; p += PL) {
+      bf16x8 v = *(const bf16x8*)(src + ((int64_t)b * HW + p) * ld + coff);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float f = (float)v[j]; s[j] += f; q[j] += f * f; }
+    }
+    float* dst = sh + ((int64_t)pl * C + c0) * 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dst[2 * j] = s[j]; dst[2 * j + 1] = q[j]; }
+  }
+  __syncthreads();
+  // reduce over pixel lanes and over the channels of each group
+  const int cpg = C / groups;
+  for (int g = tid; g < groups; g += blockDim.x) {
+    float ss = 0.f, qq = 0.f;
+    for (int pl = 0; pl < PL; ++pl)
+      for (int cc = 0; cc < cpg; ++cc) {
+        const float* e = sh + ((int64_t)pl * C + g * cpg + cc) * 2;
+        ss += e[0]; qq += e[1];
+      }
+    float* o = partial + (((int64_t)b * nchunk + chunk) * groups + g) * 2;
+    o[0] = ss; o[1] = qq;
+  }
+}
+
+// ---- GroupNorm stage 2: finish the statistics, normalise, affine, optional SiLU ------------------
+// grid (nblk, B); each block handles a contiguous range of pixels of one sample.
+__global__ void __launch_bounds__(256) gn_apply_kernel(const bf16* __restrict__ x, int C1, const bf16* __restrict__ x2, int C2,
+                                const float* __restrict__ partial, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, bf16* __restrict__ out, int HW, int groups,
+                                int nchunk, float eps, int silu) {
+  __shared__ float mean_s[64], rstd_s[64];
+  const int C = C1 + C2;
+  const int b = blockIdx.y;
+  const int cpg = C / groups;
+  for (int g = threadIdx.x; g < groups; g += blockDim.x) {
+    float ss = 0.f, qq = 0.f;
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const float* e = partial + (((int64_t)b * nchunk + ch) * groups + g) * 2;
+      ss += e[0]; qq += e[1];
+    }
+    const float n = (float)cpg * (float)HW;
+    const float mean = ss / n;
+    const float var = fmaxf(qq / n - mean * mean, 0.f);
+    mean_s[g] = mean;
+    rstd_s[g] = rsqrtf(var + eps);
+  }
+  __syncthreads();
+  const int CV = C / 8;
+  const int64_t total = (int64_t)HW * CV;
+  const int64_t per_blk = (total + gridDim.x - 1) / gridDim.x;
+  const int64_t begin = blockIdx.x * per_blk, end = min(total, begin + per_blk);
+  for (int64_t idx = begin + threadIdx.x; idx < end; idx += blockDim.x) {
+    const int cv = (int)(idx % CV);
+    const int64_t p = idx / CV;
+    const int c0 = cv * 8;
+    const bf16* src; int ld, coff;
+    if (c0 < C1) { src = x; ld = C1; coff = c0; } else { src = x2; ld = C2; coff = c0 - C1; }
+    bf16x8 v = *(const bf16x8*)(src + ((int64_t)b * HW + p) * ld + coff);
+    bf16x8 o;
+    int g = c0 / cpg, rem = c0 - g * cpg;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int cc = c0 + j;
+      if (rem == cpg) { rem = 0; ++g; }
+      ++rem;
+      float f = ((float)v[j] - mean_s[g]) * rstd_s[g] * gamma[cc] + beta[cc];
+      if (silu) f = f / (1.f + __expf(-f));
+      o[j] = (bf16)f;
+    }
+    *(bf16x8*)(out + ((int64_t)b * HW + p) * C + c0) = o;
+  }
+}
+
+// ---- LayerNorm: one wave per row -------------------------------------------------------------------
+__global__ void __launch_bounds__(256) layernorm_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, bf16* __restrict__ out, int M, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int CV = C / 8;
+  const bf16* xr = x + (int64_t)row * C;
+  // C <= 8*64*4 = 2048: up to 4 vectors per lane
+  bf16x8 v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cv = lane + 64 * i;
+    if (cv < CV) {
+      v[i] = *(const bf16x8*)(xr + cv * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (float)v[i][j];
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cv = lane + 64 * i;
+    if (cv < CV) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float d = (float)v[i][j] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cv = lane + 64 * i;
+    if (cv < CV) {
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int cc = cv * 8 + j;
+        o[j] = (bf16)(((float)v[i][j] - mean) * rstd * gamma[cc] + beta[cc]);
+      }
+      *(bf16x8*)(out + (int64_t)row * C + cv * 8) = o;
+    }
+  }
+}
+
+// ---- row softmax: f32 scores -> bf16 probabilities, one block per row ------------------------------
+__global__ void __launch_bounds__(256) softmax_rows_kernel(const float* __restrict__ sin, bf16* __restrict__ pout, int cols,
+                                    int ld_in, int ld_out, float scale) {
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const float* sr = sin + row * ld_in;
+  float mx = -INFINITY;
+  for (int c = threadIdx.x; c < cols; c += 256) mx = fmaxf(mx, sr[c] * scale);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int c = threadIdx.x; c < cols; c += 256) sum += __expf(sr[c] * scale - mx);
+  sum = wave_sum(sum);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
+  bf16* pr = pout + row * ld_out;
+  for (int c = threadIdx.x; c < ld_out; c += 256) pr[c] = (bf16)((c < cols) ? __expf(sr[c] * scale - mx) * inv : 0.f);
+}
+
+}  // namespace
+
+void groupnorm(svg_ctx* ctx, const bf16* x, int C1, const bf16* x2, int C2, const float* gamma, const float* beta,
+               bf16* out, int B, int HW, int groups, float eps, int silu, hipStream_t s) {
+  const int C = C1 + C2;
+  SVG_CHECK(C % groups == 0 && C % 8 == 0 && C1 % 8 == 0 && groups <= 64, "groupnorm: C=%d groups=%d unsupported", C, groups);
+  const int CV = C / 8;
+  SVG_CHECK(CV <= 1024, "groupnorm: C too large");
+  const int PL = std::max(1, 256 / CV);
+  int nchunk = std::max(1, std::min(64, HW / (PL * 8)));
+  // enough blocks to fill the chip at small batch
+  while (nchunk * 2 <= 64 && (int64_t)nchunk * B < 512 && HW / (nchunk * 2) >= PL * 2) nchunk *= 2;
+  ctx->arena.push();
+  float* partial = ctx->arena.get<float>((int64_t)B * nchunk * groups * 2);
+  if (SVG_LAUNCHING(ctx)) {
+    const double bytes = (double)B * HW * C * 2;
+    {
+      ProfScope ps(ctx, PK_GNORM, s, 0, bytes);
+      const int threads = (CV * PL + 63) / 64 * 64;
+      const size_t sh = (size_t)PL * C * 2 * sizeof(float);
+      hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(std::max(threads, 64)), sh, s, x, C1, x2, C2, partial, HW,
+                         groups, nchunk, CV, PL);
+      check_launch("gn_stats");
+    }
+    {
+      ProfScope ps(ctx, PK_GNORM, s, 0, 2 * bytes);
+      const int64_t total = (int64_t)HW * CV;
+      int nblk = (int)std::min<int64_t>(std::max<int64_t>(1, total / 1024), 1024);
+      hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, B), dim3(256), 0, s, x, C1, x2, C2, partial, gamma, beta, out, HW,
+                         groups, nchunk, eps, silu);
+      check_launch("gn_apply");
+    }
+  }
+  ctx->arena.pop();
+}
+
+void layernorm(svg_ctx* ctx, const bf16* x, const float* gamma, const float* beta, bf16* out, int M, int C, float eps,
+               hipStream_t s) {
+  SVG_CHECK(C % 8 == 0 && C <= 2048, "layernorm: C=%d unsupported", C);
+  if (!SVG_LAUNCHING(ctx)) return;
+  ProfScope ps(ctx, PK_LNORM, s, 0, 4.0 * M * C);
+  hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, x, gamma, beta, out, M, C, eps);
+  check_launch("layernorm");
+}
+
+void softmax_rows(svg_ctx* ctx, const float* s_in, bf16* p_out, int64_t rows, int cols, int ld_in, int ld_out, float scale,
+                  hipStream_t s) {
+  if (!SVG_LAUNCHING(ctx)) return;
+  ProfScope ps(ctx, PK_SOFTMAX, s, 0, (double)rows * cols * 10.0);
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, s_in, p_out, cols, ld_in, ld_out, scale);
+  check_launch("softmax_rows");
+}

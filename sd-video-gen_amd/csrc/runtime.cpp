@@ -1,0 +1,320 @@
+// Context, workspace arena, weight store, profiler, C-ABI error plumbing.
+#include "models.h"
+#include "../../include/svg_hip.h"
+#include <algorithm>
+#include <sstream>
+
+const char* kProfNames[PK_COUNT] = {"gemm", "conv3x3", "attention", "groupnorm", "layernorm", "eltwise",
+                                    "xf_gemm", "xf_misc", "softmax"};
+
+static std::string g_err;   // errors without a context
+
+void* svg_ctx::dalloc(int64_t bytes) {
+  void* p = nullptr;
+  HIP_OK(hipMalloc(&p, (size_t)std::max<int64_t>(bytes, 256)));
+  owned.push_back(p);
+  return p;
+}
+
+void svg_ctx::ensure_arena(int64_t bytes) {
+  bytes = align_up(bytes + (1 << 20), 1 << 20);
+  if (arena_buf.bytes >= bytes) return;
+  if (arena_buf.p) {
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipFree(arena_buf.p));
+    arena_buf.p = nullptr;
+  }
+  HIP_OK(hipMalloc(&arena_buf.p, (size_t)bytes));
+  arena_buf.bytes = bytes;
+  arena.base = (char*)arena_buf.p;
+  arena.cap = bytes;
+}
+
+ProfScope::ProfScope(svg_ctx* c_, int kind_, hipStream_t s_, double flops, double bytes) : c(c_), kind(kind_), s(s_) {
+  if (!c->prof) return;
+  auto next_event = [&]() {
+    if (c->ev_used == c->ev_pool.size()) {
+      hipEvent_t e;
+      HIP_OK(hipEventCreate(&e));
+      c->ev_pool.push_back(e);
+    }
+    return c->ev_pool[c->ev_used++];
+  };
+  e0 = next_event();
+  e1 = next_event();
+  ProfEntry& pe = c->prof_entries[kind];
+  pe.calls++;
+  pe.flops += flops;
+  pe.bytes += bytes;
+  pe.ev.push_back({e0, e1});
+  hipEventRecord(e0, s);
+}
+ProfScope::~ProfScope() {
+  if (e1) hipEventRecord(e1, s);
+}
+
+// ---- weight store ---------------------------------------------------------------------------------
+void WeightStore::put(svg_ctx* ctx, const std::string& name, const float* data, const int64_t* shape, int ndim) {
+  Weight w;
+  w.numel = 1;
+  for (int i = 0; i < ndim; ++i) { w.shape.push_back(shape[i]); w.numel *= shape[i]; }
+  SVG_CHECK(w.numel > 0, "weight %s is empty", name.c_str());
+  auto it = map.find(name);
+  if (it != map.end() && it->second.numel == w.numel && it->second.f32) {
+    w.f32 = it->second.f32;   // reload in place
+  } else {
+    HIP_OK(hipMalloc((void**)&w.f32, (size_t)w.numel * sizeof(float)));
+  }
+  HIP_OK(hipMemcpy(w.f32, data, (size_t)w.numel * sizeof(float), hipMemcpyDefault));
+  map[name] = w;
+}
+const Weight& WeightStore::get(const std::string& name) const {
+  auto it = map.find(name);
+  SVG_CHECK(it != map.end() && it->second.f32, "missing weight: %s", name.c_str());
+  return it->second;
+}
+const Weight& WeightStore::get(const std::string& name, std::initializer_list<int64_t> shape) const {
+  const Weight& w = get(name);
+  bool ok = w.shape.size() == shape.size();
+  if (ok) {
+    size_t i = 0;
+    for (int64_t s : shape) ok = ok && (w.shape[i++] == s);
+  }
+  if (!ok) {
+    std::ostringstream os;
+    os << "weight " << name << " has shape (";
+    for (auto s : w.shape) os << s << ",";
+    os << ") expected (";
+    for (auto s : shape) os << s << ",";
+    os << ")";
+    throw SvgError(os.str());
+  }
+  return w;
+}
+void WeightStore::release(const std::string& name) {
+  auto it = map.find(name);
+  if (it != map.end() && it->second.f32) {
+    hipFree(it->second.f32);
+    it->second.f32 = nullptr;
+  }
+}
+void WeightStore::clear() {
+  for (auto& kv : map)
+    if (kv.second.f32) hipFree(kv.second.f32);
+  map.clear();
+}
+int64_t WeightStore::total_params() const {
+  int64_t n = 0;
+  for (auto& kv : map) n += kv.second.numel;
+  return n;
+}
+
+// ---- "key=v,v;key=v" parser -------------------------------------------------------------------------
+std::unordered_map<std::string, std::vector<int64_t>> parse_kv(const char* kv) {
+  std::unordered_map<std::string, std::vector<int64_t>> out;
+  if (!kv) return out;
+  std::string s(kv), item;
+  std::stringstream ss(s);
+  while (std::getline(ss, item, ';')) {
+    if (item.empty()) continue;
+    size_t eq = item.find('=');
+    SVG_CHECK(eq != std::string::npos, "bad config item '%s'", item.c_str());
+    std::string key = item.substr(0, eq), vals = item.substr(eq + 1), v;
+    std::stringstream vs(vals);
+    std::vector<int64_t> arr;
+    while (std::getline(vs, v, ',')) arr.push_back(std::stoll(v));
+    out[key] = arr;
+  }
+  return out;
+}
+
+// ---- C ABI: context ------------------------------------------------------------------------------------
+#define API_BEGIN try {
+#define API_END(ctx)                                   \
+  return 0;                                            \
+  }                                                    \
+  catch (const std::exception& e) {                    \
+    if (ctx) (ctx)->err = e.what(); else g_err = e.what(); \
+    return -1;                                         \
+  }
+
+extern "C" {
+
+const char* svg_version(void) { return "svg_hip 0.1 (gfx950)"; }
+
+int svg_create(int device_id, svg_ctx** out) {
+  svg_ctx* ctx = nullptr;
+  API_BEGIN
+  SVG_CHECK(out, "svg_create: out is NULL");
+  int n = 0;
+  HIP_OK(hipGetDeviceCount(&n));
+  SVG_CHECK(device_id >= 0 && device_id < n, "svg_create: device %d of %d", device_id, n);
+  HIP_OK(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  HIP_OK(hipGetDeviceProperties(&prop, device_id));
+  SVG_CHECK(std::string(prop.gcnArchName).find("gfx950") != std::string::npos,
+            "svg_create: this library is built for gfx950 only, device reports %s", prop.gcnArchName);
+  ctx = new svg_ctx();
+  ctx->device = device_id;
+  ctx->prof_entries.resize(PK_COUNT);
+  for (int i = 0; i < PK_COUNT; ++i) ctx->prof_entries[i].name = kProfNames[i];
+  *out = ctx;
+  API_END((svg_ctx*)nullptr)
+}
+
+void svg_destroy(svg_ctx* ctx) {
+  if (!ctx) return;
+  hipDeviceSynchronize();
+  destroy_models(ctx);
+  for (void* p : ctx->owned) hipFree(p);
+  if (ctx->arena_buf.p) hipFree(ctx->arena_buf.p);
+  for (auto e : ctx->ev_pool) hipEventDestroy(e);
+  delete ctx;
+}
+
+const char* svg_last_error(svg_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int64_t svg_workspace_bytes(svg_ctx* ctx) { return ctx ? ctx->arena_buf.bytes : 0; }
+
+int svg_set_graph_mode(svg_ctx* ctx, int on) {
+  if (!ctx) return -1;
+  ctx->graph_mode = on != 0;
+  return 0;
+}
+
+int svg_prof_enable(svg_ctx* ctx, int on) {
+  if (!ctx) return -1;
+  ctx->prof = on != 0;
+  return 0;
+}
+int svg_prof_reset(svg_ctx* ctx) {
+  API_BEGIN
+  HIP_OK(hipDeviceSynchronize());
+  for (auto& e : ctx->prof_entries) { e.calls = 0; e.flops = 0; e.bytes = 0; e.ev.clear(); }
+  ctx->ev_used = 0;
+  API_END(ctx)
+}
+int svg_prof_report(svg_ctx* ctx, char* buf, int buflen) {
+  API_BEGIN
+  HIP_OK(hipDeviceSynchronize());
+  std::ostringstream os;
+  for (auto& e : ctx->prof_entries) {
+    if (!e.calls) continue;
+    double ms = 0;
+    for (auto& p : e.ev) {
+      float t = 0;
+      if (hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) ms += t;
+    }
+    os << e.name << " " << e.calls << " " << ms << " " << e.flops << " " << e.bytes << "\n";
+  }
+  std::string s = os.str();
+  SVG_CHECK((int)s.size() + 1 <= buflen, "svg_prof_report: buffer too small");
+  memcpy(buf, s.c_str(), s.size() + 1);
+  API_END(ctx)
+}
+
+// ---- C ABI: operator level -------------------------------------------------------------------------------
+int svg_op_gemm(svg_ctx* ctx, const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* residual, void* C,
+                int M, int N, int K, int act, int out_f32, void* stream) {
+  API_BEGIN
+  hipStream_t s = (hipStream_t)stream;
+  run_planned(ctx, [&]() {
+    GemmArgs g;
+    g.A = (const bf16*)A; g.lda = K; g.Wt = (const bf16*)W; g.ldb = K; g.M = M; g.N = N; g.K = K; g.n_valid = N;
+    g.bias = bias; g.residual = (const bf16*)residual; g.act = act; g.out_f32 = out_f32;
+    g.C = C;
+    if (act == ACT_GEGLU) {
+      // caller passes W rows as [h(0..F-1); gate(0..F-1)], F = N/2: pack here (test hook)
+      const int F = N / 2;
+      bf16* wp = ctx->arena.get<bf16>((int64_t)N * K);
+      float* bp = ctx->arena.get<float>(N);
+      float* wf = ctx->arena.get<float>((int64_t)N * K);
+      if (SVG_LAUNCHING(ctx)) {
+        bf16_to_f32((const bf16*)W, wf, (int64_t)N * K, s);
+        pack_geglu(wf, bias, wp, bp, F, K, s);
+      }
+      g.Wt = wp; g.bias = bias ? bp : nullptr; g.ldc = F; g.ldr = F;
+    } else {
+      g.ldc = N; g.ldr = N;
+    }
+    gemm_auto(ctx, g, s, PK_GEMM);
+  });
+  API_END(ctx)
+}
+
+int svg_op_conv3x3(svg_ctx* ctx, const uint16_t* x, const float* w_oihw, const float* bias, uint16_t* out, int B, int H, int W,
+                   int Cin, int Cout, int mode, void* stream) {
+  API_BEGIN
+  hipStream_t s = (hipStream_t)stream;
+  run_planned(ctx, [&]() {
+    const int Opad = (int)align_up(Cout, 4);
+    bf16* wp = ctx->arena.get<bf16>((int64_t)Opad * 9 * Cin);
+    float* wdev = ctx->arena.get<float>((int64_t)Cout * Cin * 9);
+    float* bdev = ctx->arena.get<float>(Opad);
+    if (SVG_LAUNCHING(ctx)) {
+      HIP_OK(hipMemcpyAsync(wdev, w_oihw, (size_t)Cout * Cin * 9 * sizeof(float), hipMemcpyDefault, s));
+      HIP_OK(hipMemsetAsync(bdev, 0, Opad * sizeof(float), s));
+      if (bias) HIP_OK(hipMemcpyAsync(bdev, bias, Cout * sizeof(float), hipMemcpyDefault, s));
+      pack_conv3x3(wdev, wp, Cout, Cin, Opad, Cin, s);
+    }
+    GemmArgs g;
+    g.A = (const bf16*)x;
+    g.H = H; g.W = W; g.Cin = Cin;
+    switch (mode) {
+      case 0: g.amode = (Cin == 8) ? A_CONV_SMALLC : A_CONV_S1; g.Ho = H; g.Wo = W; break;
+      case 1: g.amode = A_CONV_S2P1; g.Ho = H / 2; g.Wo = W / 2; break;
+      case 2: g.amode = A_CONV_S2ASYM; g.Ho = H / 2; g.Wo = W / 2; break;
+      case 3: g.amode = A_CONV_UP2; g.Ho = 2 * H; g.Wo = 2 * W; break;
+      default: throw SvgError("conv3x3: bad mode");
+    }
+    g.Wt = wp; g.ldb = 9 * Cin; g.K = 9 * Cin; g.M = B * g.Ho * g.Wo; g.N = Opad; g.n_valid = Opad;
+    g.bias = bdev; g.C = out; g.ldc = Cout;
+    SVG_CHECK(Cout % 4 == 0, "conv3x3 op: Cout must be a multiple of 4");
+    gemm_auto(ctx, g, s, PK_CONV3);
+  });
+  API_END(ctx)
+}
+
+int svg_op_groupnorm(svg_ctx* ctx, const uint16_t* x, const float* gamma, const float* beta, uint16_t* out, int B, int HW, int C,
+                     int groups, float eps, int silu, void* stream) {
+  API_BEGIN
+  run_planned(ctx, [&]() {
+    groupnorm(ctx, (const bf16*)x, C, nullptr, 0, gamma, beta, (bf16*)out, B, HW, groups, eps, silu, (hipStream_t)stream);
+  });
+  API_END(ctx)
+}
+
+int svg_op_layernorm(svg_ctx* ctx, const uint16_t* x, const float* gamma, const float* beta, uint16_t* out, int M, int C,
+                     float eps, void* stream) {
+  API_BEGIN
+  layernorm(ctx, (const bf16*)x, gamma, beta, (bf16*)out, M, C, eps, (hipStream_t)stream);
+  API_END(ctx)
+}
+
+int svg_op_attention(svg_ctx* ctx, const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* out, int B, int heads,
+                     int Sq, int Skv, int d, int ldq, int ldk, int ldvt, int ldo, int64_t qb, int64_t kb, int64_t vtb,
+                     int64_t ob, float scale, void* stream) {
+  API_BEGIN
+  AttnArgs a;
+  a.q = (const bf16*)q; a.k = (const bf16*)k; a.vt = (const bf16*)vt; a.out = (bf16*)out;
+  a.B = B; a.heads = heads; a.Sq = Sq; a.Skv = Skv; a.d = d;
+  a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo; a.qb = qb; a.kb = kb; a.vtb = vtb; a.ob = ob; a.scale = scale;
+  attention(ctx, a, (hipStream_t)stream);
+  API_END(ctx)
+}
+
+int svg_op_xf_gemm(svg_ctx* ctx, const float* X, const float* W, const float* bias, float* Y, int M, int N, int K, int relu_in,
+                   void* stream) {
+  API_BEGIN
+  xf_gemm(ctx, X, W, bias, Y, M, N, K, relu_in, (hipStream_t)stream);
+  API_END(ctx)
+}
+
+int svg_resize_nearest_u8(svg_ctx* ctx, const uint8_t* src, int N, int sh, int sw, int C, uint8_t* dst, int dh, int dw,
+                          void* stream) {
+  API_BEGIN
+  resize_nearest_u8(src, dst, N, sh, sw, C, dh, dw, (hipStream_t)stream);
+  API_END(ctx)
+}
+
+}  // extern "C"

@@ -1,0 +1,80 @@
+// Shared pieces of the SD networks (VAE, UNet): weight packing by state_dict name and the
+// conv / linear / resnet building blocks over NHWC bf16 activations.
+#include "models.h"
+
+float* keep_f32(svg_ctx* ctx, WeightStore& ws, const std::string& name, int64_t numel) {
+  const Weight& w = ws.get(name);
+  SVG_CHECK(w.numel == numel, "weight %s has %lld elements, expected %lld", name.c_str(), (long long)w.numel, (long long)numel);
+  return w.f32;   // stays in the store (small 1-D parameters)
+}
+
+ConvW load_conv3x3(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int Cin, int Cout, hipStream_t s) {
+  const Weight& w = ws.get(prefix + ".weight", {Cout, Cin, 3, 3});
+  ConvW cw;
+  cw.Cout = Cout;
+  cw.Opad = (int)align_up(Cout, 4);
+  cw.Cin = (Cin < 64) ? 8 : Cin;       // small-Cin convs (image / latent inputs) run on 8 padded channels
+  SVG_CHECK(Cin <= 8 || Cin % 64 == 0, "conv %s: Cin=%d must be <= 8 or a multiple of 64", prefix.c_str(), Cin);
+  cw.w = (bf16*)ctx->dalloc((int64_t)cw.Opad * 9 * cw.Cin * sizeof(bf16));
+  pack_conv3x3(w.f32, cw.w, Cout, Cin, cw.Opad, cw.Cin, s);
+  cw.b = (float*)ctx->dalloc(cw.Opad * sizeof(float));
+  HIP_OK(hipMemsetAsync(cw.b, 0, cw.Opad * sizeof(float), s));
+  HIP_OK(hipMemcpyAsync(cw.b, keep_f32(ctx, ws, prefix + ".bias", Cout), Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+  HIP_OK(hipStreamSynchronize(s));
+  ws.release(prefix + ".weight");
+  return cw;
+}
+
+PackedLinear load_linear(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int N, int K, bool bias, hipStream_t s) {
+  const Weight& w = ws.get(prefix + ".weight");
+  SVG_CHECK(w.numel == (int64_t)N * K && w.shape[0] == N, "weight %s.weight: expected [%d,%d(,1,1)]", prefix.c_str(), N, K);
+  PackedLinear pl;
+  pl.N = (int)align_up(N, 4); pl.K = K; pl.n_valid = N;
+  pl.w = (bf16*)ctx->dalloc((int64_t)pl.N * K * sizeof(bf16));
+  pack_linear(w.f32, pl.w, N, K, pl.N, s);
+  if (bias) {
+    pl.b = (float*)ctx->dalloc(pl.N * sizeof(float));
+    HIP_OK(hipMemsetAsync(pl.b, 0, pl.N * sizeof(float), s));
+    HIP_OK(hipMemcpyAsync(pl.b, keep_f32(ctx, ws, prefix + ".bias", N), N * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  HIP_OK(hipStreamSynchronize(s));
+  ws.release(prefix + ".weight");
+  return pl;
+}
+
+NormW load_norm(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int C) {
+  NormW n;
+  n.C = C;
+  n.g = keep_f32(ctx, ws, prefix + ".weight", C);
+  n.b = keep_f32(ctx, ws, prefix + ".bias", C);
+  return n;
+}
+
+void conv3x3(svg_ctx* ctx, const bf16* x, const ConvW& cw, void* out, int B, int H, int W, int amode, const float* bias_bn,
+             int bias_bn_ld, const bf16* residual, int out_f32, hipStream_t s) {
+  GemmArgs g;
+  g.A = x; g.H = H; g.W = W; g.Cin = cw.Cin;
+  g.amode = (cw.Cin == 8) ? A_CONV_SMALLC : amode;
+  SVG_CHECK(cw.Cin != 8 || amode == A_CONV_S1, "small-Cin conv supports stride 1 only");
+  switch (amode) {
+    case A_CONV_S1: g.Ho = H; g.Wo = W; break;
+    case A_CONV_S2P1: case A_CONV_S2ASYM: g.Ho = H / 2; g.Wo = W / 2; break;
+    case A_CONV_UP2: g.Ho = 2 * H; g.Wo = 2 * W; break;
+    default: throw SvgError("conv3x3: bad mode");
+  }
+  g.Wt = cw.w; g.ldb = 9 * cw.Cin; g.K = 9 * cw.Cin;
+  g.M = B * g.Ho * g.Wo; g.N = cw.Opad; g.n_valid = cw.Opad;
+  g.bias = cw.b;
+  g.bias_bn = bias_bn; g.bias_bn_ld = bias_bn_ld; g.rows_per_batch = g.Ho * g.Wo;
+  g.residual = residual; g.ldr = cw.Opad;
+  g.C = out; g.ldc = cw.Opad; g.out_f32 = out_f32;
+  gemm_auto(ctx, g, s, PK_CONV3);
+}
+
+void linear(svg_ctx* ctx, const bf16* A, int lda, const PackedLinear& pl, void* C, int ldc, int M, int act, const bf16* residual,
+            int ldr, int out_f32, hipStream_t s) {
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.Wt = pl.w; g.ldb = pl.K; g.M = M; g.N = pl.N; g.K = pl.K; g.n_valid = pl.N;
+  g.bias = pl.b; g.act = act; g.residual = residual; g.ldr = ldr; g.C = C; g.ldc = ldc; g.out_f32 = out_f32;
+  gemm_auto(ctx, g, s, PK_GEMM);
+}

@@ -1,0 +1,447 @@
+// SD UNet2DConditionModel graph (diffusers 0.2.x layout) and the DDIM img2img loop
+// (utils/sd_utils.py:222-267) on NHWC bf16 activations.
+#include "models.h"
+#include "../../include/svg_hip.h"
+
+void UnetModel::configure(const char* kv) {
+  auto m = parse_kv(kv);
+  auto geti = [&](const char* k, int& dst) { if (m.count(k)) dst = (int)m[k][0]; };
+  if (m.count("block_out")) { block_out.clear(); for (auto v : m["block_out"]) block_out.push_back((int)v); }
+  if (m.count("attn")) { attn.clear(); for (auto v : m["attn"]) attn.push_back((int)v); }
+  geti("layers", layers); geti("heads", heads); geti("ctx_dim", ctx_dim); geti("groups", groups);
+  geti("in_ch", in_ch); geti("out_ch", out_ch);
+  ready = false;
+}
+
+namespace {
+
+struct TembCollector {
+  std::vector<std::string> prefixes;
+  std::vector<int> couts;
+  int total = 0;
+  int add(const std::string& p, int cout) {
+    int off = total;
+    prefixes.push_back(p); couts.push_back(cout); total += cout;
+    return off;
+  }
+};
+
+ResW load_res_t(svg_ctx* ctx, WeightStore& ws, const std::string& p, int cin, int cout, TembCollector& tc, hipStream_t s) {
+  ResW r;
+  r.n1 = load_norm(ctx, ws, p + ".norm1", cin);
+  r.c1 = load_conv3x3(ctx, ws, p + ".conv1", cin, cout, s);
+  r.n2 = load_norm(ctx, ws, p + ".norm2", cout);
+  r.c2 = load_conv3x3(ctx, ws, p + ".conv2", cout, cout, s);
+  r.has_sc = cin != cout;
+  if (r.has_sc) r.sc = load_linear(ctx, ws, p + ".conv_shortcut", cout, cin, true, s);
+  r.temb_off = tc.add(p + ".time_emb_proj", cout);
+  return r;
+}
+
+// rows [W0; W1; ...] of same K packed into one bf16 matrix
+PackedLinear load_stacked(svg_ctx* ctx, WeightStore& ws, const std::vector<std::string>& names, const std::vector<int>& ns, int K,
+                          bool bias, hipStream_t s) {
+  PackedLinear pl;
+  int N = 0;
+  for (int n : ns) N += n;
+  pl.N = (int)align_up(N, 4); pl.K = K; pl.n_valid = N;
+  pl.w = (bf16*)ctx->dalloc((int64_t)pl.N * K * sizeof(bf16));
+  HIP_OK(hipMemsetAsync(pl.w, 0, (size_t)pl.N * K * sizeof(bf16), s));
+  if (bias) {
+    pl.b = (float*)ctx->dalloc(pl.N * sizeof(float));
+    HIP_OK(hipMemsetAsync(pl.b, 0, pl.N * sizeof(float), s));
+  }
+  int off = 0;
+  for (size_t i = 0; i < names.size(); ++i) {
+    const Weight& w = ws.get(names[i] + ".weight");
+    SVG_CHECK(w.numel == (int64_t)ns[i] * K, "weight %s.weight: expected [%d,%d]", names[i].c_str(), ns[i], K);
+    pack_linear(w.f32, pl.w + (int64_t)off * K, ns[i], K, ns[i], s);
+    if (bias)
+      HIP_OK(hipMemcpyAsync(pl.b + off, keep_f32(ctx, ws, names[i] + ".bias", ns[i]), ns[i] * sizeof(float), hipMemcpyDeviceToDevice, s));
+    off += ns[i];
+  }
+  HIP_OK(hipStreamSynchronize(s));
+  for (auto& n : names) ws.release(n + ".weight");
+  return pl;
+}
+
+XfBlockW load_xf(svg_ctx* ctx, WeightStore& ws, const std::string& p, int C, int ctx_dim, hipStream_t s) {
+  XfBlockW b;
+  b.C = C;
+  b.gn = load_norm(ctx, ws, p + ".norm", C);
+  b.proj_in = load_linear(ctx, ws, p + ".proj_in", C, C, true, s);
+  b.proj_out = load_linear(ctx, ws, p + ".proj_out", C, C, true, s);
+  const std::string t = p + ".transformer_blocks.0";
+  b.ln1 = load_norm(ctx, ws, t + ".norm1", C);
+  b.ln2 = load_norm(ctx, ws, t + ".norm2", C);
+  b.ln3 = load_norm(ctx, ws, t + ".norm3", C);
+  b.qk1 = load_stacked(ctx, ws, {t + ".attn1.to_q", t + ".attn1.to_k"}, {C, C}, C, false, s);
+  b.v1 = load_linear(ctx, ws, t + ".attn1.to_v", C, C, false, s);
+  b.o1 = load_linear(ctx, ws, t + ".attn1.to_out.0", C, C, true, s);
+  b.q2 = load_linear(ctx, ws, t + ".attn2.to_q", C, C, false, s);
+  b.k2 = load_linear(ctx, ws, t + ".attn2.to_k", C, ctx_dim, false, s);
+  b.v2 = load_linear(ctx, ws, t + ".attn2.to_v", C, ctx_dim, false, s);
+  b.o2 = load_linear(ctx, ws, t + ".attn2.to_out.0", C, C, true, s);
+  // GEGLU: Linear(C -> 8C) rows = [h (4C); gate (4C)] -> 16-row tiles alternating h / gate
+  {
+    const int F = 4 * C;
+    const Weight& w = ws.get(t + ".ff.net.0.proj.weight", {2 * F, C});
+    b.ff1.N = 2 * F; b.ff1.K = C; b.ff1.n_valid = 2 * F;
+    b.ff1.w = (bf16*)ctx->dalloc((int64_t)2 * F * C * sizeof(bf16));
+    b.ff1.b = (float*)ctx->dalloc(2 * F * sizeof(float));
+    pack_geglu(w.f32, keep_f32(ctx, ws, t + ".ff.net.0.proj.bias", 2 * F), b.ff1.w, b.ff1.b, F, C, s);
+    HIP_OK(hipStreamSynchronize(s));
+    ws.release(t + ".ff.net.0.proj.weight");
+  }
+  b.ff2 = load_linear(ctx, ws, t + ".ff.net.2", C, 4 * C, true, s);
+  return b;
+}
+
+}  // namespace
+
+void UnetModel::finalize(svg_ctx* ctx, int64_t* n_params) {
+  hipStream_t s = nullptr;
+  const int nb = (int)block_out.size();
+  SVG_CHECK((int)attn.size() == nb, "unet: attn flags must have one entry per block");
+  const int64_t total = ws.total_params();
+  const int c0 = block_out[0];
+  temb_dim = 4 * c0;
+  TembCollector tc;
+  time1 = load_linear(ctx, ws, "time_embedding.linear_1", temb_dim, c0, true, s);
+  time2 = load_linear(ctx, ws, "time_embedding.linear_2", temb_dim, temb_dim, true, s);
+  conv_in = load_conv3x3(ctx, ws, "conv_in", in_ch, c0, s);
+  down_res.clear(); down_attn.clear(); down_s.clear(); up_res.clear(); up_attn.clear(); up_s.clear();
+  // ---- down
+  std::vector<int> skip_ch{c0};
+  int cin = c0;
+  for (int i = 0; i < nb; ++i) {
+    std::vector<ResW> rs; std::vector<XfBlockW> as;
+    const std::string bp = "down_blocks." + std::to_string(i);
+    for (int j = 0; j < layers; ++j) {
+      rs.push_back(load_res_t(ctx, ws, bp + ".resnets." + std::to_string(j), cin, block_out[i], tc, s));
+      cin = block_out[i];
+      if (attn[i]) as.push_back(load_xf(ctx, ws, bp + ".attentions." + std::to_string(j), cin, ctx_dim, s));
+      skip_ch.push_back(cin);
+    }
+    down_res.push_back(rs); down_attn.push_back(as);
+    if (i < nb - 1) {
+      down_s.push_back(load_conv3x3(ctx, ws, bp + ".downsamplers.0.conv", cin, cin, s));
+      skip_ch.push_back(cin);
+    }
+  }
+  // ---- mid
+  mid0 = load_res_t(ctx, ws, "mid_block.resnets.0", cin, cin, tc, s);
+  mid_attn = load_xf(ctx, ws, "mid_block.attentions.0", cin, ctx_dim, s);
+  mid1 = load_res_t(ctx, ws, "mid_block.resnets.1", cin, cin, tc, s);
+  // ---- up (reversed block_out; layers+1 resnets per block, each consuming one skip)
+  for (int i = 0; i < nb; ++i) {
+    const int bi = nb - 1 - i;
+    const int cout = block_out[bi];
+    std::vector<ResW> rs; std::vector<XfBlockW> as;
+    const std::string bp = "up_blocks." + std::to_string(i);
+    for (int j = 0; j < layers + 1; ++j) {
+      const int sc = skip_ch.back(); skip_ch.pop_back();
+      rs.push_back(load_res_t(ctx, ws, bp + ".resnets." + std::to_string(j), cin + sc, cout, tc, s));
+      cin = cout;
+      if (attn[bi]) as.push_back(load_xf(ctx, ws, bp + ".attentions." + std::to_string(j), cin, ctx_dim, s));
+    }
+    up_res.push_back(rs); up_attn.push_back(as);
+    if (i < nb - 1) up_s.push_back(load_conv3x3(ctx, ws, bp + ".upsamplers.0.conv", cin, cin, s));
+  }
+  norm_out = load_norm(ctx, ws, "conv_norm_out", c0);
+  conv_out = load_conv3x3(ctx, ws, "conv_out", c0, out_ch, s);
+  temb_all = load_stacked(ctx, ws, tc.prefixes, tc.couts, temb_dim, true, s);
+  // ---- DDIM table, as diffusers' DDIMScheduler builds it: betas = linspace(sqrt(b0), sqrt(b1), 1000, f32)**2,
+  // alphas_cumprod = cumprod(1 - betas) in f32
+  alphas_cumprod.resize(1000);
+  {
+    const double b0 = sqrt(0.00085), b1 = sqrt(0.012);
+    float prod = 1.f;
+    for (int i = 0; i < 1000; ++i) {
+      const double step = (b1 - b0) / 999.0;
+      float sb = (float)(i * step + b0);
+      if (i == 999) sb = (float)b1;
+      float beta = sb * sb;
+      float alpha = 1.f - beta;
+      prod = prod * alpha;
+      alphas_cumprod[i] = prod;
+    }
+  }
+  if (n_params) *n_params = total;
+  ready = true;
+}
+
+void UnetModel::ddim_coefs(int t, int t_prev, float* sa, float* s1a, float* sap, float* s1ap) const {
+  SVG_CHECK(t >= 0 && t < 1000, "ddim: timestep %d out of range", t);
+  const float a_t = alphas_cumprod[t];
+  const float a_p = (t_prev >= 0) ? alphas_cumprod[t_prev] : 1.0f;   // set_alpha_to_one
+  *sa = sqrtf(a_t); *s1a = sqrtf(1.f - a_t); *sap = sqrtf(a_p); *s1ap = sqrtf(1.f - a_p);
+}
+
+namespace {
+struct UnetRun {
+  svg_ctx* ctx; UnetModel* m; hipStream_t s; int N;
+  const bf16* ctxb; int L, Lp;     // context (N*L, ctx_dim) bf16; Lp = L padded to 8
+  const float* temb;               // (N, temb_total) f32: every resnet's time_emb_proj(silu(temb))
+  int temb_ld;
+
+  bf16* resnet(const bf16* x, int Cx, const bf16* skip, int Cs, const ResW& r, int H, int W) {
+    const int64_t P = (int64_t)N * H * W;
+    bf16* out = ctx->arena.get<bf16>(P * r.c2.Opad);
+    ctx->arena.push();
+    const bf16* xin = x;
+    if (skip) {   // torch.cat([hidden, skip], dim=1)
+      bf16* cat = ctx->arena.get<bf16>(P * (Cx + Cs));
+      if (SVG_LAUNCHING(ctx)) { ProfScope ps(ctx, PK_ELT, s, 0, 4.0 * P * (Cx + Cs)); concat_channels(x, Cx, skip, Cs, cat, P, s); }
+      xin = cat;
+    }
+    const int Cin = Cx + Cs;
+    bf16* t0 = ctx->arena.get<bf16>(P * Cin);
+    groupnorm(ctx, xin, Cin, nullptr, 0, r.n1.g, r.n1.b, t0, N, H * W, m->groups, 1e-5f, 1, s);
+    bf16* t1 = ctx->arena.get<bf16>(P * r.c1.Opad);
+    conv3x3(ctx, t0, r.c1, t1, N, H, W, A_CONV_S1, temb + r.temb_off, temb_ld, nullptr, 0, s);
+    bf16* t2 = ctx->arena.get<bf16>(P * r.n2.C);
+    groupnorm(ctx, t1, r.n2.C, nullptr, 0, r.n2.g, r.n2.b, t2, N, H * W, m->groups, 1e-5f, 1, s);
+    const bf16* res = xin;
+    if (r.has_sc) {
+      bf16* sc = ctx->arena.get<bf16>(P * r.sc.N);
+      linear(ctx, xin, Cin, r.sc, sc, r.sc.N, (int)P, ACT_NONE, nullptr, 0, 0, s);
+      res = sc;
+    }
+    conv3x3(ctx, t2, r.c2, out, N, H, W, A_CONV_S1, nullptr, 0, res, 0, s);
+    ctx->arena.pop();
+    return out;
+  }
+
+  void attn_core(const bf16* q, int ldq, const bf16* k, int ldk, int64_t kb, const bf16* vt, int ldvt, int64_t vtb, bf16* o,
+                 int C, int Sq, int Skv) {
+    AttnArgs a;
+    a.q = q; a.k = k; a.vt = vt; a.out = o;
+    a.B = N; a.heads = m->heads; a.Sq = Sq; a.Skv = Skv; a.d = C / m->heads;
+    a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = C;
+    a.qb = (int64_t)Sq * ldq; a.kb = kb; a.vtb = vtb; a.ob = (int64_t)Sq * C;
+    a.scale = 1.f / sqrtf((float)a.d);
+    attention(ctx, a, s);
+  }
+
+  // V^T[b] (C x SkvPad) = Wv * src_b^T
+  bf16* vt_proj(const PackedLinear& wv, const bf16* src, int rows, int rows_pad, int K) {
+    const int C = wv.N;
+    bf16* vt = ctx->arena.get<bf16>((int64_t)N * C * rows_pad);
+    GemmArgs g;
+    g.A = wv.w; g.lda = K; g.Wt = src; g.ldb = K; g.M = C; g.N = rows_pad; g.n_valid = rows; g.K = K;
+    g.batch = N; g.sA = 0; g.sB = (int64_t)rows * K; g.sC = (int64_t)C * rows_pad;
+    g.C = vt; g.ldc = rows_pad;
+    gemm_auto(ctx, g, s, PK_GEMM);
+    return vt;
+  }
+
+  bf16* spatial_transformer(const bf16* x, const XfBlockW& b, int H, int W) {
+    const int HW = H * W, C = b.C;
+    const int64_t P = (int64_t)N * HW;
+    const int M = (int)P;
+    bf16* out = ctx->arena.get<bf16>(P * C);
+    ctx->arena.push();
+    bf16* n0 = ctx->arena.get<bf16>(P * C);
+    groupnorm(ctx, x, C, nullptr, 0, b.gn.g, b.gn.b, n0, N, HW, m->groups, 1e-6f, 0, s);
+    bf16* h = ctx->arena.get<bf16>(P * C);
+    linear(ctx, n0, C, b.proj_in, h, C, M, ACT_NONE, nullptr, 0, 0, s);
+    bf16* ln = ctx->arena.get<bf16>(P * C);
+    bf16* ao = ctx->arena.get<bf16>(P * C);
+    // ---- self-attention
+    layernorm(ctx, h, b.ln1.g, b.ln1.b, ln, M, C, 1e-5f, s);
+    {
+      ctx->arena.push();
+      const int HWp = (int)align_up(HW, 8);
+      bf16* qk = ctx->arena.get<bf16>(P * 2 * C);
+      linear(ctx, ln, C, b.qk1, qk, 2 * C, M, ACT_NONE, nullptr, 0, 0, s);
+      bf16* vt = vt_proj(b.v1, ln, HW, HWp, C);
+      attn_core(qk, 2 * C, qk + C, 2 * C, (int64_t)HW * 2 * C, vt, HWp, (int64_t)C * HWp, ao, C, HW, HW);
+      ctx->arena.pop();
+    }
+    bf16* h1 = ctx->arena.get<bf16>(P * C);
+    linear(ctx, ao, C, b.o1, h1, C, M, ACT_NONE, h, C, 0, s);
+    // ---- cross-attention
+    layernorm(ctx, h1, b.ln2.g, b.ln2.b, ln, M, C, 1e-5f, s);
+    {
+      ctx->arena.push();
+      bf16* q = ctx->arena.get<bf16>(P * C);
+      linear(ctx, ln, C, b.q2, q, C, M, ACT_NONE, nullptr, 0, 0, s);
+      bf16* k = ctx->arena.get<bf16>((int64_t)N * L * C);
+      linear(ctx, ctxb, m->ctx_dim, b.k2, k, C, N * L, ACT_NONE, nullptr, 0, 0, s);
+      bf16* vt = vt_proj(b.v2, ctxb, L, Lp, m->ctx_dim);
+      attn_core(q, C, k, C, (int64_t)L * C, vt, Lp, (int64_t)C * Lp, ao, C, HW, L);
+      ctx->arena.pop();
+    }
+    bf16* h2 = ctx->arena.get<bf16>(P * C);
+    linear(ctx, ao, C, b.o2, h2, C, M, ACT_NONE, h1, C, 0, s);
+    // ---- GEGLU feed-forward
+    layernorm(ctx, h2, b.ln3.g, b.ln3.b, ln, M, C, 1e-5f, s);
+    {
+      ctx->arena.push();
+      bf16* g = ctx->arena.get<bf16>(P * 4 * C);
+      linear(ctx, ln, C, b.ff1, g, 4 * C, M, ACT_GEGLU, nullptr, 0, 0, s);
+      linear(ctx, g, 4 * C, b.ff2, h, C, M, ACT_NONE, h2, C, 0, s);   // h is free again: reuse as h3
+      ctx->arena.pop();
+    }
+    linear(ctx, h, C, b.proj_out, out, C, M, ACT_NONE, x, C, 0, s);
+    ctx->arena.pop();
+    return out;
+  }
+};
+}  // namespace
+
+void UnetModel::forward(svg_ctx* ctx, const float* x, int N, int h, int w, const float* timesteps, const float* ctx_emb,
+                        int ctx_len, float* eps_out, hipStream_t s) {
+  SVG_CHECK(ready, "unet: svg_finalize has not been called");
+  const int nb = (int)block_out.size();
+  const int down = 1 << (nb - 1);
+  SVG_CHECK(N >= 1 && h % down == 0 && w % down == 0, "unet: latent %dx%d must be divisible by %d", h, w, down);
+  SVG_CHECK(ctx_len >= 1, "unet: empty context");
+  const int c0 = block_out[0];
+  UnetRun r{ctx, this, s, N};
+  r.L = ctx_len; r.Lp = (int)align_up(ctx_len, 8);
+  // context -> bf16
+  bf16* cb = ctx->arena.get<bf16>((int64_t)N * ctx_len * ctx_dim);
+  if (SVG_LAUNCHING(ctx)) { ProfScope ps(ctx, PK_ELT, s, 0, 0); f32_to_bf16(ctx_emb, cb, (int64_t)N * ctx_len * ctx_dim, s); }
+  r.ctxb = cb;
+  // time embedding: sinusoid -> linear_1 -> SiLU -> linear_2 ; every resnet applies time_emb_proj(SiLU(temb))
+  bf16* te0 = ctx->arena.get<bf16>((int64_t)N * c0);
+  if (SVG_LAUNCHING(ctx)) { ProfScope ps(ctx, PK_ELT, s, 0, 0); timestep_embed(timesteps, te0, N, c0, s); }
+  bf16* te1 = ctx->arena.get<bf16>((int64_t)N * temb_dim);
+  linear(ctx, te0, c0, time1, te1, temb_dim, N, ACT_SILU, nullptr, 0, 0, s);
+  bf16* te2 = ctx->arena.get<bf16>((int64_t)N * temb_dim);
+  linear(ctx, te1, temb_dim, time2, te2, temb_dim, N, ACT_SILU, nullptr, 0, 0, s);   // SiLU(temb), shared by all resnets
+  float* tall = ctx->arena.get<float>((int64_t)N * temb_all.N);
+  linear(ctx, te2, temb_dim, temb_all, tall, temb_all.N, N, ACT_NONE, nullptr, 0, 1, s);
+  r.temb = tall; r.temb_ld = temb_all.N;
+
+  // ---- conv_in
+  bf16* x0 = ctx->arena.get<bf16>((int64_t)N * h * w * 8);
+  if (SVG_LAUNCHING(ctx)) { ProfScope ps(ctx, PK_ELT, s, 0, 0); nchw_to_act(x, x0, N, in_ch, h, w, 8, 1.f, s); }
+  int H = h, W = w;
+  bf16* cur = ctx->arena.get<bf16>((int64_t)N * H * W * conv_in.Opad);
+  conv3x3(ctx, x0, conv_in, cur, N, H, W, A_CONV_S1, nullptr, 0, nullptr, 0, s);
+  struct Skip { const bf16* p; int C; };
+  std::vector<Skip> skips{{cur, c0}};
+  int C = c0;
+  // ---- down
+  for (int i = 0; i < nb; ++i) {
+    for (int j = 0; j < layers; ++j) {
+      cur = r.resnet(cur, C, nullptr, 0, down_res[i][j], H, W);
+      C = block_out[i];
+      if (attn[i]) cur = r.spatial_transformer(cur, down_attn[i][j], H, W);
+      skips.push_back({cur, C});
+    }
+    if (i < nb - 1) {
+      bf16* y = ctx->arena.get<bf16>((int64_t)N * (H / 2) * (W / 2) * down_s[i].Opad);
+      conv3x3(ctx, cur, down_s[i], y, N, H, W, A_CONV_S2P1, nullptr, 0, nullptr, 0, s);
+      cur = y; H /= 2; W /= 2;
+      skips.push_back({cur, C});
+    }
+  }
+  // ---- mid
+  cur = r.resnet(cur, C, nullptr, 0, mid0, H, W);
+  cur = r.spatial_transformer(cur, mid_attn, H, W);
+  cur = r.resnet(cur, C, nullptr, 0, mid1, H, W);
+  // ---- up
+  for (int i = 0; i < nb; ++i) {
+    const int bi = nb - 1 - i;
+    for (int j = 0; j < layers + 1; ++j) {
+      Skip sk = skips.back(); skips.pop_back();
+      cur = r.resnet(cur, C, sk.p, sk.C, up_res[i][j], H, W);
+      C = block_out[bi];
+      if (attn[bi]) cur = r.spatial_transformer(cur, up_attn[i][j], H, W);
+    }
+    if (i < nb - 1) {
+      bf16* y = ctx->arena.get<bf16>((int64_t)N * (2 * H) * (2 * W) * up_s[i].Opad);
+      conv3x3(ctx, cur, up_s[i], y, N, H, W, A_CONV_UP2, nullptr, 0, nullptr, 0, s);
+      cur = y; H *= 2; W *= 2;
+    }
+  }
+  // ---- out
+  bf16* t = ctx->arena.get<bf16>((int64_t)N * H * W * c0);
+  groupnorm(ctx, cur, c0, nullptr, 0, norm_out.g, norm_out.b, t, N, H * W, groups, 1e-5f, 1, s);
+  float* o = ctx->arena.get<float>((int64_t)N * H * W * conv_out.Opad);
+  conv3x3(ctx, t, conv_out, o, N, H, W, A_CONV_S1, nullptr, 0, nullptr, 1, s);
+  if (SVG_LAUNCHING(ctx)) { ProfScope ps(ctx, PK_ELT, s, 0, 0); actf32_to_nchw(o, conv_out.Opad, eps_out, N, out_ch, H, W, s); }
+}
+
+void UnetModel::ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const float* text_emb, int ctx_len, int num_steps,
+                          int start_step, float guidance, const float* noise, float* hist, hipStream_t s) {
+  SVG_CHECK(ready, "unet: svg_finalize has not been called");
+  SVG_CHECK(num_steps >= 1 && num_steps <= 1000 && start_step >= 0 && start_step <= num_steps, "ddim: bad steps %d/%d", start_step, num_steps);
+  SVG_CHECK(start_step == 0 || noise, "ddim: start_step > 0 needs the add_noise draws");
+  const int ratio = 1000 / num_steps;
+  const int64_t n = (int64_t)N * in_ch * h * w;
+  const bool cfg = guidance != 0.f;
+  const int NB = cfg ? 2 * N : N;
+  const int64_t emb_n = (int64_t)N * ctx_len * ctx_dim;
+  auto timestep_at = [&](int i) { return (num_steps - 1 - i) * ratio; };   // (arange(n)*ratio)[::-1]
+
+  // planned once for the whole loop: every step has the same shapes
+  auto body = [&]() {
+    float* tvec = ctx->arena.get<float>(NB);
+    float* zin = cfg ? ctx->arena.get<float>(2 * n) : nullptr;
+    float* eps = ctx->arena.get<float>((int64_t)NB * n / N);
+    if (SVG_LAUNCHING(ctx)) {
+      if (start_step > 0 && start_step < num_steps) {
+        const float a = alphas_cumprod[timestep_at(start_step)];
+        add_noise(z, noise, z, n, sqrtf(a), sqrtf(1.f - a), s);
+      }
+      if (hist) HIP_OK(hipMemcpyAsync(hist, z, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    for (int i = start_step; i < num_steps; ++i) {
+      const int t = timestep_at(i);
+      ctx->arena.push();
+      if (SVG_LAUNCHING(ctx)) {
+        fill_f32(tvec, NB, (float)t, s);
+        if (cfg) {
+          HIP_OK(hipMemcpyAsync(zin, z, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+          HIP_OK(hipMemcpyAsync(zin + n, z, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+      }
+      // guidance == 0: noise_pred = uncond + 0*(text - uncond) == uncond — only the uncond half is needed
+      forward(ctx, cfg ? zin : z, NB, h, w, tvec, text_emb, ctx_len, eps, s);
+      if (SVG_LAUNCHING(ctx)) {
+        float sa, s1a, sap, s1ap;
+        ddim_coefs(t, t - ratio, &sa, &s1a, &sap, &s1ap);
+        ProfScope ps(ctx, PK_ELT, s, 0, 0);
+        ddim_step(z, eps, cfg ? eps + n : nullptr, guidance, z, n, sa, s1a, sap, s1ap, s);
+        if (hist) HIP_OK(hipMemcpyAsync(hist + (int64_t)(i - start_step + 1) * n, z, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+      }
+      ctx->arena.pop();
+      if (ctx->arena.dry && i > start_step) break;   // one step is enough to size the arena
+    }
+  };
+  (void)emb_n;
+  run_planned(ctx, body);
+}
+
+extern "C" {
+int svg_unet_forward(svg_ctx* ctx, const float* x, int N, int h, int w, const float* timesteps, const float* ctx_emb, int ctx_len,
+                     float* eps_out, void* stream) {
+  try {
+    SVG_CHECK(ctx && ctx->unet, "unet: model not configured");
+    run_planned(ctx, [&]() { ctx->unet->forward(ctx, x, N, h, w, timesteps, ctx_emb, ctx_len, eps_out, (hipStream_t)stream); });
+    return 0;
+  } catch (const std::exception& e) { if (ctx) ctx->err = e.what(); return -1; }
+}
+int svg_ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const float* text_emb, int ctx_len, int num_steps, int start_step,
+                  float guidance, const float* noise, float* hist, void* stream) {
+  try {
+    SVG_CHECK(ctx && ctx->unet, "unet: model not configured");
+    ctx->unet->ddim_loop(ctx, z, N, h, w, text_emb, ctx_len, num_steps, start_step, guidance, noise, hist, (hipStream_t)stream);
+    return 0;
+  } catch (const std::exception& e) { if (ctx) ctx->err = e.what(); return -1; }
+}
+int svg_ddim_step(svg_ctx* ctx, const float* x, const float* eps, float* prev, int64_t n, int t, int t_prev, void* stream) {
+  try {
+    SVG_CHECK(ctx && ctx->unet && ctx->unet->ready, "unet: model not finalized");
+    float sa, s1a, sap, s1ap;
+    ctx->unet->ddim_coefs(t, t_prev, &sa, &s1a, &sap, &s1ap);
+    ddim_step(x, eps, nullptr, 0.f, prev, n, sa, s1a, sap, s1ap, (hipStream_t)stream);
+    return 0;
+  } catch (const std::exception& e) { if (ctx) ctx->err = e.what(); return -1; }
+}
+}

@@ -1,0 +1,273 @@
+// SD AutoencoderKL graph (diffusers 0.2.x layout) on NHWC bf16 activations.
+// Reference call sites: utils/sd_utils.py:128-145 (encode_img) and :156-169 (decode_img_latents).
+#include "models.h"
+#include "../../include/svg_hip.h"
+
+void VaeModel::configure(const char* kv) {
+  auto m = parse_kv(kv);
+  if (m.count("block_out")) { block_out.clear(); for (auto v : m["block_out"]) block_out.push_back((int)v); }
+  if (m.count("layers")) layers = (int)m["layers"][0];
+  if (m.count("groups")) groups = (int)m["groups"][0];
+  if (m.count("latent")) latent = (int)m["latent"][0];
+  ready = false;
+}
+
+static ResW load_res(svg_ctx* ctx, WeightStore& ws, const std::string& p, int cin, int cout, hipStream_t s) {
+  ResW r;
+  r.n1 = load_norm(ctx, ws, p + ".norm1", cin);
+  r.c1 = load_conv3x3(ctx, ws, p + ".conv1", cin, cout, s);
+  r.n2 = load_norm(ctx, ws, p + ".norm2", cout);
+  r.c2 = load_conv3x3(ctx, ws, p + ".conv2", cout, cout, s);
+  r.has_sc = cin != cout;
+  if (r.has_sc) r.sc = load_linear(ctx, ws, p + ".conv_shortcut", cout, cin, true, s);
+  return r;
+}
+
+static VaeAttnW load_vae_attn(svg_ctx* ctx, WeightStore& ws, const std::string& p, int C, hipStream_t s) {
+  VaeAttnW a;
+  a.C = C;
+  a.gn = load_norm(ctx, ws, p + ".group_norm", C);
+  // q and k share one GEMM: rows [Wq; Wk]
+  {
+    const Weight& wq = ws.get(p + ".query.weight", {C, C});
+    const Weight& wk = ws.get(p + ".key.weight", {C, C});
+    a.qk.N = 2 * C; a.qk.K = C; a.qk.n_valid = 2 * C;
+    a.qk.w = (bf16*)ctx->dalloc((int64_t)2 * C * C * sizeof(bf16));
+    pack_linear(wq.f32, a.qk.w, C, C, C, s);
+    pack_linear(wk.f32, a.qk.w + (int64_t)C * C, C, C, C, s);
+    a.qk.b = (float*)ctx->dalloc(2 * C * sizeof(float));
+    HIP_OK(hipMemcpyAsync(a.qk.b, keep_f32(ctx, ws, p + ".query.bias", C), C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_OK(hipMemcpyAsync(a.qk.b + C, keep_f32(ctx, ws, p + ".key.bias", C), C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_OK(hipStreamSynchronize(s));
+    ws.release(p + ".query.weight"); ws.release(p + ".key.weight");
+  }
+  a.v = load_linear(ctx, ws, p + ".value", C, C, true, s);
+  a.proj = load_linear(ctx, ws, p + ".proj_attn", C, C, true, s);
+  return a;
+}
+
+void VaeModel::finalize(svg_ctx* ctx, int64_t* n_params) {
+  hipStream_t s = nullptr;
+  SVG_CHECK(latent == 4, "vae: latent channels must be 4");
+  const int nb = (int)block_out.size();
+  const int64_t total = ws.total_params();
+  // ---- encoder
+  e_conv_in = load_conv3x3(ctx, ws, "encoder.conv_in", 3, block_out[0], s);
+  e_down.clear(); e_downs.clear();
+  int cin = block_out[0];
+  for (int i = 0; i < nb; ++i) {
+    std::vector<ResW> rs;
+    for (int j = 0; j < layers; ++j) {
+      rs.push_back(load_res(ctx, ws, "encoder.down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), cin, block_out[i], s));
+      cin = block_out[i];
+    }
+    e_down.push_back(rs);
+    if (i < nb - 1) e_downs.push_back(load_conv3x3(ctx, ws, "encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv", cin, cin, s));
+  }
+  const int cm = block_out[nb - 1];
+  e_mid0 = load_res(ctx, ws, "encoder.mid_block.resnets.0", cm, cm, s);
+  e_attn = load_vae_attn(ctx, ws, "encoder.mid_block.attentions.0", cm, s);
+  e_mid1 = load_res(ctx, ws, "encoder.mid_block.resnets.1", cm, cm, s);
+  e_norm_out = load_norm(ctx, ws, "encoder.conv_norm_out", cm);
+  e_conv_out = load_conv3x3(ctx, ws, "encoder.conv_out", cm, 2 * latent, s);
+  ws.get("quant_conv.weight", {8, 8, 1, 1}); ws.get("post_quant_conv.weight", {4, 4, 1, 1});
+  quant_w = keep_f32(ctx, ws, "quant_conv.weight", 64); quant_b = keep_f32(ctx, ws, "quant_conv.bias", 8);
+  pquant_w = keep_f32(ctx, ws, "post_quant_conv.weight", 16); pquant_b = keep_f32(ctx, ws, "post_quant_conv.bias", 4);
+  // ---- decoder (block_out reversed; layers+1 resnets per up block)
+  d_conv_in = load_conv3x3(ctx, ws, "decoder.conv_in", latent, cm, s);
+  d_mid0 = load_res(ctx, ws, "decoder.mid_block.resnets.0", cm, cm, s);
+  d_attn = load_vae_attn(ctx, ws, "decoder.mid_block.attentions.0", cm, s);
+  d_mid1 = load_res(ctx, ws, "decoder.mid_block.resnets.1", cm, cm, s);
+  d_up.clear(); d_ups.clear();
+  cin = cm;
+  for (int i = 0; i < nb; ++i) {
+    const int cout = block_out[nb - 1 - i];
+    std::vector<ResW> rs;
+    for (int j = 0; j < layers + 1; ++j) {
+      rs.push_back(load_res(ctx, ws, "decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), cin, cout, s));
+      cin = cout;
+    }
+    d_up.push_back(rs);
+    if (i < nb - 1) d_ups.push_back(load_conv3x3(ctx, ws, "decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv", cin, cin, s));
+  }
+  d_norm_out = load_norm(ctx, ws, "decoder.conv_norm_out", block_out[0]);
+  d_conv_out = load_conv3x3(ctx, ws, "decoder.conv_out", block_out[0], 3, s);
+  if (n_params) *n_params = total;
+  ready = true;
+}
+
+namespace {
+struct VaeRun {
+  svg_ctx* ctx; VaeModel* m; hipStream_t s; int N;
+  static constexpr float EPS = 1e-6f;
+
+  // out = conv2(silu(gn2(conv1(silu(gn1(x)))))) + shortcut(x)
+  bf16* resnet(const bf16* x, const ResW& r, int H, int W) {
+    const int64_t P = (int64_t)N * H * W;
+    bf16* out = ctx->arena.get<bf16>(P * r.c2.Opad);
+    ctx->arena.push();
+    bf16* t0 = ctx->arena.get<bf16>(P * r.n1.C);
+    groupnorm(ctx, x, r.n1.C, nullptr, 0, r.n1.g, r.n1.b, t0, N, H * W, m->groups, EPS, 1, s);
+    bf16* t1 = ctx->arena.get<bf16>(P * r.c1.Opad);
+    conv3x3(ctx, t0, r.c1, t1, N, H, W, A_CONV_S1, nullptr, 0, nullptr, 0, s);
+    bf16* t2 = ctx->arena.get<bf16>(P * r.n2.C);
+    groupnorm(ctx, t1, r.n2.C, nullptr, 0, r.n2.g, r.n2.b, t2, N, H * W, m->groups, EPS, 1, s);
+    const bf16* res = x;
+    if (r.has_sc) {
+      bf16* sc = ctx->arena.get<bf16>(P * r.sc.N);
+      linear(ctx, x, r.n1.C, r.sc, sc, r.sc.N, (int)P, ACT_NONE, nullptr, 0, 0, s);
+      res = sc;
+    }
+    conv3x3(ctx, t2, r.c2, out, N, H, W, A_CONV_S1, nullptr, 0, res, 0, s);
+    ctx->arena.pop();
+    return out;
+  }
+
+  // single-head attention over HW tokens, unfused (d = C = 512): S and P go through HBM
+  bf16* attn(const bf16* x, const VaeAttnW& a, int H, int W) {
+    const int HW = H * W, C = a.C;
+    const int64_t P = (int64_t)N * HW;
+    const int HWp = (int)align_up(HW, 8);
+    bf16* out = ctx->arena.get<bf16>(P * C);
+    ctx->arena.push();
+    bf16* n = ctx->arena.get<bf16>(P * C);
+    groupnorm(ctx, x, C, nullptr, 0, a.gn.g, a.gn.b, n, N, HW, m->groups, EPS, 0, s);
+    bf16* qk = ctx->arena.get<bf16>(P * 2 * C);
+    linear(ctx, n, C, a.qk, qk, 2 * C, (int)P, ACT_NONE, nullptr, 0, 0, s);
+    // V^T[b] = Wv * n_b^T + bv (per row)
+    bf16* vt = ctx->arena.get<bf16>((int64_t)N * C * HWp);
+    {
+      GemmArgs g;
+      g.A = a.v.w; g.lda = C; g.Wt = n; g.ldb = C; g.M = C; g.N = HWp; g.n_valid = HW; g.K = C;
+      g.batch = N; g.sA = 0; g.sB = (int64_t)HW * C; g.sC = (int64_t)C * HWp;
+      g.bias = a.v.b; g.bias_row = 1; g.C = vt; g.ldc = HWp;
+      gemm_auto(ctx, g, s, PK_GEMM);
+    }
+    float* S = ctx->arena.get<float>((int64_t)N * HW * HWp);
+    {
+      GemmArgs g;
+      g.A = qk; g.lda = 2 * C; g.Wt = qk + C; g.ldb = 2 * C; g.M = HW; g.N = HWp; g.n_valid = HW; g.K = C;
+      g.batch = N; g.sA = (int64_t)HW * 2 * C; g.sB = (int64_t)HW * 2 * C; g.sC = (int64_t)HW * HWp;
+      g.C = S; g.ldc = HWp; g.out_f32 = 1;
+      gemm_auto(ctx, g, s, PK_GEMM);
+    }
+    bf16* Pm = ctx->arena.get<bf16>((int64_t)N * HW * HWp);
+    softmax_rows(ctx, S, Pm, (int64_t)N * HW, HW, HWp, HWp, 1.f / sqrtf((float)C), s);
+    bf16* o = ctx->arena.get<bf16>(P * C);
+    {
+      GemmArgs g;
+      g.A = Pm; g.lda = HWp; g.Wt = vt; g.ldb = HWp; g.M = HW; g.N = C; g.n_valid = C; g.K = HWp;
+      g.batch = N; g.sA = (int64_t)HW * HWp; g.sB = (int64_t)C * HWp; g.sC = (int64_t)HW * C;
+      g.C = o; g.ldc = C;
+      gemm_auto(ctx, g, s, PK_GEMM);
+    }
+    linear(ctx, o, C, a.proj, out, C, (int)P, ACT_NONE, x, C, 0, s);
+    ctx->arena.pop();
+    return out;
+  }
+
+  bf16* norm_act(const bf16* x, const NormW& nw, int H, int W) {
+    bf16* t = ctx->arena.get<bf16>((int64_t)N * H * W * nw.C);
+    groupnorm(ctx, x, nw.C, nullptr, 0, nw.g, nw.b, t, N, H * W, m->groups, EPS, 1, s);
+    return t;
+  }
+};
+}  // namespace
+
+void VaeModel::encode(svg_ctx* ctx, const uint8_t* img, int N, int srcH, int srcW, int H, int W, const float* eps, float* z_out,
+                      float* moments_out, hipStream_t s) {
+  SVG_CHECK(ready, "vae: svg_finalize has not been called");
+  const int nb = (int)block_out.size();
+  const int down = 1 << (nb - 1);
+  SVG_CHECK(N >= 1 && H % down == 0 && W % down == 0 && H >= down && W >= down, "vae encode: bad size %dx%d (batch %d)", H, W, N);
+  run_planned(ctx, [&]() {
+    VaeRun r{ctx, this, s, N};
+    bf16* x0 = ctx->arena.get<bf16>((int64_t)N * H * W * 8);
+    if (SVG_LAUNCHING(ctx)) { ProfScope ps(ctx, PK_ELT, s, 0, 0); img_to_act(img, x0, N, srcH, srcW, H, W, s); }
+    int h = H, w = W;
+    bf16* x = ctx->arena.get<bf16>((int64_t)N * h * w * e_conv_in.Opad);
+    conv3x3(ctx, x0, e_conv_in, x, N, h, w, A_CONV_S1, nullptr, 0, nullptr, 0, s);
+    for (int i = 0; i < nb; ++i) {
+      for (auto& rw : e_down[i]) x = r.resnet(x, rw, h, w);
+      if (i < nb - 1) {
+        bf16* y = ctx->arena.get<bf16>((int64_t)N * (h / 2) * (w / 2) * e_downs[i].Opad);
+        conv3x3(ctx, x, e_downs[i], y, N, h, w, A_CONV_S2ASYM, nullptr, 0, nullptr, 0, s);
+        x = y; h /= 2; w /= 2;
+      }
+    }
+    x = r.resnet(x, e_mid0, h, w);
+    x = r.attn(x, e_attn, h, w);
+    x = r.resnet(x, e_mid1, h, w);
+    bf16* t = r.norm_act(x, e_norm_out, h, w);
+    const int64_t P = (int64_t)N * h * w;
+    float* mom0 = ctx->arena.get<float>(P * 8);
+    conv3x3(ctx, t, e_conv_out, mom0, N, h, w, A_CONV_S1, nullptr, 0, nullptr, 1, s);
+    float* mom = ctx->arena.get<float>(P * 8);
+    if (SVG_LAUNCHING(ctx)) {
+      ProfScope ps(ctx, PK_ELT, s, 0, 0);
+      pixel_linear_f32(mom0, 8, quant_w, quant_b, mom, 8, P, 8, 8, s);
+      vae_sample(mom, 8, eps, z_out, moments_out, N, h, w, s);
+    }
+  });
+}
+
+void VaeModel::decode(svg_ctx* ctx, const float* z, int N, int h, int w, uint8_t* img_out, int outH, int outW, float* float_out,
+                      hipStream_t s) {
+  SVG_CHECK(ready, "vae: svg_finalize has not been called");
+  SVG_CHECK(N >= 1 && h >= 1 && w >= 1, "vae decode: bad size");
+  const int nb = (int)block_out.size();
+  run_planned(ctx, [&]() {
+    VaeRun r{ctx, this, s, N};
+    const int64_t P0 = (int64_t)N * h * w;
+    // sd_utils.py:159: latents / 0.18215, then post_quant_conv (1x1, 4->4) in f32
+    float* zl = ctx->arena.get<float>(P0 * 4);
+    float* zq = ctx->arena.get<float>(P0 * 4);
+    bf16* x0 = ctx->arena.get<bf16>(P0 * 8);
+    if (SVG_LAUNCHING(ctx)) {
+      ProfScope ps(ctx, PK_ELT, s, 0, 0);
+      nchw_to_actf32(z, zl, N, 4, h, w, 1.f / 0.18215f, s);
+      pixel_linear_f32(zl, 4, pquant_w, pquant_b, zq, 4, P0, 4, 4, s);
+      actf32_pad_bf16(zq, 4, x0, 8, P0, s);
+    }
+    int H = h, W = w;
+    bf16* x = ctx->arena.get<bf16>(P0 * d_conv_in.Opad);
+    conv3x3(ctx, x0, d_conv_in, x, N, H, W, A_CONV_S1, nullptr, 0, nullptr, 0, s);
+    x = r.resnet(x, d_mid0, H, W);
+    x = r.attn(x, d_attn, H, W);
+    x = r.resnet(x, d_mid1, H, W);
+    for (int i = 0; i < nb; ++i) {
+      for (auto& rw : d_up[i]) x = r.resnet(x, rw, H, W);
+      if (i < nb - 1) {
+        bf16* y = ctx->arena.get<bf16>((int64_t)N * (2 * H) * (2 * W) * d_ups[i].Opad);
+        conv3x3(ctx, x, d_ups[i], y, N, H, W, A_CONV_UP2, nullptr, 0, nullptr, 0, s);
+        x = y; H *= 2; W *= 2;
+      }
+    }
+    bf16* t = r.norm_act(x, d_norm_out, H, W);
+    float* o = ctx->arena.get<float>((int64_t)N * H * W * 4);
+    conv3x3(ctx, t, d_conv_out, o, N, H, W, A_CONV_S1, nullptr, 0, nullptr, 1, s);
+    if (SVG_LAUNCHING(ctx)) {
+      ProfScope ps(ctx, PK_ELT, s, 0, 0);
+      act_to_img(o, 4, img_out, float_out, N, H, W, img_out ? outH : H, img_out ? outW : W, s);
+    }
+  });
+}
+
+extern "C" {
+int svg_vae_encode(svg_ctx* ctx, const uint8_t* img, int N, int srcH, int srcW, int H, int W, const float* eps, float* z_out,
+                   float* moments_out, void* stream) {
+  try {
+    SVG_CHECK(ctx && ctx->vae, "vae: model not configured");
+    ctx->vae->encode(ctx, img, N, srcH, srcW, H, W, eps, z_out, moments_out, (hipStream_t)stream);
+    return 0;
+  } catch (const std::exception& e) { if (ctx) ctx->err = e.what(); return -1; }
+}
+int svg_vae_decode(svg_ctx* ctx, const float* z, int N, int h, int w, uint8_t* img_out, int outH, int outW, float* float_out,
+                   void* stream) {
+  try {
+    SVG_CHECK(ctx && ctx->vae, "vae: model not configured");
+    ctx->vae->decode(ctx, z, N, h, w, img_out, outH, outW, float_out, (hipStream_t)stream);
+    return 0;
+  } catch (const std::exception& e) { if (ctx) ctx->err = e.what(); return -1; }
+}
+}

@@ -1,0 +1,98 @@
+"""Host-side mirror of the reference's latent-sequence model (models/transformer.py:9-94).
+
+Same constructor signature, same ``state_dict`` keys (the parameters are created
+with ``nn.Linear`` / ``nn.Transformer`` / ``nn.Linear`` in the reference's order, so a seed
+reproduces the reference's initial weights and its checkpoints load unchanged), same ``forward``
+contract — but ``forward`` runs on the HIP library (f32-input MFMA weight-streaming kernels).
+There is no CPU forward: calling it without a GPU / without libsvg_hip.so raises.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .config import parse_config_args
+
+
+class PositionalEncoding(nn.Module):
+    """models/positional_encoding.py:7-35 — buffer only; the add happens inside the HIP forward,
+    indexed by BATCH row like the reference (quirk: pos_encoding[:x.size(0)] on a batch-first tensor)."""
+
+    def __init__(self, dim_model, dropout_p, max_len):
+        super().__init__()
+        self.dropout_p = dropout_p
+        pos_encoding = torch.zeros(max_len, dim_model)
+        positions = torch.arange(0, max_len, dtype=torch.float).view(-1, 1)
+        division = torch.exp(torch.arange(0, dim_model, 2).float() * (-math.log(10000.0)) / dim_model)
+        pos_encoding[:, 0::2] = torch.sin(positions * division)
+        pos_encoding[:, 1::2] = torch.cos(positions * division)
+        self.register_buffer("pos_encoding", pos_encoding.unsqueeze(0).transpose(0, 1))
+
+
+class Transformer(nn.Module):
+    def __init__(self, num_tokens=0, dim_model=256, num_heads=8, num_encoder_layers=6,
+                 num_decoder_layers=6, dropout_p=0.1):
+        super().__init__()
+        self.config, self.args = parse_config_args()          # transformer.py:23 (argv/cwd are API)
+        self.dim_model = dim_model
+        self.num_heads = num_heads
+        self.num_encoder_layers = num_encoder_layers
+        self.num_decoder_layers = num_decoder_layers
+        self.height = self.config.FRAME_SIZE
+        self.width = self.config.FRAME_SIZE
+        self.compression = 8
+        d_lat = self.height // self.compression * self.width // self.compression * 4
+        self.d_lat = d_lat
+        # parameter containers in the reference's construction order (transformer.py:33-45)
+        self.positional_encoder = PositionalEncoding(dim_model=dim_model, dropout_p=dropout_p, max_len=64)
+        self.embedding = nn.Linear(d_lat, dim_model)
+        self.transformer = nn.Transformer(d_model=dim_model, nhead=num_heads, num_encoder_layers=num_encoder_layers,
+                                          num_decoder_layers=num_decoder_layers, dropout=dropout_p)
+        self.out = nn.Linear(dim_model, d_lat)
+        self._ctx = None
+        self._uploaded_version = None
+
+    # ---- weight hand-over -------------------------------------------------------------------------
+    def _version(self):
+        return tuple(int(p._version) for p in self.parameters()) + (id(self._ctx),)
+
+    def _sync_weights(self):
+        ctx = _lib.default_context()
+        if self._ctx is ctx and self._uploaded_version == self._version():
+            return ctx
+        self._ctx = ctx
+        ctx.configure(_lib.SVG_TRANSFORMER, d_lat=self.d_lat, d_model=self.dim_model, heads=self.num_heads,
+                      enc_layers=self.num_encoder_layers, dec_layers=self.num_decoder_layers,
+                      ffn=self.transformer.encoder.layers[0].linear1.out_features if self.num_encoder_layers else 2048)
+        ctx.load_state_dict(_lib.SVG_TRANSFORMER, self.state_dict())
+        self.n_params = ctx.finalize(_lib.SVG_TRANSFORMER)
+        self._uploaded_version = self._version()
+        return ctx
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._uploaded_version = None
+        return r
+
+    # ---- forward (transformer.py:47-68) ---------------------------------------------------------------
+    def forward(self, src, tgt, tgt_mask=None, src_pad_mask=None, tgt_pad_mask=None, pe_row=None):
+        if self.training and self.positional_encoder.dropout_p > 0:
+            raise RuntimeError("the HIP path implements eval-mode sampling (dropout off); call model.eval()")
+        if src_pad_mask is not None or tgt_pad_mask is not None:
+            raise NotImplementedError("key-padding masks are not on the sampling path (predict.py passes none)")
+        if not src.is_cuda:
+            raise RuntimeError("Transformer.forward runs on the HIP library and needs CUDA tensors; "
+                               "there is no CPU fallback")
+        ctx = self._sync_weights()
+        return ctx.transformer_forward(src, tgt, tgt_mask, pe_row)
+
+    def get_tgt_mask(self, size):
+        """transformer.py:70-89."""
+        mask = torch.tril(torch.ones(size, size) == 1).float()
+        mask = mask.masked_fill(mask == 0, float("-inf"))
+        mask = mask.masked_fill(mask == 1, float(0.0))
+        return mask
+
+    def create_pad_mask(self, matrix, pad_token):
+        return matrix == pad_token

@@ -1,0 +1,249 @@
+"""GPU parity of each HIP kernel family against a plain PyTorch fp32 restatement of the same op
+(inputs rounded to bf16 first so only accumulation order / output rounding differ).
+Tolerances: bf16 output rounding is 2^-9 relative per element -> rel-L2 <= 4e-3 for bf16 outputs,
+1e-5 for f32 outputs of exact-f32 kernels."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+BF16_TOL = 4e-3
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def u16(t):
+    assert t.dtype == torch.bfloat16 and t.is_contiguous()
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 320, 320), (77, 640, 768), (4096, 320, 2880),
+                                   (64, 1280, 11520), (1, 1280, 320), (257, 4, 128), (1000, 8, 512)])
+def test_gemm_bias_residual(ctx, M, N, K):
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N * 3 + K)
+    A = bf(torch.randn(M, K, device="cuda", generator=g))
+    W = bf(torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K))
+    b = torch.randn(N, device="cuda", generator=g)
+    R = bf(torch.randn(M, N, device="cuda", generator=g))
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    rc = ctx.lib.svg_op_gemm(ctx.h, u16(A), u16(W), b.data_ptr(), u16(R), out.data_ptr(), M, N, K, 0, 0, stream())
+    ctx.check(rc, "gemm")
+    ref = A.float() @ W.float().t() + b + R.float()
+    assert rel_l2(out.float(), ref) < BF16_TOL
+    # f32 output, no residual: only accumulation order differs
+    out32 = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    ctx.check(ctx.lib.svg_op_gemm(ctx.h, u16(A), u16(W), b.data_ptr(), None, out32.data_ptr(), M, N, K, 0, 1, stream()), "gemm f32")
+    assert rel_l2(out32, A.float() @ W.float().t() + b) < 2e-5
+
+
+def test_gemm_integer_exact(ctx):
+    """small-integer operands: every product and partial sum is exact in f32 -> bit-exact result;
+    asymmetric W so a row/col swap in the C write cannot hide (guide: A=I check with asymmetric B)."""
+    M, N, K = 256, 160, 128
+    A = bf(torch.randint(-3, 4, (M, K), device="cuda").float())
+    W = bf((torch.arange(N, device="cuda")[:, None] % 5 - 2).float() + (torch.arange(K, device="cuda")[None, :] % 3).float())
+    out = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    ctx.check(ctx.lib.svg_op_gemm(ctx.h, u16(A), u16(W), None, None, out.data_ptr(), M, N, K, 0, 1, stream()), "gemm")
+    assert torch.equal(out, A.float() @ W.float().t())
+    eye = bf(torch.eye(K, device="cuda"))
+    out2 = torch.empty(K, N, device="cuda", dtype=torch.float32)
+    ctx.check(ctx.lib.svg_op_gemm(ctx.h, u16(eye), u16(W), None, None, out2.data_ptr(), K, N, K, 0, 1, stream()), "gemm")
+    assert torch.equal(out2, W.float().t().contiguous())
+
+
+@pytest.mark.parametrize("act", [1, 2])
+def test_gemm_activations(ctx, act):
+    M, N, K = 200, 256, 192
+    g = torch.Generator(device="cuda").manual_seed(act)
+    A = bf(torch.randn(M, K, device="cuda", generator=g))
+    W = bf(torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K))
+    b = torch.randn(N, device="cuda", generator=g)
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ctx.check(ctx.lib.svg_op_gemm(ctx.h, u16(A), u16(W), b.data_ptr(), None, out.data_ptr(), M, N, K, act, 0, stream()), "gemm")
+    pre = A.float() @ W.float().t() + b
+    ref = F.silu(pre) if act == 1 else F.gelu(pre)
+    assert rel_l2(out.float(), ref) < BF16_TOL
+
+
+@pytest.mark.parametrize("M,C", [(256, 64), (1000, 320), (64, 1280)])
+def test_gemm_geglu(ctx, M, C):
+    """FeedForward GEGLU (diffusers attention.py): proj(x).chunk(2) -> h * gelu(gate)."""
+    Fd = 4 * C
+    g = torch.Generator(device="cuda").manual_seed(C)
+    A = bf(torch.randn(M, C, device="cuda", generator=g))
+    W = bf(torch.randn(2 * Fd, C, device="cuda", generator=g) / math.sqrt(C))
+    b = torch.randn(2 * Fd, device="cuda", generator=g)
+    out = torch.empty(M, Fd, device="cuda", dtype=torch.bfloat16)
+    ctx.check(ctx.lib.svg_op_gemm(ctx.h, u16(A), u16(W), b.data_ptr(), None, out.data_ptr(), M, 2 * Fd, C, 3, 0, stream()), "geglu")
+    pre = A.float() @ W.float().t() + b
+    h, gate = pre.chunk(2, dim=-1)
+    assert rel_l2(out.float(), h * F.gelu(gate)) < BF16_TOL
+
+
+def conv_ref(x_nhwc, w, b, mode):
+    x = x_nhwc.float().permute(0, 3, 1, 2)
+    if mode == 0:
+        y = F.conv2d(x, w, b, padding=1)
+    elif mode == 1:
+        y = F.conv2d(x, w, b, stride=2, padding=1)
+    elif mode == 2:
+        y = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b, stride=2)
+    else:
+        y = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,mode", [
+    (1, 16, 16, 64, 64, 0), (2, 8, 8, 128, 320, 0), (1, 32, 32, 320, 320, 0), (3, 5, 7, 64, 128, 0),
+    (2, 16, 16, 64, 64, 1), (1, 8, 8, 128, 128, 1), (2, 16, 16, 64, 64, 2), (1, 12, 12, 128, 64, 2),
+    (2, 8, 8, 64, 64, 3), (1, 6, 10, 128, 128, 3), (2, 16, 16, 8, 128, 0), (1, 64, 64, 8, 320, 0),
+    (1, 8, 8, 1280, 1280, 0), (1, 16, 16, 64, 4, 0), (2, 16, 16, 128, 8, 0)])
+def test_conv3x3(ctx, B, H, W, Cin, Cout, mode):
+    g = torch.Generator(device="cuda").manual_seed(B + H * 3 + Cin + Cout + mode)
+    x = bf(torch.randn(B, H, W, Cin, device="cuda", generator=g))
+    w = bf(torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / math.sqrt(9 * Cin)).float()
+    b = torch.randn(Cout, device="cuda", generator=g)
+    ref = conv_ref(x, w, b, mode)
+    out = torch.empty(ref.shape, device="cuda", dtype=torch.bfloat16)
+    ctx.check(ctx.lib.svg_op_conv3x3(ctx.h, u16(x), w.data_ptr(), b.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout, mode, stream()), "conv")
+    assert rel_l2(out.float(), ref) < BF16_TOL
+
+
+def test_conv3x3_integer_exact(ctx):
+    """integer data: exact sums -> the gather (tap order, padding, image borders) is checked bit for bit."""
+    B, H, W, Cin, Cout = 2, 9, 11, 64, 64
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = bf(torch.randint(-2, 3, (B, H, W, Cin), device="cuda", generator=g).float())
+    w = torch.randint(-2, 3, (Cout, Cin, 3, 3), device="cuda", generator=g).float()
+    for mode in range(4):
+        if mode in (1, 2):
+            xx = x[:, :8, :10].contiguous()
+        else:
+            xx = x
+        ref = conv_ref(xx, w, None, mode)
+        out = torch.empty(ref.shape, device="cuda", dtype=torch.bfloat16)
+        ctx.check(ctx.lib.svg_op_conv3x3(ctx.h, u16(xx), w.data_ptr(), None, out.data_ptr(), B, xx.shape[1], xx.shape[2], Cin, Cout, mode, stream()), "conv")
+        assert torch.equal(out.float(), ref), "mode %d" % mode
+
+
+@pytest.mark.parametrize("B,HW,C,silu", [(2, 64, 64, 1), (1, 4096, 320, 1), (3, 256, 1280, 0), (2, 1024, 960, 1),
+                                         (1, 64, 2560, 1), (2, 4096, 128, 0), (1, 100, 1920, 1)])
+def test_groupnorm(ctx, B, HW, C, silu):
+    g = torch.Generator(device="cuda").manual_seed(C + HW)
+    x = bf(torch.randn(B, HW, C, device="cuda", generator=g) * 2 + 0.5)
+    gamma = torch.randn(C, device="cuda", generator=g)
+    beta = torch.randn(C, device="cuda", generator=g)
+    out = torch.empty_like(x)
+    ctx.check(ctx.lib.svg_op_groupnorm(ctx.h, u16(x), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), B, HW, C, 32, 1e-5, silu, stream()), "gn")
+    ref = F.group_norm(x.float().permute(0, 2, 1), 32, gamma, beta, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    assert rel_l2(out.float(), ref.permute(0, 2, 1)) < BF16_TOL
+
+
+@pytest.mark.parametrize("M,C", [(100, 320), (4096, 640), (77, 1280), (5, 64)])
+def test_layernorm(ctx, M, C):
+    g = torch.Generator(device="cuda").manual_seed(C + M)
+    x = bf(torch.randn(M, C, device="cuda", generator=g) * 3 - 1)
+    gamma = torch.randn(C, device="cuda", generator=g)
+    beta = torch.randn(C, device="cuda", generator=g)
+    out = torch.empty_like(x)
+    ctx.check(ctx.lib.svg_op_layernorm(ctx.h, u16(x), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), M, C, 1e-5, stream()), "ln")
+    assert rel_l2(out.float(), F.layer_norm(x.float(), (C,), gamma, beta, 1e-5)) < BF16_TOL
+
+
+def run_attention(ctx, q, k, v, heads, Skv_pad):
+    """q (B,Sq,heads*d), k/v (B,Skv,heads*d) bf16 -> out (B,Sq,heads*d) via V^T layout."""
+    B, Sq, Cc = q.shape
+    Skv = k.shape[1]
+    d = Cc // heads
+    vt = torch.zeros(B, Cc, Skv_pad, device="cuda", dtype=torch.bfloat16)
+    vt[:, :, :Skv] = v.transpose(1, 2)
+    out = torch.empty_like(q)
+    ctx.check(ctx.lib.svg_op_attention(ctx.h, u16(q), u16(k), u16(vt), out.data_ptr(), B, heads, Sq, Skv, d, Cc, Cc, Skv_pad, Cc,
+                                       Sq * Cc, Skv * Cc, Cc * Skv_pad, Sq * Cc, 1.0 / math.sqrt(d), stream()), "attention")
+    return out
+
+
+def attention_ref(q, k, v, heads):
+    B, Sq, Cc = q.shape
+    d = Cc // heads
+    qh = q.float().view(B, Sq, heads, d).transpose(1, 2)
+    kh = k.float().view(B, -1, heads, d).transpose(1, 2)
+    vh = v.float().view(B, -1, heads, d).transpose(1, 2)
+    p = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(d), dim=-1)
+    return (p @ vh).transpose(1, 2).reshape(B, Sq, Cc)
+
+
+@pytest.mark.parametrize("B,heads,Sq,Skv,d", [(1, 8, 4096, 4096, 40), (2, 8, 1024, 1024, 80), (2, 8, 256, 256, 160),
+                                             (1, 8, 64, 64, 160), (2, 8, 4096, 77, 40), (1, 8, 256, 77, 160),
+                                             (1, 4, 100, 130, 16), (2, 2, 33, 65, 32), (1, 8, 1024, 77, 80), (1, 2, 200, 300, 8)])
+def test_attention(ctx, B, heads, Sq, Skv, d):
+    g = torch.Generator(device="cuda").manual_seed(Sq + Skv + d)
+    Cc = heads * d
+    q = bf(torch.randn(B, Sq, Cc, device="cuda", generator=g))
+    k = bf(torch.randn(B, Skv, Cc, device="cuda", generator=g))
+    v = bf(torch.randn(B, Skv, Cc, device="cuda", generator=g))
+    out = run_attention(ctx, q, k, v, heads, (Skv + 7) // 8 * 8)
+    assert rel_l2(out.float(), attention_ref(q, k, v, heads)) < 8e-3   # P is rounded to bf16 before PV
+
+
+def test_attention_online_rescale(ctx):
+    """forces the running-max rescale: one key far later in the sequence dominates a query's row, so the
+    accumulated O and l must be scaled down exactly once when that tile arrives (guide rule 26)."""
+    B, heads, S, d = 1, 1, 512, 40
+    g = torch.Generator(device="cuda").manual_seed(3)
+    q = bf(torch.randn(B, S, d, device="cuda", generator=g))
+    k = bf(torch.randn(B, S, d, device="cuda", generator=g))
+    v = bf(torch.randn(B, S, d, device="cuda", generator=g))
+    k[0, 300] = q[0, 17] * 4        # spike: q17 . k300 >> everything before tile 4
+    k[0, 450] = q[0, 200] * 6
+    out = run_attention(ctx, q, k, v, heads, S)
+    assert rel_l2(out.float(), attention_ref(q, k, v, heads)) < 8e-3
+
+
+@pytest.mark.parametrize("M,N,K,relu", [(6, 2048, 256, 0), (5, 6144, 2048, 0), (48, 2048, 2048, 1), (1, 256, 2048, 0),
+                                        (64, 96, 32, 0), (17, 1024, 2048, 1), (6, 32, 256, 0)])
+def test_xf_gemm(ctx, M, N, K, relu):
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    X = torch.randn(M, K, device="cuda", generator=g)
+    W = torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)
+    b = torch.randn(N, device="cuda", generator=g)
+    Y = torch.empty(M, N, device="cuda")
+    ctx.check(ctx.lib.svg_op_xf_gemm(ctx.h, X.data_ptr(), W.data_ptr(), b.data_ptr(), Y.data_ptr(), M, N, K, relu, stream()), "xf_gemm")
+    ref = (F.relu(X) if relu else X).double() @ W.double().t() + b.double()
+    assert rel_l2(Y, ref) < 2e-6
+
+
+def test_xf_gemm_integer_exact(ctx):
+    M, N, K = 7, 64, 128
+    X = torch.randint(-4, 5, (M, K), device="cuda").float()
+    W = (torch.arange(N, device="cuda")[:, None] % 7 - 3).float() + (torch.arange(K, device="cuda")[None, :] % 4).float()
+    Y = torch.empty(M, N, device="cuda")
+    ctx.check(ctx.lib.svg_op_xf_gemm(ctx.h, X.data_ptr(), W.data_ptr(), None, Y.data_ptr(), M, N, K, 0, stream()), "xf_gemm")
+    assert torch.equal(Y, X @ W.t())
+
+
+def test_resize_nearest_u8(ctx):
+    g = torch.Generator(device="cuda").manual_seed(9)
+    img = torch.randint(0, 256, (2, 64, 64, 3), device="cuda", dtype=torch.uint8, generator=g)
+    up = ctx.resize_nearest_u8(img, 512, 512)
+    ref = F.interpolate(img.permute(0, 3, 1, 2).float(), (512, 512)).permute(0, 2, 3, 1).to(torch.uint8)
+    assert torch.equal(up, ref)
+    down = ctx.resize_nearest_u8(up, 64, 64)
+    assert torch.equal(down, img)
+    odd = ctx.resize_nearest_u8(img, 100, 37)
+    ref = F.interpolate(img.permute(0, 3, 1, 2).float(), (100, 37)).permute(0, 2, 3, 1).to(torch.uint8)
+    assert torch.equal(odd, ref)
