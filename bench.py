@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py — generated frames/sec of the sampling hot path on N MI355X (one process per GPU).
+
+  python bench.py --gpus N --steps K --warmup W           (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[2], the one the metric is quoted on): config 1_16_kitti_L1_64 (F=64 frames,
+latent Transformer d=2048 4enc/8dec, 437.6 M params) with --denoise --denoise_start_step 0: per generated
+frame one Transformer forward, VAE decode @64, VAE encode @512x512, 50 DDIM steps of the SD-v1.4 UNet at
+64x64 latents (guidance_scale 0 as predict.py:169 -> batch-1 UNet is algorithmic), VAE decode @512x512,
+VAE encode @64.  One "step" = `clips` independent synthetic bouncing-ball clips x `pred_frames` frames per GPU
+(weak scaling: per-GPU work fixed), inputs resident in HBM, followed by the one all-gather of the clips.
+Weights are seeded random-init tensors of the exact architectures (no checkpoints offline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16 = 2.5e15        # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM = 8.0e12
+UNET_FLOP = 803.27e9      # per sample per call
+FRAME_FLOP = 43.85e12     # per generated frame, denoise @512, 50 steps, F=64, guidance 0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=2)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--clips", type=int, default=8, help="clips sampled in lock step per GPU")
+    p.add_argument("--pred_frames", type=int, default=1)
+    p.add_argument("--start_step", type=int, default=0)
+    p.add_argument("--config", type=str, default="1_16_kitti_L1_64")
+    p.add_argument("--no-denoise", action="store_true")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-roofline", action="store_true")
+    return p.parse_args()
+
+
+def cpu_baseline(cfg_name, start_step):
+    """The CPU restatement (oracle/, kind "port") timed on this host's cores on a bounded sample of the same
+    per-frame work; linear extrapolation to (50 - start_step) UNet steps and to 512x512 VAE passes is stated."""
+    import torch
+    from oracle import sd_oracle as SO, transformer_oracle as TO
+    from sd_video_gen_amd import sd_layout
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    t = {}
+
+    def timed(name, fn, reps=1):
+        fn() if reps > 1 else None
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        t[name] = (time.perf_counter() - t0) / reps
+    with torch.no_grad():
+        # latent Transformer at the configured size (weights drawn by torch.nn init, as the reference's)
+        from sd_video_gen_amd import config as svg_config
+        from sd_video_gen_amd.transformer import Transformer
+        svg_config.set_args(["--dataset", "synthetic-ball", "--config", cfg_name])
+        cfg = svg_config.load_config(cfg_name)
+        torch.manual_seed(0)
+        m = Transformer(dim_model=cfg.DIM_MODEL[0], num_heads=cfg.NUM_HEADS[0], num_encoder_layers=cfg.NUM_ENCODER_LAYERS[0],
+                        num_decoder_layers=cfg.NUM_DECODER_LAYERS[0], dropout_p=cfg.DROPOUT_P[0])
+        sd = m.state_dict()
+        D = m.d_lat
+        X = torch.randn(1, 6, D)
+        timed("transformer", lambda: TO.predict(sd, X, cfg.NUM_HEADS[0]), reps=2)
+        del m, sd
+        usd = sd_layout.seeded_weights(sd_layout.unet_shapes(), 2)
+        x = torch.randn(1, 4, 64, 64)
+        c = torch.randn(1, 77, 768)
+        timed("unet_step_b1", lambda: SO.unet_forward(usd, x, 500, c))
+        del usd
+        vsd = sd_layout.seeded_weights(sd_layout.vae_shapes(), 1)
+        F = cfg.FRAME_SIZE
+        img = torch.randint(0, 256, (1, 256, 256, 3), dtype=torch.uint8)
+        timed("vae_enc_256", lambda: SO.encode_img(vsd, img))
+        z = torch.randn(1, 4, 32, 32) * 0.2
+        timed("vae_dec_256", lambda: SO.decode_img_latents(vsd, z))
+        imgF = torch.randint(0, 256, (1, F, F, 3), dtype=torch.uint8)
+        timed("vae_enc_F", lambda: SO.encode_img(vsd, imgF))
+        zF = torch.randn(1, 4, F // 8, F // 8) * 0.2
+        timed("vae_dec_F", lambda: SO.decode_img_latents(vsd, zF))
+    n_unet = 50 - start_step
+    per_frame = t["transformer"] + n_unet * t["unet_step_b1"] + 4.0 * (t["vae_enc_256"] + t["vae_dec_256"]) + t["vae_enc_F"] + t["vae_dec_F"]
+    return {"value": 1.0 / per_frame, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "oracle (plain torch fp32) on host cores: 1 Transformer fwd %.3fs, 1 batch-1 UNet step %.2fs (x%d extrapolated), "
+                      "VAE enc+dec at 256x256 %.2fs+%.2fs (x4 extrapolated to 512x512, conv work is linear in pixels), VAE enc+dec at F %.2fs+%.2fs"
+                      % (t["transformer"], t["unet_step_b1"], n_unet, t["vae_enc_256"], t["vae_dec_256"], t["vae_enc_F"], t["vae_dec_F"])}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus or world == 1 and args.gpus == 1, "launch N>1 with torch.distributed.run --nproc-per-node N"
+    assert torch.cuda.is_available(), "bench.py needs the GPU: the product path has no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from sd_video_gen_amd import config as svg_config, sharding
+    from sd_video_gen_amd.predict import sample_clips, bouncing_ball_clips
+    from sd_video_gen_amd.sd_utils import SDUtils
+    from sd_video_gen_amd.transformer import Transformer
+
+    denoise = not args.no_denoise
+    argv = ["--dataset", "synthetic-ball", "--config", args.config, "--pred_frames", str(args.pred_frames),
+            "--denoise_start_step", str(args.start_step)] + (["--denoise", "True"] if denoise else [])
+    svg_config.set_args(argv)
+    cfg = svg_config.load_config(args.config)
+    dev = torch.device("cuda", local_rank)
+    torch.manual_seed(0)
+    sd_utils = SDUtils(seed=0, verbose=(rank == 0))
+    torch.manual_seed(0)
+    model = Transformer(num_tokens=0, dim_model=cfg.DIM_MODEL[0], num_heads=cfg.NUM_HEADS[0],
+                        num_encoder_layers=cfg.NUM_ENCODER_LAYERS[0], num_decoder_layers=cfg.NUM_DECODER_LAYERS[0],
+                        dropout_p=cfg.DROPOUT_P[0]).eval()
+    F = cfg.FRAME_SIZE
+    C = args.clips
+    n_global = C * world
+    a, b = sharding.shard_range(n_global, rank, world)
+    clips = bouncing_ball_clips(b - a, F, 5, seed=a, device=dev)          # resident in HBM before timing
+    seeds = sharding.clip_seeds(1234, a, b)
+    emb = sd_utils.encode_text([""]) if denoise else None
+
+    def step():
+        lat = sample_clips(model, sd_utils, clips, args.pred_frames, denoise=denoise, start_step=args.start_step,
+                           seeds=seeds, text_embeddings=emb)
+        return sharding.gather_clips(lat, n_global)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert out.shape[0] == n_global and torch.isfinite(out).all()
+    frames = n_global * args.pred_frames * args.steps
+    fps = frames / dt
+
+    line = {"metric": "generated frames/sec at 50 DDIM denoise steps, 512x512", "value": fps, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[2]: %s F=%d, --denoise --denoise_start_step %d (%d DDIM steps of the SD-v1.4 UNet at 64x64 latents, "
+                                   "VAE enc/dec at 512x512), guidance_scale 0" % (args.config, F, args.start_step, 50 - args.start_step)
+                       if denoise else "%s F=%d no --denoise (latent Transformer only)" % (args.config, F),
+                       "clips_per_gpu": C, "pred_frames": args.pred_frames, "global_clips": n_global, "parallelism": "clip-sharded dp%d" % world,
+                       "weights": "seeded random init (SD v1.4 architecture, %s)" % args.config}}
+
+    if rank == 0 and not args.no_roofline:
+        # instrumented pass: hipEvent brackets around every launch of each kernel family, on the launch stream
+        ctx = sd_utils.ctx
+        ctx.prof_reset()
+        ctx.prof_enable(True)
+        step()
+        torch.cuda.synchronize()
+        rep = ctx.prof_report()
+        ctx.prof_enable(False)
+        fam = {k: {"calls": v["calls"], "ms": round(v["ms"], 3), "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1)} for k, v in rep.items()}
+        if denoise:
+            dom = rep["conv3x3"]
+            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            line["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel<*, conv3x3> (implicit-GEMM 3x3 conv, all UNet/VAE shapes of one step)",
+                                "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": ach / (PEAK_BF16 / 1e12),
+                                "traffic": None, "launches": dom["calls"], "avg_launch_ms": dom["ms"] / dom["calls"],
+                                "algorithmic_flop_per_launch": dom["flops"] / dom["calls"]}
+            tot_ms = sum(v["ms"] for v in rep.values())
+            line["roofline"]["whole_frame_frac_of_mfma_peak"] = FRAME_FLOP * C * args.pred_frames / (tot_ms * 1e-3) / PEAK_BF16
+        else:
+            dom = rep["xf_gemm"]
+            ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+            line["roofline"] = {"bound": "hbm", "kernel": "xf_gemm_kernel (f32 weight stream)", "achieved": ach, "peak": PEAK_HBM / 1e9,
+                                "unit": "GB/s", "frac": ach / (PEAK_HBM / 1e9), "traffic": None, "launches": dom["calls"],
+                                "avg_launch_ms": dom["ms"] / dom["calls"]}
+        line["families"] = fam
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args.config, args.start_step) if denoise else None
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

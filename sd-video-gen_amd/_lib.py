@@ -119,6 +119,8 @@ class Context:
     def configure(self, model, **kv):
         s = ";".join("%s=%s" % (k, ",".join(str(int(x)) for x in (v if isinstance(v, (list, tuple)) else [v])))
                      for k, v in kv.items())
+        if model == SVG_VAE:
+            self.vae_down = 2 ** (len(kv.get("block_out", (128, 256, 512, 512))) - 1)
         self.check(self.lib.svg_model_configure(self.h, model, s.encode()), "svg_model_configure")
 
     def load_state_dict(self, model, sd):
@@ -155,8 +157,9 @@ class Context:
         H = H or sh
         W = W or sw
         img_u8 = img_u8.contiguous()
-        z = torch.empty((N, 4, H // 8, W // 8), device=img_u8.device, dtype=torch.float32)
-        mom = torch.empty((N, 8, H // 8, W // 8), device=img_u8.device, dtype=torch.float32) if return_moments else None
+        f = getattr(self, "vae_down", 8)
+        z = torch.empty((N, 4, H // f, W // f), device=img_u8.device, dtype=torch.float32)
+        mom = torch.empty((N, 8, H // f, W // f), device=img_u8.device, dtype=torch.float32) if return_moments else None
         eps = eps.contiguous().float() if eps is not None else None
         self.check(self.lib.svg_vae_encode(self.h, _ptr(img_u8), N, sh, sw, H, W, _ptr(eps), _ptr(z), _ptr(mom), _stream()),
                    "svg_vae_encode")
@@ -166,9 +169,10 @@ class Context:
         N, c, h, w = z.shape
         assert c == 4
         z = z.contiguous().float()
-        oh, ow = out_hw if out_hw else (8 * h, 8 * w)
+        f = getattr(self, "vae_down", 8)
+        oh, ow = out_hw if out_hw else (f * h, f * w)
         img = torch.empty((N, oh, ow, 3), device=z.device, dtype=torch.uint8)
-        fo = torch.empty((N, 3, 8 * h, 8 * w), device=z.device, dtype=torch.float32) if return_float else None
+        fo = torch.empty((N, 3, f * h, f * w), device=z.device, dtype=torch.float32) if return_float else None
         self.check(self.lib.svg_vae_decode(self.h, _ptr(z), N, h, w, _ptr(img), oh, ow, _ptr(fo), _stream()), "svg_vae_decode")
         return (img, fo) if return_float else img
 

@@ -22,7 +22,12 @@ extern "C" {
 int svg_model_configure(svg_ctx* ctx, int model, const char* kv) {
   try {
     SVG_CHECK(ctx, "null context");
-    store_of(ctx, model, true);
+    // a new configuration starts a fresh model: drop the previous weights and packed buffers
+    if (WeightStore* old = store_of(ctx, model, true)) old->clear();
+    HIP_OK(hipDeviceSynchronize());
+    for (void* p : ctx->owned[model]) hipFree(p);
+    ctx->owned[model].clear();
+    if (model == SVG_TRANSFORMER) { ctx->xf->pe = nullptr; ctx->xf->iota = nullptr; }
     if (model == SVG_TRANSFORMER) ctx->xf->configure(kv);
     else if (model == SVG_VAE) ctx->vae->configure(kv);
     else ctx->unet->configure(kv);
@@ -48,9 +53,13 @@ int svg_finalize(svg_ctx* ctx, int model, int64_t* n_params) {
     SVG_CHECK(ctx, "null context");
     SVG_CHECK(store_of(ctx, model, false), "svg_finalize: model %d has no weights", model);
     HIP_OK(hipSetDevice(ctx->device));
-    if (model == SVG_TRANSFORMER) ctx->xf->finalize(ctx, n_params);
-    else if (model == SVG_VAE) ctx->vae->finalize(ctx, n_params);
-    else ctx->unet->finalize(ctx, n_params);
+    ctx->cur_model = model;
+    try {
+      if (model == SVG_TRANSFORMER) ctx->xf->finalize(ctx, n_params);
+      else if (model == SVG_VAE) ctx->vae->finalize(ctx, n_params);
+      else ctx->unet->finalize(ctx, n_params);
+    } catch (...) { ctx->cur_model = 3; throw; }
+    ctx->cur_model = 3;
     HIP_OK(hipDeviceSynchronize());
     return 0;
   } catch (const std::exception& e) { if (ctx) ctx->err = e.what(); return -1; }

@@ -97,7 +97,8 @@ struct svg_ctx {
   struct XfModel* xf = nullptr;
   struct VaeModel* vae = nullptr;
   struct UnetModel* unet = nullptr;
-  std::vector<void*> owned;   // device allocations to free at destroy
+  std::vector<void*> owned[4];   // device allocations per model id (3 = context) freed at reconfigure / destroy
+  int cur_model = 3;
   void* dalloc(int64_t bytes);
   void ensure_arena(int64_t bytes);
 };

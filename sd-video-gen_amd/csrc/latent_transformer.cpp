@@ -42,7 +42,7 @@ void XfModel::finalize(svg_ctx* ctx, int64_t* n_params) {
   ws.get("transformer.decoder.norm.weight", {d}); ws.get("transformer.decoder.norm.bias", {d});
   // positional table (models/positional_encoding.py:16-30): use the state_dict buffer when it was handed
   // over, else build it — sin/cos in double, rounded to f32.
-  if (!pe) pe = (float*)ctx->dalloc(64 * d * sizeof(float));
+  if (!pe || pe_d != d) { pe = (float*)ctx->dalloc(64 * d * sizeof(float)); pe_d = (int)d; }
   if (ws.has("positional_encoder.pos_encoding")) {
     const Weight& w = ws.get("positional_encoder.pos_encoding");
     SVG_CHECK(w.numel == 64 * d, "positional_encoder.pos_encoding has %lld elements", (long long)w.numel);

@@ -43,6 +43,7 @@ struct XfModel {
   int d_lat = 0, d_model = 0, heads = 8, enc_layers = 0, dec_layers = 0, ffn = 2048;
   bool ready = false;
   float* pe = nullptr;   // (64, d_model)
+  int pe_d = 0;
   int32_t* iota = nullptr;
   void configure(const char* kv);
   void finalize(svg_ctx* ctx, int64_t* n_params);

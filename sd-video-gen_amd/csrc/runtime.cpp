@@ -12,7 +12,7 @@ static std::string g_err;   // errors without a context
 void* svg_ctx::dalloc(int64_t bytes) {
   void* p = nullptr;
   HIP_OK(hipMalloc(&p, (size_t)std::max<int64_t>(bytes, 256)));
-  owned.push_back(p);
+  owned[cur_model].push_back(p);
   return p;
 }
 
@@ -166,7 +166,7 @@ void svg_destroy(svg_ctx* ctx) {
   if (!ctx) return;
   hipDeviceSynchronize();
   destroy_models(ctx);
-  for (void* p : ctx->owned) hipFree(p);
+  for (auto& v : ctx->owned) for (void* p : v) hipFree(p);
   if (ctx->arena_buf.p) hipFree(ctx->arena_buf.p);
   for (auto e : ctx->ev_pool) hipEventDestroy(e);
   delete ctx;

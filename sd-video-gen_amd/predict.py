@@ -21,6 +21,92 @@ def predict(model, input_sequence, pe_row=None):
     return pred[0, -1]
 
 
+def clip_noise(seeds, shape, device):
+    """One standard-normal draw of `shape` per clip from that clip's own generator, stacked: results do not
+    depend on how clips are batched or sharded over ranks."""
+    return torch.stack([torch.randn(shape, generator=g, device=device) for g in seeds])
+
+
+def sample_clips(model, sd_utils, clips_u8, pred_frames, denoise=False, start_step=40, seeds=None,
+                 text_embeddings=None, num_inference_steps=50, guidance_scale=0.0, return_frames=False, timers=None):
+    """The per-clip loop of prediction/predict.py:117-197 for C independent clips in lock step, device resident.
+
+    clips_u8: (C,5,F,F,3) uint8 conditioning frames on the device.  Every stage is batched over clips; a clip's
+    result equals running it alone (PE row 0 per clip, per-clip noise generators seeded ``seeds[c]``).  The noise
+    draws follow the reference's order: VAE sample of the 5 conditioning frames; then per predicted frame the VAE
+    sample @512, add_noise (start_step>0), the VAE sample @F.  The four host crossings per frame of the reference
+    (decode -> numpy -> tensor -> interpolate, twice) become fused on-device uint8 nearest resizes with identical
+    rounding.  Returns all_latents (C, 4+N, D_lat) f32 [and the decoded frames (C,4+N,F,F,3) uint8].
+    """
+    ctx = sd_utils.ctx
+    dev = clips_u8.device
+    C, T, F = clips_u8.shape[0], clips_u8.shape[1], clips_u8.shape[2]
+    assert T == 5, "the reference conditions on 5 frames (predict.py:57, window hard-coded at :196)"
+    L = F // 8
+    D = 4 * L * L
+    if seeds is None:
+        seeds = list(range(C))
+    gens = [torch.Generator(device=dev).manual_seed(int(s)) for s in seeds]
+    model.eval()
+    with torch.no_grad():
+        eps = clip_noise(gens, (T, 4, L, L), dev).reshape(C * T, 4, L, L)
+        z = ctx.vae_encode(clips_u8.reshape(C * T, F, F, 3), eps=eps).reshape(C, T, D)     # predict.py:124
+        X = torch.cat((sd_utils.SOS_token.repeat(C, 1, 1), z), dim=1)
+        inputs = z                                                                          # :136-141
+        pe0 = torch.zeros(C, dtype=torch.int32, device=dev)
+        preds = []
+        if denoise:
+            emb = text_embeddings if text_embeddings is not None else sd_utils.encode_text([""])   # :148 (constant: hoisted)
+            n = emb.shape[0] // 2
+            if n == 1 and C > 1:
+                emb = torch.cat([emb[:1].repeat(C, 1, 1), emb[1:].repeat(C, 1, 1)])
+        all_latents = None
+        for _ in range(pred_frames):
+            pred = predict(model, X, pe_row=pe0)                                            # :144  (C, D)
+            if denoise:
+                noisy_img = ctx.vae_decode(pred.reshape(C, 4, L, L))                        # :149-153 (uint8, on device)
+                e512 = clip_noise(gens, (4, 64, 64), dev)
+                resized = ctx.vae_encode(noisy_img, H=512, W=512, eps=e512)                 # :158 resize + :163-164
+                noise = clip_noise(gens, (4, 64, 64), dev) if 0 < start_step else None
+                den = ctx.ddim_loop(resized, emb, num_steps=num_inference_steps, start_step=start_step,
+                                    guidance=guidance_scale, noise=noise)                   # :168-170
+                small = ctx.vae_decode(den, out_hw=(F, F))                                  # :173-179
+                eF = clip_noise(gens, (4, L, L), dev)
+                pred = ctx.vae_encode(small, eps=eF).reshape(C, D)                          # :183-185
+            preds.append(pred)
+            all_latents = torch.cat([inputs[:, :-1], torch.stack(preds, dim=1)], dim=1)     # :193
+            X = all_latents[:, -5:]                                                         # :196
+        if not return_frames:
+            return all_latents
+        n_out = all_latents.shape[1]
+        frames = ctx.vae_decode(all_latents.reshape(C * n_out, 4, L, L)).reshape(C, n_out, F, F, 3)   # :208-211
+        return all_latents, frames
+
+
+def bouncing_ball_clips(n_clips, frame_size, n_frames=5, seed=0, device="cpu"):
+    """Synthetic stand-in for the bouncing-ball dataset (datasets are absent offline): black F x F x 3 uint8
+    background, one white disc of radius F/8 moving at constant velocity with elastic wall bounces.
+    Returns (n_clips, n_frames, F, F, 3) uint8, BGR == RGB (grey)."""
+    import numpy as np
+    F = frame_size
+    out = np.zeros((n_clips, n_frames, F, F, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:F, 0:F]
+    r = F / 8.0
+    for c in range(n_clips):
+        rng = np.random.default_rng(seed + c)
+        pos = rng.uniform(r, F - r, size=2)
+        vel = rng.uniform(-F / 10.0, F / 10.0, size=2)
+        for t in range(n_frames):
+            out[c, t][(yy - pos[0]) ** 2 + (xx - pos[1]) ** 2 <= r * r] = 255
+            pos = pos + vel
+            for a in range(2):
+                if pos[a] < r:
+                    pos[a], vel[a] = 2 * r - pos[a], -vel[a]
+                if pos[a] > F - r:
+                    pos[a], vel[a] = 2 * (F - r) - pos[a], -vel[a]
+    return torch.from_numpy(out).to(device)
+
+
 def rollout_latents(model, new_batch, pred_frames, post=None):
     """predict.py:124-197 for one clip with the VAE taken out: ``new_batch`` (1,6,D) = SOS + 5 encoded frames.
     ``post(pred)`` is the optional denoise round trip (predict.py:145-185).  Returns (all_latents, trace)."""

@@ -1,0 +1,199 @@
+"""Host-side mirror of the reference's Stable-Diffusion wrapper (utils/sd_utils.py:20-295): same class,
+attributes and method contracts; the numerics run in libsvg_hip.so (HIP, gfx950).
+
+Weights: the reference fetches 'CompVis/stable-diffusion-v1-4' and 'openai/clip-vit-large-patch14' from the
+HF hub by name (sd_utils.py:52-66) — unreachable offline.  Here, in order: an explicit ``weights=`` dict of
+diffusers-named state_dicts, a local directory in ``$SVG_SD_WEIGHTS`` (``vae/`` and ``unet/`` holding
+``diffusion_pytorch_model.bin|.safetensors``), else seeded synthetic weights of the exact SD v1.4
+architecture (a notice is printed).  The CLIP text encoder produces an INPUT of this path; without its
+weights ``encode_text`` returns a seeded (2n,77,768) stand-in, or real embeddings handed in via
+``text_embeddings=``.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import _lib, sd_layout
+from .config import parse_config_args
+
+SCALE = 0.18215
+
+
+def _load_local(dirname, sub):
+    for fn in ("diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.bin"):
+        p = os.path.join(dirname, sub, fn)
+        if os.path.exists(p):
+            if fn.endswith(".safetensors"):
+                from safetensors.torch import load_file
+                return load_file(p)
+            return torch.load(p, map_location="cpu")
+    return None
+
+
+class _VAE:
+    """Stands where ``SDUtils.vae`` (diffusers AutoencoderKL) stands: encode(x).sample() / decode(z)."""
+
+    def __init__(self, ctx, n_params):
+        self.ctx = ctx
+        self.n_params = n_params
+
+    class _Posterior:
+        def __init__(self, ctx, imgs_u8):
+            self.ctx, self.imgs = ctx, imgs_u8
+
+        def sample(self, eps=None):
+            N, H, W, _ = self.imgs.shape
+            if eps is None:
+                eps = torch.randn((N, 4, H // 8, W // 8), device=self.imgs.device)
+            return self.ctx.vae_encode(self.imgs, eps=eps) / SCALE
+
+        def mode(self):
+            return self.ctx.vae_encode(self.imgs) / SCALE
+
+    def encode_u8(self, imgs_u8):
+        return _VAE._Posterior(self.ctx, imgs_u8)
+
+    def decode(self, z):
+        """z unscaled latents -> float NCHW image in about [-1,1]."""
+        return self.ctx.vae_decode(z * SCALE, return_float=True)[1]
+
+
+class _UNet:
+    in_channels = 4
+
+    def __init__(self, ctx, n_params):
+        self.ctx = ctx
+        self.n_params = n_params
+
+    def __call__(self, sample, timestep, encoder_hidden_states=None):
+        return {"sample": self.ctx.unet_forward(sample, timestep, encoder_hidden_states)}
+
+
+class SDUtils():
+    def __init__(self, weights=None, text_embeddings=None, seed=0, verbose=True):
+        self.config, self.args = parse_config_args()             # sd_utils.py:22
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        if self.device.type != "cuda":
+            raise RuntimeError("SDUtils runs on the HIP library and needs a GPU (gfx950); there is no CPU fallback")
+        self.ctx = _lib.default_context()
+        self._seed = seed
+        self._verbose = verbose
+        self._text_embeddings = text_embeddings
+        vae, tokenizer, text_encoder, unet, scheduler = self.load_models(weights)
+        self.vae = vae
+        # sd_utils.py:30 builds a default-size Transformer and throws it away; it consumes CPU RNG, which matters
+        # to anyone seeding before construction — reproduced by drawing the same parameters.
+        from .transformer import Transformer
+        Transformer()
+        self.SOS_token = torch.ones((1, 1, self.config.FRAME_SIZE ** 2 // 64 * 4), dtype=torch.float32, device=self.device) * 2
+        self.tokenizer = tokenizer
+        self.text_encoder = text_encoder
+        self.unet = unet
+        self.scheduler = scheduler
+
+    # ---- sd_utils.py:39-76 ---------------------------------------------------------------------------
+    def _weights_for(self, name, given, shapes_fn, seed):
+        if given is not None and name in given:
+            return given[name], "given"
+        d = os.environ.get("SVG_SD_WEIGHTS")
+        if d:
+            sd = _load_local(d, name)
+            if sd is not None:
+                return sd, "local:" + d
+        if self._verbose:
+            print("[sd-video-gen] no %s weights available offline: using seeded synthetic weights (seed %d)" % (name, seed))
+        return sd_layout.seeded_weights(shapes_fn(), seed, device=self.device), "synthetic"
+
+    def load_models(self, weights=None):
+        ctx = self.ctx
+        sd, self.vae_source = self._weights_for("vae", weights, sd_layout.vae_shapes, self._seed + 1)
+        ctx.configure(_lib.SVG_VAE, block_out=list(sd_layout.SD_VAE["block_out"]), layers=2, groups=32, latent=4)
+        ctx.load_state_dict(_lib.SVG_VAE, sd)
+        vae = _VAE(ctx, ctx.finalize(_lib.SVG_VAE))
+        del sd
+        if not self.args.denoise:
+            return vae, None, None, None, None
+        sd, self.unet_source = self._weights_for("unet", weights, sd_layout.unet_shapes, self._seed + 2)
+        c = sd_layout.SD_UNET
+        ctx.configure(_lib.SVG_UNET, block_out=list(c["block_out"]), layers=c["layers"], heads=c["heads"], ctx_dim=c["ctx_dim"],
+                      groups=c["groups"], in_ch=4, out_ch=4, attn=list(c["attn"]))
+        ctx.load_state_dict(_lib.SVG_UNET, sd)
+        unet = _UNet(ctx, ctx.finalize(_lib.SVG_UNET))
+        del sd
+        return vae, None, None, unet, None
+
+    # ---- sd_utils.py:78-95 -----------------------------------------------------------------------------
+    def encode_text(self, prompt):
+        """-> (2*len(prompt), 77, 768) = [uncond ; text].  Without CLIP weights: seeded stand-ins, one per distinct
+        prompt string ('' included), so equal prompts give equal embeddings as the real encoder would."""
+        if self._text_embeddings is not None:
+            return self._text_embeddings.to(self.device)
+        import zlib
+
+        def emb(p):
+            g = torch.Generator().manual_seed((self._seed * 7919 + zlib.crc32(p.encode())) % (2 ** 31))
+            return torch.randn((1, 77, 768), generator=g)
+        text = torch.cat([emb(p) for p in prompt])
+        uncond = torch.cat([emb("") for _ in prompt])
+        return torch.cat([uncond, text]).to(self.device)
+
+    # ---- sd_utils.py:128-154 ---------------------------------------------------------------------------
+    def encode_img(self, imgs, eps=None):
+        """imgs (N,H,W,3) uint8 (tensor, any device) -> (N,4,H/8,W/8) scaled latents on device.
+        ``eps`` = the .sample() draws (sd_utils.py:142); drawn on the device generator when None."""
+        imgs = torch.as_tensor(imgs).to(self.device)
+        if imgs.dtype != torch.uint8:
+            imgs = imgs.round().clamp(0, 255).to(torch.uint8)
+        N, H, W, _ = imgs.shape
+        if eps is None:
+            eps = torch.randn((N, 4, H // 8, W // 8), device=self.device)
+        return self.ctx.vae_encode(imgs, eps=eps)
+
+    def encode_batch(self, img_batch, use_sos=True, eps=None):
+        img_batch = torch.as_tensor(img_batch)
+        new_batch = self.encode_img(img_batch.reshape(-1, img_batch.shape[2], img_batch.shape[3], img_batch.shape[4]), eps)
+        new_batch = new_batch.reshape(img_batch.shape[0], img_batch.shape[1], -1)
+        if use_sos:
+            SOS_token = self.SOS_token.repeat(new_batch.shape[0], 1, 1)
+            new_batch = torch.cat((SOS_token, new_batch), dim=1)
+        return new_batch
+
+    # ---- sd_utils.py:156-169 ---------------------------------------------------------------------------
+    def decode_img_latents(self, latents):
+        """-> numpy (N,8h,8w,3) uint8 on the HOST, like the reference (callers do np.array(img[0]))."""
+        return self.ctx.vae_decode(latents.to(self.device)).cpu().numpy()
+
+    def decode_img_latents_device(self, latents, out_hw=None):
+        """same frames, kept on the device (no D2H sync), optionally nearest-resized (predict.py:158,178)."""
+        return self.ctx.vae_decode(latents.to(self.device), out_hw=out_hw)
+
+    # ---- sd_utils.py:222-267 ---------------------------------------------------------------------------
+    def gen_i2i_latents(self, text_embeddings, height=512, width=512, num_inference_steps=50, guidance_scale=7.5,
+                        latents=None, return_all_latents=False, start_step=10, noise=None):
+        if self.unet is None:
+            raise RuntimeError("gen_i2i_latents needs the UNet: construct SDUtils with --denoise")
+        if latents is None:
+            latents = torch.randn((text_embeddings.shape[0] // 2, self.unet.in_channels, height // 8, width // 8))
+        latents = latents.to(self.device)
+        if start_step > 0 and noise is None:
+            noise = torch.randn_like(latents)
+        return self.ctx.ddim_loop(latents, text_embeddings.to(self.device), num_steps=num_inference_steps, start_step=start_step,
+                                  guidance=guidance_scale, noise=noise, return_hist=return_all_latents)
+
+    def perturb_latents(self, latents, scale=0.1):
+        noise = torch.randn_like(latents)
+        new_latents = (1 - scale) * latents + scale * noise
+        return (new_latents - new_latents.mean()) / new_latents.std()
+
+    def img_to_img(self, prompts, height=512, width=512, num_inference_steps=50, guidance_scale=7.5, img=None,
+                   return_all_latents=False, batch_size=2, start_step=10):
+        if isinstance(prompts, str):
+            prompts = [prompts]
+        lat = self.encode_img(img)
+        emb = self.encode_text(prompts)
+        out = self.gen_i2i_latents(emb, height, width, num_inference_steps, guidance_scale, lat, return_all_latents, start_step)
+        imgs = []
+        for i in range(0, len(out), batch_size):
+            imgs.extend(self.decode_img_latents(out[i:i + batch_size]))
+        return imgs

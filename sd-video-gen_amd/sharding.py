@@ -1,0 +1,42 @@
+"""Clip sharding over the GPUs of a node (one process per GPU, torch.distributed; backend "nccl" is RCCL over
+xGMI on ROCm).  The path shards by CLIP: inside a clip every frame depends on the previous one
+(prediction/predict.py:193-196) and the DDIM loop is sequential in t, so there is no data-path collective —
+clips are dealt to ranks, each rank samples its clips with its own full weight replica, and ONE all-gather
+reassembles the generated clips at the end (<= 1 MB per clip: latency-bound, link bandwidth irrelevant).
+Per-clip seeds (base + clip index) make results independent of the world size.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_range(n_clips, rank, world_size):
+    """Contiguous block of clip indices for `rank` (sizes differ by at most one)."""
+    base, rem = divmod(n_clips, world_size)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def clip_seeds(base_seed, start, stop):
+    return [base_seed + c for c in range(start, stop)]
+
+
+def gather_clips(local, n_clips):
+    """local: (c_local, ...) tensor of this rank's clips -> (n_clips, ...) on every rank, in clip order.
+    One all_gather; ragged shards are padded to the largest shard and trimmed."""
+    rank, ws = world()
+    if ws == 1:
+        return local
+    sizes = [shard_range(n_clips, r, ws) for r in range(ws)]
+    cmax = max(b - a for a, b in sizes)
+    pad = local
+    if local.shape[0] < cmax:
+        pad = torch.cat([local, local.new_zeros((cmax - local.shape[0],) + tuple(local.shape[1:]))])
+    out = [torch.empty_like(pad) for _ in range(ws)]
+    dist.all_gather(out, pad.contiguous())
+    return torch.cat([o[: b - a] for o, (a, b) in zip(out, sizes)])
