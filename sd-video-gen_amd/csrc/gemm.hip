@@ -179,26 +179,36 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const GemmArgs g) {
   }
 
   uint4 ra[4], rb[BIT];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
 
+  // Branch-free staging: an invalid chunk (padding tap, row/col out of range, K tail) reads offset 0 of its
+  // tensor (always mapped) and is replaced by zeros with a select — no control flow around the loads, so
+  // the staged tile stays in registers and the loads issue back to back.
+  auto sel = [&](bool ok, uint4 v) -> uint4 {
+    return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+  };
   auto load_tiles = [&](int kt) {
     const int k = kt * BK + c * 8;
+    const bool k_ok = k < g.K;
     if (AMODE == A_DENSE) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        ra[i] = (a_base[i] >= 0 && k < g.K) ? *(const uint4*)(Ap + a_base[i] + k) : zero4;
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = (a_base[i] >= 0) && k_ok;
+        ra[i] = sel(ok, *(const uint4*)(Ap + (ok ? a_base[i] + k : 0)));
+      }
     } else if (AMODE == A_CONV_SMALLC) {
       // Cin == 8: one 16-B chunk per tap
       const int tap = kt * 8 + c;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        int off = tap_offset(i, tap);
-        ra[i] = (off >= 0) ? *(const uint4*)(Ap + off) : zero4;
+        const int off = tap_offset(i, tap);
+        ra[i] = sel(off >= 0, *(const uint4*)(Ap + (off >= 0 ? off : 0)));
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        ra[i] = (a_off[i] >= 0) ? *(const uint4*)(Ap + a_off[i] + ld_cin0 + c * 8) : zero4;
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = a_off[i] >= 0;
+        ra[i] = sel(ok, *(const uint4*)(Ap + (ok ? a_off[i] : 0) + ld_cin0 + c * 8));
+      }
       ld_cin0 += BK;
       if (ld_cin0 >= g.Cin) {
         ld_cin0 = 0;
@@ -208,8 +218,10 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const GemmArgs g) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < BIT; ++i)
-      rb[i] = (b_base[i] >= 0 && k < g.K) ? *(const uint4*)(Bp + b_base[i] + k) : zero4;
+    for (int i = 0; i < BIT; ++i) {
+      const bool ok = (b_base[i] >= 0) && k_ok;
+      rb[i] = sel(ok, *(const uint4*)(Bp + (ok ? b_base[i] + k : 0)));
+    }
   };
 
   auto store_tiles = [&](int buf) {

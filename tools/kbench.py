@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Per-shape kernel timings through the op-level C ABI (hipEvent brackets inside the library).
+usage: python tools/kbench.py [conv|gemm|attn|gn|xf] [--b B]"""
+import argparse
+import math
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sd_video_gen_amd import _lib  # noqa: E402
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def timeit(ctx, fam, fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    rep = ctx.prof_report()
+    ctx.prof_enable(False)
+    r = rep[fam]
+    return r["ms"] / reps, r["flops"] / reps, r["bytes"] / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="*", default=["conv", "gemm", "attn", "gn", "xf"])
+    ap.add_argument("--b", type=int, default=8)
+    a = ap.parse_args()
+    ctx = _lib.Context(0)
+    B = a.b
+    bf = torch.bfloat16
+    if "conv" in a.what:
+        print("== conv3x3 (B=%d): H Cin Cout mode  ms  TFLOP/s" % B)
+        shapes = [(64, 320, 320, 0), (64, 640, 320, 0), (64, 960, 320, 0), (32, 640, 640, 0), (32, 320, 640, 0), (32, 1280, 640, 0),
+                  (32, 1920, 640, 0), (16, 1280, 1280, 0), (16, 640, 1280, 0), (16, 2560, 1280, 0), (8, 1280, 1280, 0), (8, 2560, 1280, 0),
+                  (64, 320, 320, 1), (32, 640, 640, 1), (16, 1280, 1280, 1), (8, 1280, 1280, 3), (16, 1280, 1280, 3), (32, 640, 640, 3),
+                  (64, 8, 320, 0), (64, 320, 4, 0),
+                  (512, 8, 128, 0), (512, 128, 128, 0), (256, 128, 256, 0), (256, 256, 256, 0), (128, 256, 512, 0), (128, 512, 512, 0),
+                  (64, 512, 512, 0), (256, 256, 256, 3), (128, 512, 512, 3), (512, 128, 128, 2), (512, 128, 4, 0)]
+        for (H, Cin, Cout, mode) in shapes:
+            b = B if H <= 64 else max(1, B // 4)
+            x = torch.randn(b, H, H, Cin, device="cuda").to(bf)
+            w = torch.randn(Cout, Cin, 3, 3, device="cuda") / math.sqrt(9 * Cin)
+            Ho = H // 2 if mode in (1, 2) else (2 * H if mode == 3 else H)
+            out = torch.empty(b, Ho, Ho, Cout, device="cuda", dtype=bf)
+            ms, fl, _ = timeit(ctx, "conv3x3", lambda: ctx.check(ctx.lib.svg_op_conv3x3(
+                ctx.h, x.data_ptr(), w.data_ptr(), None, out.data_ptr(), b, H, H, Cin, Cout, mode, stream()), "conv"))
+            print("b=%d %4d %5d %5d %d  %8.3f ms  %7.1f TF" % (b, H, Cin, Cout, mode, ms, fl / ms / 1e9))
+    if "gemm" in a.what:
+        print("== gemm (B=%d): M N K act  ms  TFLOP/s" % B)
+        shapes = []
+        for hw, C in ((4096, 320), (1024, 640), (256, 1280), (64, 1280)):
+            M = hw * B
+            shapes += [(M, C, C, 0), (M, 2 * C, C, 0), (M, 8 * C, C, 3), (M, C, 4 * C, 0)]
+        shapes += [(77 * B, 320, 768, 0), (77 * B, 1280, 768, 0), (B, 1280, 320, 1), (B, 31360, 1280, 0), (8192 * B, 512, 512, 0)]
+        for (M, N, K, act) in shapes:
+            A = torch.randn(M, K, device="cuda").to(bf)
+            W = (torch.randn(N, K, device="cuda") / math.sqrt(K)).to(bf)
+            out = torch.empty(M, N // 2 if act == 3 else N, device="cuda", dtype=bf)
+            ms, fl, _ = timeit(ctx, "gemm", lambda: ctx.check(ctx.lib.svg_op_gemm(
+                ctx.h, A.data_ptr(), W.data_ptr(), None, None, out.data_ptr(), M, N, K, act, 0, stream()), "gemm"))
+            print("%7d %6d %6d %d  %8.3f ms  %7.1f TF" % (M, N, K, act, ms, fl / ms / 1e9))
+    if "attn" in a.what:
+        print("== attention (B=%d): Sq Skv d  ms  TFLOP/s" % B)
+        for (Sq, Skv, d) in ((4096, 4096, 40), (1024, 1024, 80), (256, 256, 160), (64, 64, 160), (4096, 77, 40), (1024, 77, 80), (256, 77, 160)):
+            C = 8 * d
+            Sp = (Skv + 7) // 8 * 8
+            q = torch.randn(B, Sq, C, device="cuda").to(bf)
+            k = torch.randn(B, Skv, C, device="cuda").to(bf)
+            vt = torch.randn(B, C, Sp, device="cuda").to(bf)
+            o = torch.empty_like(q)
+            ms, fl, _ = timeit(ctx, "attention", lambda: ctx.check(ctx.lib.svg_op_attention(
+                ctx.h, q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr(), B, 8, Sq, Skv, d, C, C, Sp, C, Sq * C, Skv * C, C * Sp, Sq * C,
+                1 / math.sqrt(d), stream()), "attn"))
+            print("%5d %5d %4d  %8.3f ms  %7.1f TF" % (Sq, Skv, d, ms, fl / ms / 1e9))
+    if "gn" in a.what:
+        print("== groupnorm+silu (B=%d): HW C  ms  GB/s (read+write once)" % B)
+        for (HW, C) in ((4096, 320), (4096, 640), (4096, 960), (1024, 640), (1024, 1920), (256, 1280), (256, 2560), (64, 1280), (64, 2560),
+                        (262144, 128), (65536, 256), (16384, 512)):
+            b = B if HW <= 4096 else max(1, B // 4)
+            x = torch.randn(b, HW, C, device="cuda").to(bf)
+            g = torch.ones(C, device="cuda")
+            o = torch.empty_like(x)
+            ms, _, _ = timeit(ctx, "groupnorm", lambda: ctx.check(ctx.lib.svg_op_groupnorm(
+                ctx.h, x.data_ptr(), g.data_ptr(), g.data_ptr(), o.data_ptr(), b, HW, C, 32, 1e-5, 1, stream()), "gn"))
+            print("b=%d %7d %5d  %8.3f ms  %7.1f GB/s" % (b, HW, C, ms, 3 * x.numel() * 2 / ms / 1e6))
+    if "xf" in a.what:
+        print("== xf_gemm: M N K  ms  GB/s")
+        for (M, N, K) in ((6, 2048, 2048), (6, 6144, 2048), (48, 6144, 2048), (48, 2048, 2048), (6, 2048, 256), (6, 256, 2048), (48, 4096, 2048)):
+            X = torch.randn(M, K, device="cuda")
+            W = torch.randn(N, K, device="cuda")
+            Y = torch.empty(M, N, device="cuda")
+            ms, _, by = timeit(ctx, "xf_gemm", lambda: ctx.check(ctx.lib.svg_op_xf_gemm(
+                ctx.h, X.data_ptr(), W.data_ptr(), None, Y.data_ptr(), M, N, K, 0, stream()), "xf"))
+            print("%3d %5d %5d  %8.4f ms  %7.1f GB/s" % (M, N, K, ms, N * K * 4 / ms / 1e6))
+
+
+if __name__ == "__main__":
+    main()
