@@ -16,6 +16,7 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -111,20 +112,30 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const GemmArgs g) {
   const bf16* __restrict__ Bp = g.Wt + (int64_t)z * g.sB;
 
   // ---- loader state ---------------------------------------------------------------------------
+  // Global -> register staging uses buffer loads: per-lane byte offset in voffset, the K-slab offset (uniform)
+  // in the scalar soffset, and the hardware range check for zero fill — an invalid chunk (padding tap, row or
+  // column out of range, K tail) gets voffset 0x80000000, which is past num_records and reads as zeros.
+  constexpr unsigned INVALID = 0x80000000u;
   const int c = tid & 7;         // 16-B chunk within the 64-wide K slab
   const int r0 = tid >> 3;       // 0..31
   const int cswz = (c ^ ((r0 >> 1) & 7)) << 4;
+  unsigned a_bytes, b_bytes;
+  if (AMODE == A_DENSE) a_bytes = (unsigned)(((int64_t)(g.M - 1) * g.lda + g.K) * 2);
+  else a_bytes = (unsigned)((int64_t)(g.M / (g.Ho * g.Wo)) * g.H * g.W * g.Cin * 2);
+  b_bytes = (unsigned)(((int64_t)(g.n_valid - 1) * g.ldb + g.K) * 2);
+  const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc((void*)Ap, 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, b_bytes, 0x00020000);
 
   // A rows
-  int a_base[4];                 // dense: element offset of the row; conv: element offset of (b,0,0,0)
+  int a_base[4];                 // conv: element offset of (b,0,0,0)
   int a_yx[4];                   // conv: (y<<16)|x of the output pixel, -1 = row out of range
-  int a_off[4];                  // conv: element offset of the current tap's pixel, -1 = padding
+  unsigned a_voff[4];            // byte offset of this lane's chunk (dense: row; conv: current tap's pixel) or INVALID
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int m = m0 + r0 + 32 * i;
     if (AMODE == A_DENSE) {
-      a_base[i] = (m < g.M) ? m * g.lda : -1;
-      a_yx[i] = 0; a_off[i] = 0;
+      a_voff[i] = (m < g.M) ? (unsigned)(m * g.lda + c * 8) * 2u : INVALID;
+      a_base[i] = 0; a_yx[i] = 0;
     } else {
       if (m < g.M) {
         int hw = g.Ho * g.Wo;
@@ -137,17 +148,18 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const GemmArgs g) {
       } else {
         a_yx[i] = -1; a_base[i] = 0;
       }
-      a_off[i] = -1;
+      a_voff[i] = INVALID;
     }
   }
   // B rows
-  int b_base[BIT];
+  unsigned b_voff[BIT];
 #pragma unroll
   for (int i = 0; i < BIT; ++i) {
     int n = n0 + r0 + 32 * i;
-    b_base[i] = (n < g.n_valid) ? n * g.ldb : -1;
+    b_voff[i] = (n < g.n_valid) ? (unsigned)(n * g.ldb + c * 8) * 2u : INVALID;
   }
 
+  // element offset of the pixel under `tap` for row i, or -1 (padding / row out of range)
   auto tap_offset = [&](int i, int tap) -> int {
     if (a_yx[i] < 0 || tap >= 9) return -1;
     int y = a_yx[i] >> 16, x = a_yx[i] & 0xffff;
@@ -167,6 +179,10 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const GemmArgs g) {
     if ((unsigned)yy >= (unsigned)g.H || (unsigned)xx >= (unsigned)g.W) return -1;
     return a_base[i] + (yy * g.W + xx) * g.Cin;
   };
+  auto tap_voff = [&](int i, int tap) -> unsigned {
+    const int off = tap_offset(i, tap);
+    return off >= 0 ? (unsigned)(off + c * 8) * 2u : INVALID;
+  };
 
   // incremental (tap, cin0) of the K slab being loaded (conv modes with Cin % 64 == 0)
   int ld_tap = 0, ld_cin0 = 0;
@@ -175,62 +191,51 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const GemmArgs g) {
     ld_tap = k0 / g.Cin;
     ld_cin0 = k0 - ld_tap * g.Cin;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a_off[i] = tap_offset(i, ld_tap);
+    for (int i = 0; i < 4; ++i) a_voff[i] = tap_voff(i, ld_tap);
   }
 
-  uint4 ra[4], rb[BIT];
+  u32x4 ra0[4], rb0[BIT], ra1[4], rb1[BIT];   // two staged K slabs in flight (statically indexed)
+  const bool k_tail = (g.K & (BK - 1)) != 0;
 
-  // Branch-free staging: an invalid chunk (padding tap, row/col out of range, K tail) reads offset 0 of its
-  // tensor (always mapped) and is replaced by zeros with a select — no control flow around the loads, so
-  // the staged tile stays in registers and the loads issue back to back.
-  auto sel = [&](bool ok, uint4 v) -> uint4 {
-    return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
-  };
-  auto load_tiles = [&](int kt) {
-    const int k = kt * BK + c * 8;
-    const bool k_ok = k < g.K;
+  auto load_tiles = [&](int kt, u32x4 (&ra)[4], u32x4 (&rb)[BIT]) {
+    const int ksoff = kt * (BK * 2);                        // bytes, wave-uniform
+    const bool k_ok = !k_tail || (kt * BK + c * 8 < g.K);   // only the last slab of a ragged K can fail
     if (AMODE == A_DENSE) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bool ok = (a_base[i] >= 0) && k_ok;
-        ra[i] = sel(ok, *(const uint4*)(Ap + (ok ? a_base[i] + k : 0)));
-      }
+      for (int i = 0; i < 4; ++i)
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(srdA, k_ok ? a_voff[i] : INVALID, ksoff, 0);
     } else if (AMODE == A_CONV_SMALLC) {
       // Cin == 8: one 16-B chunk per tap
       const int tap = kt * 8 + c;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int off = tap_offset(i, tap);
-        ra[i] = sel(off >= 0, *(const uint4*)(Ap + (off >= 0 ? off : 0)));
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(srdA, off >= 0 ? (unsigned)off * 2u : INVALID, 0, 0);
       }
     } else {
+      const int csoff = ld_cin0 * 2;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bool ok = a_off[i] >= 0;
-        ra[i] = sel(ok, *(const uint4*)(Ap + (ok ? a_off[i] : 0) + ld_cin0 + c * 8));
-      }
+      for (int i = 0; i < 4; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(srdA, a_voff[i], csoff, 0);
       ld_cin0 += BK;
       if (ld_cin0 >= g.Cin) {
         ld_cin0 = 0;
         ++ld_tap;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a_off[i] = tap_offset(i, ld_tap);
+        for (int i = 0; i < 4; ++i) a_voff[i] = tap_voff(i, ld_tap);
       }
     }
 #pragma unroll
-    for (int i = 0; i < BIT; ++i) {
-      const bool ok = (b_base[i] >= 0) && k_ok;
-      rb[i] = sel(ok, *(const uint4*)(Bp + (ok ? b_base[i] + k : 0)));
-    }
+    for (int i = 0; i < BIT; ++i)
+      rb[i] = __builtin_amdgcn_raw_buffer_load_b128(srdB, k_ok ? b_voff[i] : INVALID, ksoff, 0);
   };
 
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf, const u32x4 (&ra)[4], const u32x4 (&rb)[BIT]) {
     char* sa = smem + buf * (A_BYTES + B_BYTES);
     char* sb = sa + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *(uint4*)(sa + (r0 + 32 * i) * 128 + cswz) = ra[i];
+    for (int i = 0; i < 4; ++i) *(u32x4*)(sa + (r0 + 32 * i) * 128 + cswz) = ra[i];
 #pragma unroll
-    for (int i = 0; i < BIT; ++i) *(uint4*)(sb + (r0 + 32 * i) * 128 + cswz) = rb[i];
+    for (int i = 0; i < BIT; ++i) *(u32x4*)(sb + (r0 + 32 * i) * 128 + cswz) = rb[i];
   };
 
   f32x4 acc[MT][NT];
@@ -259,17 +264,25 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const GemmArgs g) {
     }
   };
 
+  // Software pipeline, prefetch distance 2: while slab t is multiplied out of LDS stage t&1, slab t+1 sits in
+  // one register set (written to the other LDS stage after the MFMAs) and slab t+2 is in flight in the second.
   if (kt_begin < kt_end) {
-    load_tiles(kt_begin);
-    store_tiles(0);
+    load_tiles(kt_begin, ra0, rb0);
+    store_tiles(0, ra0, rb0);
+    if (kt_begin + 1 < kt_end) load_tiles(kt_begin + 1, ra0, rb0);
+    if (kt_begin + 2 < kt_end) load_tiles(kt_begin + 2, ra1, rb1);
     __syncthreads();
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      const int buf = (kt - kt_begin) & 1;
-      const bool more = (kt + 1 < kt_end);
-      if (more) load_tiles(kt + 1);
-      compute(buf);
-      if (more) store_tiles(buf ^ 1);
+    for (int kt = kt_begin; kt < kt_end; kt += 2) {
+      compute(0);
+      if (kt + 1 < kt_end) store_tiles(1, ra0, rb0);
       __syncthreads();
+      if (kt + 3 < kt_end) load_tiles(kt + 3, ra0, rb0);
+      if (kt + 1 < kt_end) {
+        compute(1);
+        if (kt + 2 < kt_end) store_tiles(0, ra1, rb1);
+        __syncthreads();
+        if (kt + 4 < kt_end) load_tiles(kt + 4, ra1, rb1);
+      }
     }
   }
 
@@ -394,11 +407,20 @@ int pick_bn(const GemmArgs& g) {
   if (g.act == ACT_GEGLU) return 128;
   if (g.N <= 32) return 32;
   if (g.N <= 64) return 64;
-  if (g.N % 160 == 0 && g.N % 128 != 0) return 160;
-  if (g.N % 128 == 0) return 128;
-  // fewest wasted columns
-  int w128 = (g.N + 127) / 128 * 128 - g.N, w160 = (g.N + 159) / 160 * 160 - g.N;
-  return (w160 < w128) ? 160 : 128;
+  // per-CU serial work ~ ceil(blocks / 256) * BN (blocks beyond one per CU share the matrix pipe); ties go to the
+  // width with fewer padded columns, then to the wider tile (the A panel is re-read once per column tile)
+  const int64_t tm = (int64_t)cdiv(g.M, BM) * g.batch;
+  int best = 128;
+  int64_t best_cost = -1, best_pad = 0;
+  for (int bn : {128, 160}) {
+    const int64_t tn = cdiv(g.N, bn);
+    const int64_t cost = ((tm * tn + 255) / 256) * bn;
+    const int64_t pad = tn * bn - g.N;
+    if (best_cost < 0 || cost < best_cost || (cost == best_cost && (pad < best_pad || (pad == best_pad && bn > best)))) {
+      best = bn; best_cost = cost; best_pad = pad;
+    }
+  }
+  return best;
 }
 
 }  // namespace

@@ -63,11 +63,13 @@ __global__ void gn_stats_kernel(const bf16* __restrict__ x, int C1, const bf16* 
 }
 
 // ---- GroupNorm stage 2: finish the statistics, normalise, affine, optional SiLU ------------------
-// grid (nblk, B); each block handles a contiguous range of pixels of one sample.
-__global__ void __launch_bounds__(256) gn_apply_kernel(const bf16* __restrict__ x, int C1, const bf16* __restrict__ x2, int C2,
+// grid (nblk, B); block = CV*PL threads like stage 1.  Each thread owns one 8-channel vector: it folds
+// (mean, rstd, gamma, beta) into 8 (scale, shift) pairs once, then streams its pixels with 16-B loads/stores
+// and 8 FMAs per vector — no divisions or table lookups in the loop.
+__global__ void gn_apply_kernel(const bf16* __restrict__ x, int C1, const bf16* __restrict__ x2, int C2,
                                 const float* __restrict__ partial, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, bf16* __restrict__ out, int HW, int groups,
-                                int nchunk, float eps, int silu) {
+                                int nchunk, float eps, int silu, int CV, int PL) {
   __shared__ float mean_s[64], rstd_s[64];
   const int C = C1 + C2;
   const int b = blockIdx.y;
@@ -85,29 +87,40 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16* __restrict__ 
     rstd_s[g] = rsqrtf(var + eps);
   }
   __syncthreads();
-  const int CV = C / 8;
-  const int64_t total = (int64_t)HW * CV;
-  const int64_t per_blk = (total + gridDim.x - 1) / gridDim.x;
-  const int64_t begin = blockIdx.x * per_blk, end = min(total, begin + per_blk);
-  for (int64_t idx = begin + threadIdx.x; idx < end; idx += blockDim.x) {
-    const int cv = (int)(idx % CV);
-    const int64_t p = idx / CV;
-    const int c0 = cv * 8;
-    const bf16* src; int ld, coff;
-    if (c0 < C1) { src = x; ld = C1; coff = c0; } else { src = x2; ld = C2; coff = c0 - C1; }
-    bf16x8 v = *(const bf16x8*)(src + ((int64_t)b * HW + p) * ld + coff);
-    bf16x8 o;
+  const int tid = threadIdx.x;
+  if (tid >= CV * PL) return;
+  const int cv = tid % CV, pl = tid / CV;
+  const int c0 = cv * 8;
+  float sc[8], sh[8];
+  {
     int g = c0 / cpg, rem = c0 - g * cpg;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int cc = c0 + j;
       if (rem == cpg) { rem = 0; ++g; }
       ++rem;
-      float f = ((float)v[j] - mean_s[g]) * rstd_s[g] * gamma[cc] + beta[cc];
-      if (silu) f = f / (1.f + __expf(-f));
+      const float a = rstd_s[g] * gamma[c0 + j];
+      sc[j] = a;
+      sh[j] = beta[c0 + j] - mean_s[g] * a;
+    }
+  }
+  const bf16* src; int ld, coff;
+  if (c0 < C1) { src = x; ld = C1; coff = c0; } else { src = x2; ld = C2; coff = c0 - C1; }
+  const int per_blk = (HW + gridDim.x - 1) / gridDim.x;
+  const int p_begin = blockIdx.x * per_blk;
+  const int p_end = min(HW, p_begin + per_blk);
+  const bf16* sp = src + ((int64_t)b * HW + p_begin + pl) * ld + coff;
+  bf16* dp = out + ((int64_t)b * HW + p_begin + pl) * C + c0;
+  const int64_t sstep = (int64_t)PL * ld, dstep = (int64_t)PL * C;
+  for (int p = p_begin + pl; p < p_end; p += PL, sp += sstep, dp += dstep) {
+    const bf16x8 v = *(const bf16x8*)sp;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f = fmaf((float)v[j], sc[j], sh[j]);
+      if (silu) f = f * __builtin_amdgcn_rcpf(1.f + __expf(-f));
       o[j] = (bf16)f;
     }
-    *(bf16x8*)(out + ((int64_t)b * HW + p) * C + c0) = o;
+    *(bf16x8*)dp = o;
   }
 }
 
@@ -206,10 +219,11 @@ void groupnorm(svg_ctx* ctx, const bf16* x, int C1, const bf16* x2, int C2, cons
     }
     {
       ProfScope ps(ctx, PK_GNORM, s, 0, 2 * bytes);
-      const int64_t total = (int64_t)HW * CV;
-      int nblk = (int)std::min<int64_t>(std::max<int64_t>(1, total / 1024), 1024);
-      hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, B), dim3(256), 0, s, x, C1, x2, C2, partial, gamma, beta, out, HW,
-                         groups, nchunk, eps, silu);
+      const int threads = std::max((CV * PL + 63) / 64 * 64, 64);
+      // ~16 pixels per thread, at least enough blocks to fill the chip
+      int nblk = std::max(1, std::min(HW / PL, std::max(HW / (PL * 16), (2048 + B - 1) / B)));
+      hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, B), dim3(threads), 0, s, x, C1, x2, C2, partial, gamma, beta, out, HW,
+                         groups, nchunk, eps, silu, CV, PL);
       check_launch("gn_apply");
     }
   }
