@@ -41,13 +41,25 @@ def parse():
     return p.parse_args()
 
 
+def host_cores():
+    """CPU cores this process may actually use: affinity mask, cgroup quota, and the GPU box's per-GPU share (16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("SVG_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(cfg_name, start_step):
     """The CPU restatement (oracle/, kind "port") timed on this host's cores on a bounded sample of the same
     per-frame work; linear extrapolation to (50 - start_step) UNet steps and to 512x512 VAE passes is stated."""
     import torch
     from oracle import sd_oracle as SO, transformer_oracle as TO
     from sd_video_gen_amd import sd_layout
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     t = {}
 
@@ -69,7 +81,7 @@ def cpu_baseline(cfg_name, start_step):
         sd = m.state_dict()
         D = m.d_lat
         X = torch.randn(1, 6, D)
-        timed("transformer", lambda: TO.predict(sd, X, cfg.NUM_HEADS[0]), reps=2)
+        timed("transformer", lambda: TO.predict(sd, X, cfg.NUM_HEADS[0]), reps=3)
         del m, sd
         usd = sd_layout.seeded_weights(sd_layout.unet_shapes(), 2)
         x = torch.randn(1, 4, 64, 64)

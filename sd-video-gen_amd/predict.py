@@ -124,3 +124,91 @@ def rollout_latents(model, new_batch, pred_frames, post=None):
         X = all_latents[:, -5:]                                      # predict.py:196
         trace.append((shape_in, tuple(all_latents.shape)))
     return all_latents, trace
+
+
+# ---- `python -m prediction.predict` (reference prediction/predict.py:44-247) ---------------------------------------
+def _png_clips(folder, frame_size, n_frames=5):
+    """Fixed-length clips of consecutive PNG frames under `folder` (one clip per sub-directory run), BGR like cv2.imread."""
+    import glob
+    import os
+    import numpy as np
+    from PIL import Image
+    clips = []
+    dirs = sorted({os.path.dirname(p) for p in glob.glob(os.path.join(folder, "**", "*.png"), recursive=True)})
+    for d in dirs:
+        files = sorted(glob.glob(os.path.join(d, "*.png")))
+        for i in range(0, len(files) - n_frames + 1, n_frames):
+            fr = [np.asarray(Image.open(f).convert("RGB").resize((frame_size, frame_size), Image.NEAREST))[..., ::-1] for f in files[i:i + n_frames]]
+            clips.append(np.stack(fr))
+    if not clips:
+        raise ValueError("no PNG clips of %d frames under %s" % (n_frames, folder))
+    return torch.from_numpy(np.ascontiguousarray(np.stack(clips)))
+
+
+def save_frames(frames_u8, is_pred, out_dir):
+    """predict.py:201-223: one PNG per frame, predicted frames get a 1-px red border (BGR [0,0,255])."""
+    import os
+    import numpy as np
+    from PIL import Image
+    os.makedirs(out_dir, exist_ok=True)
+    for i, img in enumerate(frames_u8):
+        img = np.asarray(img)
+        if is_pred[i]:
+            b = np.zeros((img.shape[0] + 2, img.shape[1] + 2, 3), dtype=np.uint8)
+            b[..., 2] = 255
+            b[1:-1, 1:-1] = img
+            img = b
+        Image.fromarray(np.ascontiguousarray(img[..., ::-1])).save(os.path.join(out_dir, "%d.png" % i))
+
+
+def main(argv=None):
+    """Same flags and flow as the reference's __main__; datasets: 'synthetic-ball' (built in) or a folder of PNG
+    clips via --folder.  Clips are sharded over ranks when launched under torch.distributed.run."""
+    import os
+    from . import config as svg_config, sharding
+    from .sd_utils import SDUtils
+    from .transformer import Transformer
+    if argv is not None:
+        svg_config.set_args(argv)
+    config, args = svg_config.parse_config_args()
+    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl")
+    rank, ws = sharding.world()
+    sd_utils = SDUtils(verbose=(rank == 0))
+    device = sd_utils.device
+    model = Transformer(num_tokens=0, dim_model=config.DIM_MODEL[0], num_heads=config.NUM_HEADS[0],
+                        num_encoder_layers=config.NUM_ENCODER_LAYERS[0], num_decoder_layers=config.NUM_DECODER_LAYERS[0],
+                        dropout_p=config.DROPOUT_P[0])
+    ckpt = "./checkpoints/" + str(args.config) + "_" + str(args.index) + "_" + str(args.mode) + ".pt"     # predict.py:51
+    if os.path.exists(ckpt):
+        model.load_state_dict(torch.load(ckpt, map_location="cpu"))
+    elif rank == 0:
+        print("[sd-video-gen] checkpoint %s not found: sampling with the seeded initial weights" % ckpt)
+    model.eval()
+    F = config.FRAME_SIZE
+    if args.dataset in ("synthetic-ball", "synthetic"):
+        clips = bouncing_ball_clips(8, F, 5, seed=0)
+    elif args.folder:
+        clips = _png_clips(args.folder, F)
+    elif args.dataset in ("ball", "kitti") or "ucf" in args.dataset:
+        raise ValueError("dataset '%s' needs --folder with PNG clips (the reference's loaders/datasets are not bundled)" % args.dataset)
+    else:
+        raise ValueError("Invalid dataset name")                                                          # predict.py:70
+    n = clips.shape[0]
+    a, b = sharding.shard_range(n, rank, ws)
+    out = sample_clips(model, sd_utils, clips[a:b].to(device), args.pred_frames, denoise=bool(args.denoise),
+                       start_step=args.denoise_start_step, seeds=sharding.clip_seeds(0, a, b), return_frames=True)
+    lat = sharding.gather_clips(out[0], n)
+    frames = sharding.gather_clips(out[1], n)
+    if rank == 0:
+        print("all_latents shape: ", tuple(lat.shape))
+        if args.save_output:
+            n_in = 4
+            for c in range(n):
+                os.makedirs("outputs", exist_ok=True)
+                folder_index = len(os.listdir("outputs"))
+                save_frames(frames[c].cpu().numpy(), [False] * n_in + [True] * (frames.shape[1] - n_in),
+                            os.path.join("outputs", str(folder_index)))
+    return lat
