@@ -28,7 +28,7 @@ def clip_noise(seeds, shape, device):
 
 
 def sample_clips(model, sd_utils, clips_u8, pred_frames, denoise=False, start_step=40, seeds=None,
-                 text_embeddings=None, num_inference_steps=50, guidance_scale=0.0, return_frames=False, timers=None):
+                 text_embeddings=None, num_inference_steps=50, guidance_scale=0.0, return_frames=False, res=512):
     """The per-clip loop of prediction/predict.py:117-197 for C independent clips in lock step, device resident.
 
     clips_u8: (C,5,F,F,3) uint8 conditioning frames on the device.  Every stage is batched over clips; a clip's
@@ -65,9 +65,9 @@ def sample_clips(model, sd_utils, clips_u8, pred_frames, denoise=False, start_st
             pred = predict(model, X, pe_row=pe0)                                            # :144  (C, D)
             if denoise:
                 noisy_img = ctx.vae_decode(pred.reshape(C, 4, L, L))                        # :149-153 (uint8, on device)
-                e512 = clip_noise(gens, (4, 64, 64), dev)
-                resized = ctx.vae_encode(noisy_img, H=512, W=512, eps=e512)                 # :158 resize + :163-164
-                noise = clip_noise(gens, (4, 64, 64), dev) if 0 < start_step else None
+                e512 = clip_noise(gens, (4, res // 8, res // 8), dev)
+                resized = ctx.vae_encode(noisy_img, H=res, W=res, eps=e512)                 # :158 resize + :163-164
+                noise = clip_noise(gens, (4, res // 8, res // 8), dev) if 0 < start_step else None
                 den = ctx.ddim_loop(resized, emb, num_steps=num_inference_steps, start_step=start_step,
                                     guidance=guidance_scale, noise=noise)                   # :168-170
                 small = ctx.vae_decode(den, out_hw=(F, F))                                  # :173-179

@@ -71,7 +71,7 @@ class _UNet:
 
 
 class SDUtils():
-    def __init__(self, weights=None, text_embeddings=None, seed=0, verbose=True):
+    def __init__(self, weights=None, text_embeddings=None, seed=0, verbose=True, arch=None):
         self.config, self.args = parse_config_args()             # sd_utils.py:22
         self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
         if self.device.type != "cuda":
@@ -80,6 +80,9 @@ class SDUtils():
         self._seed = seed
         self._verbose = verbose
         self._text_embeddings = text_embeddings
+        # `arch` overrides the SD v1.4 widths (reduced-size parity tests): {'vae': {...}, 'unet': {...}}
+        self.vae_arch = dict(sd_layout.SD_VAE, **((arch or {}).get('vae', {})))
+        self.unet_arch = dict(sd_layout.SD_UNET, **((arch or {}).get('unet', {})))
         vae, tokenizer, text_encoder, unet, scheduler = self.load_models(weights)
         self.vae = vae
         # sd_utils.py:30 builds a default-size Transformer and throws it away; it consumes CPU RNG, which matters
@@ -107,15 +110,16 @@ class SDUtils():
 
     def load_models(self, weights=None):
         ctx = self.ctx
-        sd, self.vae_source = self._weights_for("vae", weights, sd_layout.vae_shapes, self._seed + 1)
-        ctx.configure(_lib.SVG_VAE, block_out=list(sd_layout.SD_VAE["block_out"]), layers=2, groups=32, latent=4)
+        va = self.vae_arch
+        sd, self.vae_source = self._weights_for("vae", weights, lambda: sd_layout.vae_shapes(va), self._seed + 1)
+        ctx.configure(_lib.SVG_VAE, block_out=list(va["block_out"]), layers=va["layers"], groups=va["groups"], latent=4)
         ctx.load_state_dict(_lib.SVG_VAE, sd)
         vae = _VAE(ctx, ctx.finalize(_lib.SVG_VAE))
         del sd
         if not self.args.denoise:
             return vae, None, None, None, None
-        sd, self.unet_source = self._weights_for("unet", weights, sd_layout.unet_shapes, self._seed + 2)
-        c = sd_layout.SD_UNET
+        c = self.unet_arch
+        sd, self.unet_source = self._weights_for("unet", weights, lambda: sd_layout.unet_shapes(c), self._seed + 2)
         ctx.configure(_lib.SVG_UNET, block_out=list(c["block_out"]), layers=c["layers"], heads=c["heads"], ctx_dim=c["ctx_dim"],
                       groups=c["groups"], in_ch=4, out_ch=4, attn=list(c["attn"]))
         ctx.load_state_dict(_lib.SVG_UNET, sd)

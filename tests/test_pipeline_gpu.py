@@ -1,0 +1,101 @@
+"""GPU: the whole sampling loop (sample_clips -> C ABI) against the CPU loop oracle on identical seeded weights,
+clips and noise; batch invariance of the clip-batched loop; the reference-shaped SDUtils surface."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import loop_oracle, sd_oracle as SO  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+VCFG = dict(block_out=(64, 128, 128, 128), layers=1, groups=32, latent=4)
+UCFG = dict(block_out=(64, 128), layers=1, heads=4, ctx_dim=768, groups=32, in_ch=4, out_ch=4, attn=(1, 0))
+
+
+def build(denoise, seed=3):
+    from sd_video_gen_amd import config as svg_config
+    from sd_video_gen_amd.sd_utils import SDUtils
+    from sd_video_gen_amd.transformer import Transformer
+    svg_config.set_args(["--dataset", "synthetic-ball", "--config", "model_10_26"] + (["--denoise", "1"] if denoise else []))
+    vsd = SO.seeded_weights(SO.vae_shapes(VCFG), seed)
+    usd = SO.seeded_weights(SO.unet_shapes(UCFG), seed + 1)
+    sdu = SDUtils(weights={"vae": vsd, "unet": usd}, arch={"vae": VCFG, "unet": UCFG}, verbose=False)
+    torch.manual_seed(seed)
+    m = Transformer(dim_model=64, num_heads=4, num_encoder_layers=1, num_decoder_layers=2).eval()
+    return sdu, m, vsd, usd
+
+
+def clip_noise_cpu(seed, res, F, pred_frames, start_step):
+    """the per-clip draws of sample_clips, reproduced: a cuda generator seeded `seed`, in the documented order."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    L = F // 8
+    n = {"cond": torch.randn((5, 4, L, L), generator=g, device="cuda").cpu(), "e512": [], "add": [], "eF": []}
+    for _ in range(pred_frames):
+        n["e512"].append(torch.randn((4, res // 8, res // 8), generator=g, device="cuda").cpu())
+        if start_step > 0:
+            n["add"].append(torch.randn((4, res // 8, res // 8), generator=g, device="cuda").cpu())
+        n["eF"].append(torch.randn((4, L, L), generator=g, device="cuda").cpu())
+    return n
+
+
+def test_loop_no_denoise_matches_oracle(ctx):
+    from sd_video_gen_amd.predict import sample_clips, bouncing_ball_clips
+    sdu, m, vsd, _ = build(False)
+    clips = bouncing_ball_clips(3, 64, 5, seed=5)
+    seeds = [11, 12, 13]
+    lat, frames = sample_clips(m, sdu, clips.cuda(), 4, seeds=seeds, return_frames=True)
+    assert lat.shape == (3, 8, 256) and frames.shape == (3, 8, 64, 64, 3)          # 4 cond + 4 pred
+    xsd = {k: v.cpu() for k, v in m.state_dict().items()}
+    for c in range(3):
+        noise = clip_noise_cpu(seeds[c], 512, 64, 0, 0)
+        ref = loop_oracle.sample_clip(xsd, 4, vsd, clips[c], 4, noise, vae_cfg=VCFG)
+        assert rel_l2(lat[c:c + 1].cpu(), ref) < 3e-2
+    # batch invariance: a clip sampled alone equals the same clip inside the batch
+    alone = sample_clips(m, sdu, clips[1:2].cuda(), 4, seeds=seeds[1:2])
+    assert rel_l2(alone.cpu(), lat[1:2].cpu()) < 2e-3
+
+
+def test_loop_denoise_matches_oracle(ctx):
+    """denoise round trip at a reduced resolution (128 instead of 512) and 3 DDIM steps so the CPU oracle stays short."""
+    from sd_video_gen_amd.predict import sample_clips, bouncing_ball_clips
+    sdu, m, vsd, usd = build(True)
+    clips = bouncing_ball_clips(2, 64, 5, seed=9)
+    seeds = [21, 22]
+    emb = sdu.encode_text([""])
+    assert emb.shape == (2, 77, 768) and torch.equal(emb[0], emb[1])               # [uncond(''); text('')]
+    S = 47
+    lat = sample_clips(m, sdu, clips.cuda(), 2, denoise=True, start_step=S, seeds=seeds, text_embeddings=emb, res=128)
+    assert lat.shape == (2, 6, 256) and torch.isfinite(lat).all()
+    xsd = {k: v.cpu() for k, v in m.state_dict().items()}
+    for c in range(2):
+        noise = clip_noise_cpu(seeds[c], 128, 64, 2, S)
+        ref = loop_oracle.sample_clip(xsd, 4, vsd, clips[c], 2, noise, denoise=True, start_step=S, unet_sd=usd,
+                                      text_emb=emb.cpu(), vae_cfg=VCFG, unet_cfg=UCFG, res=128)
+        # three uint8 round trips per frame sit between the networks: a 1-LSB pixel difference re-enters the encoder
+        assert rel_l2(lat[c:c + 1].cpu(), ref) < 6e-2
+
+
+def test_sdutils_reference_surface(ctx):
+    sdu, m, vsd, usd = build(True)
+    for attr in ("vae", "unet", "text_encoder", "tokenizer", "scheduler", "device", "SOS_token", "config", "args"):
+        assert hasattr(sdu, attr)
+    assert sdu.SOS_token.shape == (1, 1, 256) and float(sdu.SOS_token[0, 0, 0]) == 2.0
+    batch = torch.randint(0, 256, (1, 5, 64, 64, 3), dtype=torch.uint8)
+    nb = sdu.encode_batch(batch, use_sos=True)
+    assert nb.shape == (1, 6, 256) and nb.is_cuda and torch.equal(nb[:, 0], sdu.SOS_token[0])
+    assert sdu.encode_batch(batch, use_sos=False).shape == (1, 5, 256)
+    img = sdu.decode_img_latents(nb[0, 1].reshape(1, 4, 8, 8))
+    assert isinstance(img, np.ndarray) and img.shape == (1, 64, 64, 3) and img.dtype == np.uint8   # host array like the reference
+    out = sdu.gen_i2i_latents(sdu.encode_text([""]), latents=torch.randn(1, 4, 16, 16), guidance_scale=0, start_step=48)
+    assert out.shape == (1, 4, 16, 16)
+    hist = sdu.gen_i2i_latents(sdu.encode_text([""]), latents=torch.randn(1, 4, 16, 16), guidance_scale=0, start_step=48,
+                               return_all_latents=True)
+    assert hist.shape == (3, 4, 16, 16)
+    assert sdu.unet(torch.randn(2, 4, 16, 16).cuda(), 500, encoder_hidden_states=torch.randn(2, 77, 768).cuda())["sample"].shape == (2, 4, 16, 16)
