@@ -85,8 +85,16 @@ struct XfBlockW {   // SpatialTransformer with one BasicTransformerBlock
   PackedLinear proj_in, proj_out, qk1, v1, o1, q2, k2, v2, o2, ff1, ff2;
   int C = 0;
 };
+// cross-attention K / V^T of a constant context, computed on the first DDIM step and reused by the others
+struct KvCache {
+  std::vector<bf16*> k, vt;
+  std::vector<int64_t> k_cap, vt_cap;
+  bool valid = false;
+};
+
 struct UnetModel {
   WeightStore ws;
+  KvCache kv;
   std::vector<int> block_out{320, 640, 1280, 1280};
   std::vector<int> attn{1, 1, 1, 0};
   int layers = 2, heads = 8, ctx_dim = 768, groups = 32, in_ch = 4, out_ch = 4;
@@ -102,7 +110,7 @@ struct UnetModel {
   void configure(const char* kv);
   void finalize(svg_ctx* ctx, int64_t* n_params);
   void forward(svg_ctx* ctx, const float* x, int N, int h, int w, const float* timesteps, const float* ctx_emb, int ctx_len,
-               float* eps_out, hipStream_t s);
+               float* eps_out, hipStream_t s, KvCache* cache = nullptr);
   void ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const float* text_emb, int ctx_len, int num_steps,
                  int start_step, float guidance, const float* noise, float* hist, hipStream_t s);
   void ddim_coefs(int t, int t_prev, float* sa, float* s1a, float* sap, float* s1ap) const;

@@ -184,6 +184,8 @@ struct UnetRun {
   const bf16* ctxb; int L, Lp;     // context (N*L, ctx_dim) bf16; Lp = L padded to 8
   const float* temb;               // (N, temb_total) f32: every resnet's time_emb_proj(silu(temb))
   int temb_ld;
+  KvCache* cache = nullptr;        // cross-attention K / V^T reuse across DDIM steps (constant context)
+  int xf_idx = 0;
 
   bf16* resnet(const bf16* x, int Cx, const bf16* skip, int Cs, const ResW& r, int H, int W) {
     const int64_t P = (int64_t)N * H * W;
@@ -225,14 +227,17 @@ struct UnetRun {
   }
 
   // V^T[b] (C x SkvPad) = Wv * src_b^T
-  bf16* vt_proj(const PackedLinear& wv, const bf16* src, int rows, int rows_pad, int K) {
+  void vt_proj_into(const PackedLinear& wv, const bf16* src, int rows, int rows_pad, int K, bf16* vt) {
     const int C = wv.N;
-    bf16* vt = ctx->arena.get<bf16>((int64_t)N * C * rows_pad);
     GemmArgs g;
     g.A = wv.w; g.lda = K; g.Wt = src; g.ldb = K; g.M = C; g.N = rows_pad; g.n_valid = rows; g.K = K;
     g.batch = N; g.sA = 0; g.sB = (int64_t)rows * K; g.sC = (int64_t)C * rows_pad;
     g.C = vt; g.ldc = rows_pad;
     gemm_auto(ctx, g, s, PK_GEMM);
+  }
+  bf16* vt_proj(const PackedLinear& wv, const bf16* src, int rows, int rows_pad, int K) {
+    bf16* vt = ctx->arena.get<bf16>((int64_t)N * wv.N * rows_pad);
+    vt_proj_into(wv, src, rows, rows_pad, K, vt);
     return vt;
   }
 
@@ -267,9 +272,22 @@ struct UnetRun {
       ctx->arena.push();
       bf16* q = ctx->arena.get<bf16>(P * C);
       linear(ctx, ln, C, b.q2, q, C, M, ACT_NONE, nullptr, 0, 0, s);
-      bf16* k = ctx->arena.get<bf16>((int64_t)N * L * C);
-      linear(ctx, ctxb, m->ctx_dim, b.k2, k, C, N * L, ACT_NONE, nullptr, 0, 0, s);
-      bf16* vt = vt_proj(b.v2, ctxb, L, Lp, m->ctx_dim);
+      const int idx = xf_idx++;
+      const int64_t kn = (int64_t)N * L * C, vn = (int64_t)N * C * Lp;
+      bf16 *k, *vt;
+      if (cache && SVG_LAUNCHING(ctx)) {
+        if ((int)cache->k.size() <= idx) { cache->k.resize(idx + 1, nullptr); cache->vt.resize(idx + 1, nullptr); cache->k_cap.resize(idx + 1, 0); cache->vt_cap.resize(idx + 1, 0); }
+        if (cache->k_cap[idx] < kn) { cache->k[idx] = (bf16*)ctx->dalloc(kn * sizeof(bf16)); cache->k_cap[idx] = kn; cache->valid = false; }
+        if (cache->vt_cap[idx] < vn) { cache->vt[idx] = (bf16*)ctx->dalloc(vn * sizeof(bf16)); cache->vt_cap[idx] = vn; cache->valid = false; }
+        k = cache->k[idx]; vt = cache->vt[idx];
+      } else {
+        k = ctx->arena.get<bf16>(kn);
+        vt = ctx->arena.get<bf16>(vn);
+      }
+      if (!(cache && cache->valid && SVG_LAUNCHING(ctx))) {
+        linear(ctx, ctxb, m->ctx_dim, b.k2, k, C, N * L, ACT_NONE, nullptr, 0, 0, s);
+        vt_proj_into(b.v2, ctxb, L, Lp, m->ctx_dim, vt);
+      }
       attn_core(q, C, k, C, (int64_t)L * C, vt, Lp, (int64_t)C * Lp, ao, C, HW, L);
       ctx->arena.pop();
     }
@@ -292,7 +310,7 @@ struct UnetRun {
 }  // namespace
 
 void UnetModel::forward(svg_ctx* ctx, const float* x, int N, int h, int w, const float* timesteps, const float* ctx_emb,
-                        int ctx_len, float* eps_out, hipStream_t s) {
+                        int ctx_len, float* eps_out, hipStream_t s, KvCache* cache) {
   SVG_CHECK(ready, "unet: svg_finalize has not been called");
   const int nb = (int)block_out.size();
   const int down = 1 << (nb - 1);
@@ -300,6 +318,7 @@ void UnetModel::forward(svg_ctx* ctx, const float* x, int N, int h, int w, const
   SVG_CHECK(ctx_len >= 1, "unet: empty context");
   const int c0 = block_out[0];
   UnetRun r{ctx, this, s, N};
+  r.cache = cache;
   r.L = ctx_len; r.Lp = (int)align_up(ctx_len, 8);
   // context -> bf16
   bf16* cb = ctx->arena.get<bf16>((int64_t)N * ctx_len * ctx_dim);
@@ -365,6 +384,7 @@ void UnetModel::forward(svg_ctx* ctx, const float* x, int N, int h, int w, const
   float* o = ctx->arena.get<float>((int64_t)N * H * W * conv_out.Opad);
   conv3x3(ctx, t, conv_out, o, N, H, W, A_CONV_S1, nullptr, 0, nullptr, 1, s);
   if (SVG_LAUNCHING(ctx)) { ProfScope ps(ctx, PK_ELT, s, 0, 0); actf32_to_nchw(o, conv_out.Opad, eps_out, N, out_ch, H, W, s); }
+  if (cache && SVG_LAUNCHING(ctx)) cache->valid = true;   // every block's K / V^T of this context is now stored
 }
 
 void UnetModel::ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const float* text_emb, int ctx_len, int num_steps,
@@ -381,6 +401,7 @@ void UnetModel::ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const flo
 
   // planned once for the whole loop: every step has the same shapes
   auto body = [&]() {
+    kv.valid = false;   // the context is constant over the loop: K / V^T of the cross-attentions are computed once
     float* tvec = ctx->arena.get<float>(NB);
     float* zin = cfg ? ctx->arena.get<float>(2 * n) : nullptr;
     float* eps = ctx->arena.get<float>((int64_t)NB * n / N);
@@ -402,7 +423,7 @@ void UnetModel::ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const flo
         }
       }
       // guidance == 0: noise_pred = uncond + 0*(text - uncond) == uncond — only the uncond half is needed
-      forward(ctx, cfg ? zin : z, NB, h, w, tvec, text_emb, ctx_len, eps, s);
+      forward(ctx, cfg ? zin : z, NB, h, w, tvec, text_emb, ctx_len, eps, s, &kv);
       if (SVG_LAUNCHING(ctx)) {
         float sa, s1a, sap, s1ap;
         ddim_coefs(t, t - ratio, &sa, &s1a, &sap, &s1ap);

@@ -6,7 +6,7 @@ CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 files = sys.argv[1:] or ["gemm", "attn", "norm", "xformer", "eltwise"]
 tmp = tempfile.mkdtemp()
 for f in files:
-    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + CSRC, "-c", os.path.join(CSRC, f + ".hip"),
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans", "-I" + CSRC, "-c", os.path.join(CSRC, f + ".hip"),
                     "-o", os.path.join(tmp, f + ".o"), "-save-temps"], cwd=tmp, check=True, stderr=subprocess.DEVNULL)
     s = open(os.path.join(tmp, f + "-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
     for m in re.finditer(r"^(_Z\w+):.*?\.amdhsa_kernel \1(.*?)\.end_amdhsa_kernel", s, re.S | re.M):

@@ -16,6 +16,16 @@ if sys.argv[1] == "conv":
     out = torch.empty(B, Ho, Ho, Cout, device="cuda", dtype=bf)
     for _ in range(6):
         ctx.check(ctx.lib.svg_op_conv3x3(ctx.h, x.data_ptr(), w.data_ptr(), None, out.data_ptr(), B, H, H, Cin, Cout, mode, s), "conv")
+elif sys.argv[1] == "attn":
+    B, Sq, Skv, d = map(int, sys.argv[2:6])
+    C = 8 * d
+    Sp = (Skv + 7) // 8 * 8
+    q = torch.randn(B, Sq, C, device="cuda").to(bf)
+    k = torch.randn(B, Skv, C, device="cuda").to(bf)
+    vt = torch.randn(B, C, Sp, device="cuda").to(bf)
+    o = torch.empty_like(q)
+    for _ in range(6):
+        ctx.check(ctx.lib.svg_op_attention(ctx.h, q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr(), B, 8, Sq, Skv, d, C, C, Sp, C, Sq * C, Skv * C, C * Sp, Sq * C, 1 / math.sqrt(d), s), "attn")
 else:
     M, N, K = map(int, sys.argv[2:5])
     A = torch.randn(M, K, device="cuda").to(bf)
