@@ -2,9 +2,10 @@
 //
 //   C[M,N] = epilogue( A[M,K] * Wt[N,K]^T ),  f32 accumulate on v_mfma_f32_16x16x32_bf16.
 //
-// Tile 128 x BN x 64 per 256-thread workgroup (4 waves as 2x2, each 64 x BN/2), two LDS stages.
-// Global -> registers -> LDS staging with the loads of K-step t+1 issued before the MFMAs of
-// K-step t and written to the other LDS stage after them (one barrier per K-step).
+// Tile 128 x BN x 64 per 256-thread workgroup (4 waves as 2x2, each 64 x BN/2), two LDS stages filled by LDS-direct
+// buffer loads (no VGPR round trip): the DMA of K-step t+1 is issued before the MFMAs of K-step t.
+// (A 256 x 320 tile — 4 waves x 512 registers, half the L2 traffic per FLOP — was tried: hipcc cannot allocate its
+//  320 accumulator registers without hundreds of AGPR<->VGPR copies and scratch spills in the loop; it needs hand asm.)
 // LDS rows are 128 B (64 bf16); 16-B chunk c of row r is stored at chunk c ^ ((r>>1)&7) so the
 // ds_read_b128 fragment reads (16 rows x 2 k-chunks per lane group) are bank-conflict free.
 // The MFMA is issued with the WEIGHT fragment as the A operand and the activation fragment as
@@ -12,6 +13,7 @@
 // j = output row m: the epilogue stores 4 contiguous outputs per lane (8 B bf16 / 16 B f32).
 // 3x3 conv = same GEMM with the A tile gathered from NHWC: K index = (tap, cin), cin contiguous.
 #include "kernels.h"
+#include <cstdlib>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -39,8 +41,8 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-// bias / per-sample bias / residual / activation / store for 4 consecutive columns n..n+3 of row m
-__device__ __forceinline__ void epi_store(const GemmArgs& g, int z, int m, int n, f32x4 v) {
+// bias / per-sample bias / residual / activation for 4 consecutive columns n..n+3 of row m
+__device__ __forceinline__ f32x4 epi_value(const GemmArgs& g, int z, int m, int n, f32x4 v) {
   if (g.bias) {
     if (g.bias_row) {
       float b = g.bias[m];
@@ -63,28 +65,33 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, int z, int m, int n
   } else if (g.act == ACT_GELU) {
     for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
   }
-  int64_t o = (int64_t)z * g.sC + (int64_t)m * g.ldc + n;
-  if (g.out_f32) {
-    *(f32x4*)((float*)g.C + o) = v;
-  } else {
-    bf16x4 w;
-    w[0] = (bf16)v[0]; w[1] = (bf16)v[1]; w[2] = (bf16)v[2]; w[3] = (bf16)v[3];
-    *(bf16x4*)((bf16*)g.C + o) = w;
-  }
+  return v;
 }
-
-// GEGLU: h and gate are 4 consecutive packed columns nh.. / nh+16..; output column oc..oc+3
-__device__ __forceinline__ void epi_store_geglu(const GemmArgs& g, int z, int m, int nh, int oc, f32x4 h, f32x4 gt) {
+__device__ __forceinline__ bf16x4 to_bf16x4(f32x4 v) {
+  bf16x4 w;
+  w[0] = (bf16)v[0]; w[1] = (bf16)v[1]; w[2] = (bf16)v[2]; w[3] = (bf16)v[3];
+  return w;
+}
+__device__ __forceinline__ void epi_store(const GemmArgs& g, int z, int m, int n, f32x4 v) {
+  v = epi_value(g, z, m, n, v);
+  int64_t o = (int64_t)z * g.sC + (int64_t)m * g.ldc + n;
+  if (g.out_f32) *(f32x4*)((float*)g.C + o) = v;
+  else *(bf16x4*)((bf16*)g.C + o) = to_bf16x4(v);
+}
+__device__ __forceinline__ f32x4 geglu_value(const GemmArgs& g, int nh, f32x4 h, f32x4 gt) {
   if (g.bias) {
     h += *(const f32x4*)(g.bias + nh);
     gt += *(const f32x4*)(g.bias + nh + 16);
   }
   f32x4 v;
   for (int i = 0; i < 4; ++i) v[i] = h[i] * gelu_erf(gt[i]);
+  return v;
+}
+
+// GEGLU: h and gate are 4 consecutive packed columns nh.. / nh+16..; output column oc..oc+3
+__device__ __forceinline__ void epi_store_geglu(const GemmArgs& g, int z, int m, int nh, int oc, f32x4 h, f32x4 gt) {
   int64_t o = (int64_t)z * g.sC + (int64_t)m * g.ldc + oc;
-  bf16x4 w;
-  w[0] = (bf16)v[0]; w[1] = (bf16)v[1]; w[2] = (bf16)v[2]; w[3] = (bf16)v[3];
-  *(bf16x4*)((bf16*)g.C + o) = w;
+  *(bf16x4*)((bf16*)g.C + o) = to_bf16x4(geglu_value(g, nh, h, gt));
 }
 
 template <int BN, int AMODE>
@@ -211,6 +218,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const GemmArgs g) {
 
   // issue the DMA of K slab `kt` into LDS stage `buf`: 4 + BIT wave instructions of 1 KiB each, no VGPR staging
   auto dma_tiles = [&](int kt, int buf) {
+    if (g.dbg == 3) return;
     char* sa = smem + buf * (A_BYTES + B_BYTES) + wave_u * 1024;
     char* sb = sa + A_BYTES;
     const int ksoff = kt * (BK * 2);                        // bytes, wave-uniform
@@ -253,6 +261,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const GemmArgs g) {
   const int l15 = lane & 15, lq = lane >> 4;
 
   auto compute = [&](int buf) {
+    if (g.dbg == 2) return;
     const char* sa = smem + buf * (A_BYTES + B_BYTES);
     const char* sb = sa + A_BYTES;
 #pragma unroll
@@ -287,11 +296,14 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const GemmArgs g) {
   }
 
   // ---- epilogue --------------------------------------------------------------------------------
+  if (g.dbg == 1 && acc[0][0][0] != 12345.f) return;
+  const bool geglu = g.act == ACT_GEGLU;
+  const int n_out = geglu ? (g.N >> 1) : g.N;          // columns of C
+  if (g.splitk > 1) {
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + l15;
-    if (m >= g.M) continue;
-    if (g.splitk > 1) {
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + l15;
+      if (m >= g.M) continue;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int n = n0 + wn * (BN / 2) + j * 16 + lq * 4;
@@ -299,23 +311,52 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const GemmArgs g) {
         float* sl = g.slabs + ((int64_t)(ks * g.batch + z) * g.M + m) * g.N + n;
         *(f32x4*)sl = acc[i][j];
       }
-    } else if (g.act == ACT_GEGLU) {
+    }
+    return;
+  }
+  // bf16 outputs whose rows are 16-byte granular go through LDS (free after the K loop): every lane computes its
+  // 4-column groups as before but parks them in a [128][tile width] image; the workgroup then writes whole rows
+  // with 16-byte stores (a lane's own 8-byte pieces land 16 rows apart — measured 25-40 % of a short-K GEMM).
+  const bool staged = !g.out_f32 && (n_out & 7) == 0 && (g.ldc & 7) == 0;
+  const int ow = geglu ? (BN / 2) : BN;                 // tile width in output columns
+  const int rowb = ow * 2 + 16;                         // LDS bytes per tile row (pad keeps the 8-byte writes conflict free)
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int rl = wm * 64 + i * 16 + l15;
+    const int m = m0 + rl;
+    if (m >= g.M) continue;
+    if (geglu) {
       if constexpr ((NT & 1) == 0) {
 #pragma unroll
         for (int j = 0; j < NT; j += 2) {
           const int nh = n0 + wn * (BN / 2) + j * 16 + lq * 4;
           if (nh >= g.N) continue;
-          const int oc = (n0 >> 1) + wn * (BN / 4) + (j >> 1) * 16 + lq * 4;
-          epi_store_geglu(g, z, m, nh, oc, acc[i][j] * g.alpha, acc[i][j + 1] * g.alpha);
+          const int cl = wn * (BN / 4) + (j >> 1) * 16 + lq * 4;
+          const f32x4 v = geglu_value(g, nh, acc[i][j] * g.alpha, acc[i][j + 1] * g.alpha);
+          if (staged) *(bf16x4*)(smem + rl * rowb + cl * 2) = to_bf16x4(v);
+          else *(bf16x4*)((bf16*)g.C + (int64_t)z * g.sC + (int64_t)m * g.ldc + (n0 >> 1) + cl) = to_bf16x4(v);
         }
       }
     } else {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 16 + lq * 4;
+        const int cl = wn * (BN / 2) + j * 16 + lq * 4;
+        const int n = n0 + cl;
         if (n >= g.N) continue;
-        epi_store(g, z, m, n, acc[i][j] * g.alpha);
+        if (staged) *(bf16x4*)(smem + rl * rowb + cl * 2) = to_bf16x4(epi_value(g, z, m, n, acc[i][j] * g.alpha));
+        else epi_store(g, z, m, n, acc[i][j] * g.alpha);
       }
+    }
+  }
+  if (staged) {
+    __syncthreads();
+    const int cpr = ow >> 3;                            // 16-byte chunks per tile row
+    const int nc0 = geglu ? (n0 >> 1) : n0;
+    bf16* Cp = (bf16*)g.C + (int64_t)z * g.sC;
+    for (int id = tid; id < BM * cpr; id += 256) {
+      const int row = id / cpr, ch = id - row * cpr;
+      const int m = m0 + row, n = nc0 + ch * 8;
+      if (m < g.M && n < n_out) *(u32x4*)(Cp + (int64_t)m * g.ldc + n) = *(const u32x4*)(smem + row * rowb + ch * 16);
     }
   }
 }
@@ -446,6 +487,8 @@ void launch_gemm(svg_ctx* ctx, const GemmArgs& g, hipStream_t s, int prof_kind) 
   ProfScope ps(ctx, prof_kind, s, 2.0 * g.M * (double)g.N * g.K * g.batch,
                2.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N) * g.batch);
   GemmArgs a = g;
+  static const int dbg_env = getenv("SVG_GEMM_DBG") ? atoi(getenv("SVG_GEMM_DBG")) : 0;
+  a.dbg = dbg_env;
   if (a.splitk < 1) a.splitk = 1;
   if (a.n_valid <= 0) a.n_valid = a.N;
   switch (bn) {
