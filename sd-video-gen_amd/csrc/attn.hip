@@ -27,7 +27,7 @@ namespace {
 constexpr int KVT = 64;     // keys per tile
 constexpr int VROW = 136;   // bytes per V^T LDS row (64 kv * 2 B + 8)
 
-template <int D, int QB>  // head dim (multiple of 8); 32-query blocks per wave
+template <int D, int QB, int NSTW>  // head dim (multiple of 8); 32-query blocks per wave; LDS stages wanted
 __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
   constexpr int KS = (D + 15) / 16;           // k-steps of the QK^T contraction
   constexpr int DK = KS * 16;
@@ -41,9 +41,11 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
   constexpr int K_BYTES = KVT * KROW;
   constexpr int V_BYTES = DVT * 32 * VROW;
   constexpr int NLD = (KVT * CPR + 255) / 256;   // 16-B chunks per thread per tile, for K and for V^T
-  __shared__ __attribute__((aligned(16))) char smem[K_BYTES + V_BYTES];
-  char* const sK = smem;
-  char* const sV = smem + K_BYTES;
+  // two LDS stages (a K + V^T tile is ~10-40 KB): tile t+1 is written into the other stage right after the MFMAs of
+  // tile t, so the loop needs ONE barrier per tile
+  constexpr int STAGE = K_BYTES + V_BYTES;
+  constexpr int NST = (NSTW == 2 && 2 * STAGE <= 65536) ? 2 : 1;   // static LDS limit: d = 160 keeps one stage and two barriers
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -79,8 +81,13 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
     if (v_row[i] >= D) v_row[i] = -1;
   }
   // once: zero the K pad columns (D .. DK-1); fill V^T row D with ones (bf16 1.0 = 0x3F80)
-  if (CPR * 8 < DK && tid < KVT) *(uint4*)(sK + tid * KROW + CPR * 16) = make_uint4(0, 0, 0, 0);
-  if (ONES && tid < 16) *(uint2*)(sV + D * VROW + tid * 8) = make_uint2(0x3F803F80u, 0x3F803F80u);
+#pragma unroll
+  for (int st = 0; st < NST; ++st) {
+    char* const sK = smem + st * STAGE;
+    char* const sV = sK + K_BYTES;
+    if (CPR * 8 < DK && tid < KVT) *(uint4*)(sK + tid * KROW + CPR * 16) = make_uint4(0, 0, 0, 0);
+    if (ONES && tid < 16) *(uint2*)(sV + D * VROW + tid * 8) = make_uint2(0x3F803F80u, 0x3F803F80u);
+  }
 
   uint4 rk[NLD], rv[NLD];
   auto load_regs = [&](int t) {
@@ -95,7 +102,9 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
         rv[i] = *(const uint4*)(Vt + (int64_t)v_row[i] * a.ldvt + kv0 + v_ch[i] * 8);
     }
   };
-  auto write_lds = [&]() {
+  auto write_lds = [&](int stage) {
+    char* const sK = smem + stage * STAGE;
+    char* const sV = sK + K_BYTES;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       if (k_row[i] >= 0) *(uint4*)(sK + k_row[i] * KROW + k_ch[i] * 16) = rk[i];
@@ -121,12 +130,14 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
 
   const int ntiles = (a.Skv + KVT - 1) / KVT;
   load_regs(0);
-  write_lds();
+  write_lds(0);
   __syncthreads();
 
   for (int t = 0; t < ntiles; ++t) {
     const bool more = (t + 1 < ntiles);
     if (more) load_regs(t + 1);
+    const char* const sK = smem + (t & (NST - 1)) * STAGE;
+    const char* const sV = sK + K_BYTES;
 
     // ---- S^T = K_tile * Q^T for the two 32-key sub-tiles (K fragments shared by the QB query blocks) ------
     f32x16 S0[QB], S1[QB];
@@ -219,8 +230,8 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
         }
       }
     }
-    __syncthreads();
-    if (more) write_lds();
+    if (NST == 1) __syncthreads();
+    if (more) write_lds((t + 1) & (NST - 1));
     __syncthreads();
   }
 
@@ -260,14 +271,17 @@ template <int D>
 void launch(const AttnArgs& a, hipStream_t s) {
   // Two query blocks per wave (QB = 2) when the registers allow two waves per SIMD (d <= 64: 222 VGPRs):
   // 0.67 vs 0.73 ms at 16 x 8 x 4096^2 x 40.  SVG_ATTN_QB=1 forces the single-block form.
+  static const int nst_env = getenv("SVG_ATTN_NST") ? atoi(getenv("SVG_ATTN_NST")) : 1;   // same-box A/B: one stage + two barriers is 1-2 % faster than two stages + one barrier
   static const int qb_env = getenv("SVG_ATTN_QB") ? atoi(getenv("SVG_ATTN_QB")) : 2;
   constexpr int QB = (D <= 64) ? 2 : 1;
   if (QB == 2 && qb_env == 2 && a.Sq >= 512) {
     dim3 grid(cdiv(a.Sq, 256), a.heads, a.B);
-    hipLaunchKernelGGL((attn_kernel<D, QB>), grid, dim3(256), 0, s, a);
+    if (nst_env == 2) hipLaunchKernelGGL((attn_kernel<D, QB, 2>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_kernel<D, QB, 1>), grid, dim3(256), 0, s, a);
   } else {
     dim3 grid(cdiv(a.Sq, 128), a.heads, a.B);
-    hipLaunchKernelGGL((attn_kernel<D, 1>), grid, dim3(256), 0, s, a);
+    if (nst_env == 2) hipLaunchKernelGGL((attn_kernel<D, 1, 2>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_kernel<D, 1, 1>), grid, dim3(256), 0, s, a);
   }
 }
 

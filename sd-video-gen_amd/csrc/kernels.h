@@ -41,7 +41,7 @@ struct GemmArgs {
   // split-K (0/1 = off). slabs: f32 [splitk][M][N] workspace
   int splitk = 1;
   float* slabs = nullptr;
-  int dbg = 0;                       // ablation switch (SVG_GEMM_DBG): 1 no stores, 2 no MFMA, 3 no DMA
+  int dbg = 0;                       // ablation switch (SVG_GEMM_DBG): 1 no stores, 2 no MFMA, 3 no DMA, 5 LDS-staged epilogue
 };
 
 void launch_gemm(svg_ctx* ctx, const GemmArgs& g, hipStream_t s, int prof_kind);
