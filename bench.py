@@ -115,10 +115,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus or world == 1 and args.gpus == 1, "launch N>1 with torch.distributed.run --nproc-per-node N"
     assert torch.cuda.is_available(), "bench.py needs the GPU: the product path has no CPU fallback"
+    # rehearsal knobs (single-GPU box): SVG_DEVICE_OVERRIDE pins every rank to one device, SVG_DIST_BACKEND=gloo
+    # replaces RCCL (two ranks cannot share a GPU under RCCL); the driver's multi-GPU runs use neither.
+    if os.environ.get("SVG_DEVICE_OVERRIDE") is not None:
+        local_rank = int(os.environ["SVG_DEVICE_OVERRIDE"])
+    backend = os.environ.get("SVG_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from sd_video_gen_amd import config as svg_config, sharding
     from sd_video_gen_amd.predict import sample_clips, bouncing_ball_clips
@@ -145,10 +153,10 @@ def main():
     seeds = sharding.clip_seeds(1234, a, b)
     emb = sd_utils.encode_text([""]) if denoise else None
 
-    def step():
+    def step(gather=True):
         lat = sample_clips(model, sd_utils, clips, args.pred_frames, denoise=denoise, start_step=args.start_step,
                            seeds=seeds, text_embeddings=emb)
-        return sharding.gather_clips(lat, n_global)
+        return sharding.gather_clips(lat, n_global) if gather else lat
 
     def sync():
         if world > 1:
@@ -185,7 +193,7 @@ def main():
         ctx = sd_utils.ctx
         ctx.prof_reset()
         ctx.prof_enable(True)
-        step()
+        step(gather=False)          # rank-0-only pass: no collective
         torch.cuda.synchronize()
         rep = ctx.prof_report()
         ctx.prof_enable(False)

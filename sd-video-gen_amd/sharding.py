@@ -37,6 +37,10 @@ def gather_clips(local, n_clips):
     pad = local
     if local.shape[0] < cmax:
         pad = torch.cat([local, local.new_zeros((cmax - local.shape[0],) + tuple(local.shape[1:]))])
+    pad = pad.contiguous()
+    dev = pad.device
+    if dist.get_backend() == "gloo" and pad.is_cuda:
+        pad = pad.cpu()          # rehearsal backend: gloo moves host memory; RCCL ("nccl") takes the device tensor as is
     out = [torch.empty_like(pad) for _ in range(ws)]
-    dist.all_gather(out, pad.contiguous())
-    return torch.cat([o[: b - a] for o, (a, b) in zip(out, sizes)])
+    dist.all_gather(out, pad)
+    return torch.cat([o[: b - a] for o, (a, b) in zip(out, sizes)]).to(dev)
