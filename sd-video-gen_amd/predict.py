@@ -83,6 +83,43 @@ def sample_clips(model, sd_utils, clips_u8, pred_frames, denoise=False, start_st
         return all_latents, frames
 
 
+def sample_clips_streams(workers, clips_u8, pred_frames, seeds, **kw):
+    """Run `sample_clips` on several (model, sd_utils, stream) workers at once: the clips are split into contiguous
+    groups, each group is driven by its own host thread on its own HIP stream and library context (full weight
+    replica each), so kernels of different groups can share the GPU (ALU/HBM-bound normalisation and softmax work of
+    one group under the MFMA-bound convs of another).  Results are identical to one call on all clips."""
+    import threading
+    n = clips_u8.shape[0]
+    G = len(workers)
+    bounds = [(n * g) // G for g in range(G + 1)]
+    out = [None] * G
+    errs = []
+    cur = torch.cuda.current_stream()
+
+    def run(g):
+        try:
+            model, sdu, stream = workers[g]
+            a, b = bounds[g], bounds[g + 1]
+            stream.wait_stream(cur)
+            with torch.cuda.stream(stream):
+                out[g] = sample_clips(model, sdu, clips_u8[a:b], pred_frames, seeds=seeds[a:b], **kw)
+        except Exception as e:      # surfaced on the caller's thread
+            errs.append(e)
+    threads = [threading.Thread(target=run, args=(g,)) for g in range(G) if bounds[g + 1] > bounds[g]]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errs:
+        raise errs[0]
+    for _, _, stream in workers:
+        cur.wait_stream(stream)
+    parts = [o for o in out if o is not None]
+    if isinstance(parts[0], tuple):
+        return tuple(torch.cat([p[i] for p in parts]) for i in range(len(parts[0])))
+    return torch.cat(parts)
+
+
 def bouncing_ball_clips(n_clips, frame_size, n_frames=5, seed=0, device="cpu"):
     """Synthetic stand-in for the bouncing-ball dataset (datasets are absent offline): black F x F x 3 uint8
     background, one white disc of radius F/8 moving at constant velocity with elastic wall bounces.

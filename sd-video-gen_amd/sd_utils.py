@@ -71,12 +71,12 @@ class _UNet:
 
 
 class SDUtils():
-    def __init__(self, weights=None, text_embeddings=None, seed=0, verbose=True, arch=None):
+    def __init__(self, weights=None, text_embeddings=None, seed=0, verbose=True, arch=None, ctx=None):
         self.config, self.args = parse_config_args()             # sd_utils.py:22
         self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
         if self.device.type != "cuda":
             raise RuntimeError("SDUtils runs on the HIP library and needs a GPU (gfx950); there is no CPU fallback")
-        self.ctx = _lib.default_context()
+        self.ctx = ctx if ctx is not None else _lib.default_context()
         self._seed = seed
         self._verbose = verbose
         self._text_embeddings = text_embeddings

@@ -57,8 +57,14 @@ class Transformer(nn.Module):
     def _version(self):
         return tuple(int(p._version) for p in self.parameters()) + (id(self._ctx),)
 
+    def use_context(self, ctx):
+        """bind this module to a specific library context (default: the process-wide one of the current GPU)"""
+        self._bound_ctx = ctx
+        self._uploaded_version = None
+        return self
+
     def _sync_weights(self):
-        ctx = _lib.default_context()
+        ctx = getattr(self, "_bound_ctx", None) or _lib.default_context()
         if self._ctx is ctx and self._uploaded_version == self._version():
             return ctx
         self._ctx = ctx
