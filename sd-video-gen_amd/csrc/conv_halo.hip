@@ -1,0 +1,271 @@
+// Halo 3x3 convolution (stride 1, pad 1) for gfx950: the L2-traffic-lean form of the implicit GEMM.
+//
+// The plain implicit GEMM (gemm.hip) re-loads its 128-pixel A tile once per tap: 9x the input through L2 -> LDS.
+// Measured on MI355X that traffic runs at ~39 % of the L2 rate while the matrix pipe is ~38 % busy — at a 128 x 160
+// tile the two limits coincide.  Here a workgroup owns a 16 x 16 PIXEL BLOCK (256 output pixels) x BN channels:
+//   * per 64-channel chunk it DMAs the block's 18 x 18 halo patch ONCE (41 KB) and reads all nine taps out of LDS at
+//     shifted pixel addresses (the activation fragment of tap (ky,kx), pixel (y,x) is patch pixel (y+ky, x+kx));
+//   * only the weights stream per tap (BN x 64, THREE LDS stages, LDS-direct buffer loads, counted vmcnt: the slab of
+//     step s+2 is issued while step s is multiplied — one workgroup per CU has no neighbour to hide DMA latency);
+//   => (41.5 + 9*20) KB per 47 MFLOP instead of 9*(16+20) KB per 23.6 MFLOP: 2.8x fewer L2 bytes per FLOP.
+// 8 waves as 4 (pixel rows) x 2 (channels); wave tile = 4 image rows x 16 px x BN/2 channels; v_mfma_f32_16x16x32_bf16
+// with the weight fragment as the A operand (4 consecutive output channels per lane, like gemm.hip).
+// Image borders and ragged channel tiles are zero-filled by the buffer range check (voffset 0x80000000).
+#include "igemm_epi.h"
+#include <cstdlib>
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// LDS-direct 16-byte buffer load issued from inline asm: hipcc's waitcnt pass does not see it, so it cannot add its own
+// conservative vmcnt(0) in front of the fragment reads (it does for the builtin form here: the stage index is dynamic) —
+// every wait for these DMAs is one of the explicit counted s_waitcnt below.  M0 (LDS base of the wave's 1-KiB piece) is
+// written in the same statement that uses it and restored afterwards.
+__device__ __forceinline__ void dma16(v4i srd, unsigned voff, int soff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(srd), "s"(soff), "s"(lds_addr)
+               : "memory");
+}
+
+// LDS rows are 128 B; 16-byte chunk c of row r sits at chunk c ^ (r & 7).  For a ds_read_b128 lane group (rows l = 0-3
+// and 12-15 at chunk c0, rows 4-11 at chunk c0+1) over ANY 16 consecutive rows this is conflict free: rows r and r+8 share
+// a key but sit in different chunk classes, and keys of equal parity never differ by exactly 1.  (gemm.hip's (r>>1)&7 key
+// needs 16-aligned windows; the tap-shifted patch reads here start anywhere: it measured 25 % conflict cycles.)
+__device__ __forceinline__ int lds_off7(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+constexpr int PW = 18;                 // patch width / height in pixels
+constexpr int PPIX = PW * PW;          // 324
+constexpr int NPD = 6;                 // patch DMA instructions per wave: 8 waves * 64 lanes * 6 = 3072 >= 324 * 8 chunks
+
+template <int BN>
+__global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
+  constexpr int NT = BN / 32;            // 16-wide channel tiles per wave
+  constexpr int MT = 4;                  // image rows per wave
+  constexpr int BIT = BN / 64;           // weight row groups per thread (64 rows per DMA instruction of all 8 waves)
+  constexpr int B_BYTES = BN * 128;
+  constexpr int PBUF = PPIX * 128;       // one patch buffer: 324 px * 128 B = 41472 B (lanes past it are EXEC-masked)
+  constexpr int NWS = 3;                 // weight stages
+  constexpr int NW = (BN + 63) / 64;     // weight DMA instructions per wave and slab (BN = 160: waves 4-7 pad with a dummy)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sP = smem;                 // 2 patch buffers
+  char* const sB = smem + 2 * PBUF;      // NWS weight stages
+  char* const sDummy = sB + NWS * B_BYTES;   // 8 KiB sink for the padding DMAs (1 KiB per wave)
+  constexpr unsigned INVALID = 0x80000000u;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wid);
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int ks = blockIdx.z;
+
+  // tile order: the channel tiles of one pixel block are adjacent (they share the patch through L2)
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int bx_n = g.W >> 4, by_n = g.H >> 4;
+  int tile;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tn = tile % tiles_n;
+  int pb = tile / tiles_n;
+  const int bx = pb % bx_n; pb /= bx_n;
+  const int by = pb % by_n;
+  const int b = pb / by_n;
+  const int y0 = by << 4, x0 = bx << 4, n0 = tn * BN;
+
+  // channel chunks of this K split
+  const int CC = g.Cin >> 6;
+  const int cc_per = (CC + g.splitk - 1) / g.splitk;
+  const int cc_begin = ks * cc_per;
+  const int cc_end = min(CC, cc_begin + cc_per);
+
+  const unsigned a_bytes = (unsigned)((int64_t)(g.M / (g.H * g.W)) * g.H * g.W * g.Cin * 2);
+  const unsigned b_bytes = (unsigned)(((int64_t)(g.n_valid - 1) * g.ldb + g.K) * 2);
+  // buffer descriptors: {base[31:0], base[47:32] (stride 0), num_records, flags}
+  const uint64_t pa = (uint64_t)g.A, pw = (uint64_t)g.Wt;
+  const v4i srdA = {(int)(unsigned)pa, (int)((pa >> 32) & 0xffff), (int)a_bytes, 0x00020000};
+  const v4i srdB = {(int)(unsigned)pw, (int)((pw >> 32) & 0xffff), (int)b_bytes, 0x00020000};
+  const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);   // LDS address of smem[0]
+
+  // ---- patch DMA map: linear LDS image [pixel][8 chunks]; lane id -> (pp, position); the swizzle rides on the source chunk
+  unsigned p_voff[NPD];
+#pragma unroll
+  for (int i = 0; i < NPD; ++i) {
+    const int id = (i * 8 + wid) * 64 + lane;          // 16-byte slot in the patch buffer
+    const int pp = id >> 3, pos = id & 7;
+    const int c = pos ^ (pp & 7);
+    const int py = pp / PW, px = pp - py * PW;
+    const int yy = y0 - 1 + py, xx = x0 - 1 + px;
+    const bool ok = pp < PPIX && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W;
+    p_voff[i] = ok ? (unsigned)(((b * g.H + yy) * g.W + xx) * g.Cin + c * 8) * 2u : INVALID;
+  }
+  // ---- weight DMA map (as gemm.hip): rows r0 + 64 i, chunk swizzled on the source
+  const int r0 = tid >> 3;                                // 0..63
+  const int cB = (tid & 7) ^ (r0 & 7);
+  unsigned b_voff[5];
+#pragma unroll
+  for (int i = 0; i < BIT; ++i) {
+    const int n = n0 + r0 + 64 * i;
+    b_voff[i] = (n < g.n_valid) ? (unsigned)(n * g.ldb + cB * 8) * 2u : INVALID;
+  }
+  constexpr bool B_TAIL = (BN % 64) != 0;                 // BN = 160: a last half group of 32 rows
+  unsigned b_voff_tail = INVALID;
+  if (B_TAIL) {
+    const int n = n0 + BIT * 64 + r0;
+    if (r0 < 32 && n < g.n_valid) b_voff_tail = (unsigned)(n * g.ldb + cB * 8) * 2u;
+  }
+
+  constexpr int OFF_B = 2 * PBUF, OFF_DUMMY = OFF_B + NWS * B_BYTES;
+  auto dma_patch = [&](int cc, int buf) {
+    const unsigned dst = lds0 + buf * PBUF + wave_u * 1024;
+    const int soff = cc * 128;
+#pragma unroll
+    for (int i = 0; i < NPD - 1; ++i) dma16(srdA, p_voff[i], soff, dst + i * 8192);
+    // last piece: only slots < 324*8 exist (32 of them, on wave 0).  Every wave still issues the instruction so that all
+    // waves count the same number of DMAs: wave 0 with lanes 32-63 switched off (a DMA writes active lanes only), the
+    // other waves into the sink with an out-of-range source.
+    const unsigned d5 = (wave_u == 0) ? (dst + (NPD - 1) * 8192) : (lds0 + OFF_DUMMY + wave_u * 1024);
+    if (wid != 0 || lane < 32) dma16(srdA, wid == 0 ? p_voff[NPD - 1] : INVALID, soff, d5);
+  };
+  auto dma_weights = [&](int cc, int tap, int stage) {
+    const unsigned dst = lds0 + OFF_B + stage * B_BYTES + wave_u * 1024;
+    const int soff = (tap * g.Cin + cc * 64) * 2;
+#pragma unroll
+    for (int i = 0; i < BIT; ++i) dma16(srdB, b_voff[i], soff, dst + i * 8192);
+    if (B_TAIL) {
+      // rows BIT*64 .. BIT*64+31 ride on waves 0-3 (r0 < 32); waves 4-7 issue a padding DMA into the sink so that
+      // every wave has the same number of DMAs per slab (the counted vmcnt below relies on it)
+      const unsigned tdst = (wave_u < 4) ? (dst + BIT * 8192) : (lds0 + OFF_DUMMY + wave_u * 1024);
+      dma16(srdB, b_voff_tail, soff, tdst);
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // patch pixel of (image row wm*4 + i, column l15) for tap (0,0); tap (ky,kx) adds ky*18 + kx
+  int pp0[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) pp0[i] = (wm * 4 + i) * PW + l15;
+
+  auto compute = [&](int pbuf, int stage, int toff) {
+    const char* sp = sP + pbuf * PBUF;
+    const char* sb = sB + stage * B_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 xf[MT], wf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) xf[i] = *(const bf16x8*)(sp + lds_off7(pp0[i] + toff, kk * 4 + lq));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wf[j] = *(const bf16x8*)(sb + lds_off7(wn * (BN / 2) + j * 16 + l15, kk * 4 + lq));
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---- main loop over steps s = (cc, tap): weight slab s lives in stage s % 3; the patch alternates per chunk -------
+  // iteration s:  wait until slab s (and anything older) has landed, leaving only slab s+1 (and a just-issued patch)
+  //               in flight -> barrier (everyone's pieces landed; stage (s+2)%3 and, at tap 0, the other patch buffer
+  //               were last read in iteration s-1) -> issue patch(cc+1) [tap 0] and slab s+2 -> multiply slab s.
+  if (cc_begin < cc_end) {
+    const int nsteps = (cc_end - cc_begin) * 9;
+    auto issue_w = [&](int sidx) {
+      if (sidx < nsteps) dma_weights(cc_begin + sidx / 9, sidx % 9, sidx % NWS);
+    };
+    dma_patch(cc_begin, 0);
+    issue_w(0);
+    issue_w(1);
+    bool patch_just_issued = false;
+    int s = 0;
+    for (int cc = cc_begin; cc < cc_end; ++cc) {
+      const int pbuf = (cc - cc_begin) & 1;
+      for (int tap = 0; tap < 9; ++tap, ++s) {
+        // outstanding, oldest first: [slab s] [patch (if issued last iteration)] [slab s+1]
+        if (s + 1 >= nsteps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (patch_just_issued) {
+          if (NW == 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+          if (NW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        patch_just_issued = false;
+        if (tap == 0 && cc + 1 < cc_end) { dma_patch(cc + 1, pbuf ^ 1); patch_just_issued = true; }
+        issue_w(s + 2);
+        const int ky = tap / 3, kx = tap - ky * 3;
+        compute(pbuf, s % NWS, ky * PW + kx);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue -----------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = (b * g.H + y0 + wm * 4 + i) * g.W + x0 + l15;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + wn * (BN / 2) + j * 16 + lq * 4;
+      if (n >= g.N) continue;
+      if (g.splitk > 1) {
+        float* sl = g.slabs + ((int64_t)ks * g.M + m) * g.N + n;
+        *(f32x4*)sl = acc[i][j];
+      } else {
+        epi_store(g, 0, m, n, acc[i][j] * g.alpha);
+      }
+    }
+  }
+}
+
+template <int BN>
+void launch_halo(const GemmArgs& g, dim3 grid, hipStream_t s) {
+  constexpr int smem = 2 * PPIX * 128 + 3 * BN * 128 + 8192;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_OK(hipFuncSetAttribute((const void*)conv_halo_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_halo_kernel<BN>), grid, dim3(512), smem, s, g);
+}
+
+}  // namespace
+
+int conv_halo_bn(const GemmArgs& g);
+
+// stride-1 3x3 convs on images whose sides are multiples of 16, with enough 16x16-pixel blocks x channel tiles to give
+// every CU a workgroup (below that the 128-row implicit GEMM with its split-K is faster: same-box A/B at 16x16 images)
+bool conv_halo_supported(const GemmArgs& g) {
+  static const int off = getenv("SVG_NO_HALO") ? atoi(getenv("SVG_NO_HALO")) : 0;
+  if (off || g.amode != A_CONV_S1 || g.Cin % 64 != 0 || g.H % 16 != 0 || g.W % 16 != 0 || g.batch != 1 || g.out_f32 ||
+      g.act == ACT_GEGLU || g.N < 128 || g.Ho != g.H || g.Wo != g.W)
+    return false;
+  return (int64_t)(g.M / 256) * cdiv(g.N, conv_halo_bn(g)) >= 192;
+}
+
+// channel-tile width: fewest serial rounds of workgroups (one per CU) times tile width; ties -> fewer padded columns
+int conv_halo_bn(const GemmArgs& g) {
+  const int64_t pb = g.M / 256;
+  int best = 128;
+  int64_t best_cost = -1, best_pad = 0;
+  for (int bn : {128, 160}) {
+    const int64_t tn = cdiv(g.N, bn);
+    const int64_t cost = ((pb * tn + 255) / 256) * bn, pad = tn * bn - g.N;
+    if (best_cost < 0 || cost < best_cost || (cost == best_cost && pad < best_pad)) { best = bn; best_cost = cost; best_pad = pad; }
+  }
+  return best;
+}
+
+void launch_conv_halo(const GemmArgs& g, dim3 grid, hipStream_t s) {
+  if (conv_halo_bn(g) == 160) launch_halo<160>(g, grid, s);
+  else launch_halo<128>(g, grid, s);
+}

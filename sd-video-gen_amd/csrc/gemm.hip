@@ -12,81 +12,16 @@
 // the B operand, so D[i][j] has i = output column n (4 consecutive n per lane in registers) and
 // j = output row m: the epilogue stores 4 contiguous outputs per lane (8 B bf16 / 16 B f32).
 // 3x3 conv = same GEMM with the A tile gathered from NHWC: K index = (tap, cin), cin contiguous.
-#include "kernels.h"
 #include <cstdlib>
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#include "igemm_epi.h"
+
+// conv_halo.hip
+bool conv_halo_supported(const GemmArgs& g);
+int conv_halo_bn(const GemmArgs& g);
+void launch_conv_halo(const GemmArgs& g, dim3 grid, hipStream_t s);
 
 namespace {
-
-constexpr int BM = 128;
-constexpr int BK = 64;
-
-// exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 output rounding):
-// ~12 VALU + exp + rcp per element instead of the ~40-instruction libm erff — the GEGLU epilogue applies it to
-// 64 values per thread.
-__device__ __forceinline__ float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float e = 1.f - poly * __expf(-z * z);
-  return 0.5f * x * (1.f + copysignf(e, x));
-}
-__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
-
-__device__ __forceinline__ int lds_off(int row, int chunk) {
-  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-}
-
-// bias / per-sample bias / residual / activation for 4 consecutive columns n..n+3 of row m
-__device__ __forceinline__ f32x4 epi_value(const GemmArgs& g, int z, int m, int n, f32x4 v) {
-  if (g.bias) {
-    if (g.bias_row) {
-      float b = g.bias[m];
-      v += b;
-    } else {
-      f32x4 b = *(const f32x4*)(g.bias + n);
-      v += b;
-    }
-  }
-  if (g.bias_bn) {
-    f32x4 b = *(const f32x4*)(g.bias_bn + (int64_t)(m / g.rows_per_batch) * (g.bias_bn_ld ? g.bias_bn_ld : g.N) + n);
-    v += b;
-  }
-  if (g.residual) {
-    bf16x4 r = *(const bf16x4*)(g.residual + (int64_t)z * g.sC + (int64_t)m * g.ldr + n);
-    v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
-  }
-  if (g.act == ACT_SILU) {
-    for (int i = 0; i < 4; ++i) v[i] = silu_f(v[i]);
-  } else if (g.act == ACT_GELU) {
-    for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
-  }
-  return v;
-}
-__device__ __forceinline__ bf16x4 to_bf16x4(f32x4 v) {
-  bf16x4 w;
-  w[0] = (bf16)v[0]; w[1] = (bf16)v[1]; w[2] = (bf16)v[2]; w[3] = (bf16)v[3];
-  return w;
-}
-__device__ __forceinline__ void epi_store(const GemmArgs& g, int z, int m, int n, f32x4 v) {
-  v = epi_value(g, z, m, n, v);
-  int64_t o = (int64_t)z * g.sC + (int64_t)m * g.ldc + n;
-  if (g.out_f32) *(f32x4*)((float*)g.C + o) = v;
-  else *(bf16x4*)((bf16*)g.C + o) = to_bf16x4(v);
-}
-__device__ __forceinline__ f32x4 geglu_value(const GemmArgs& g, int nh, f32x4 h, f32x4 gt) {
-  if (g.bias) {
-    h += *(const f32x4*)(g.bias + nh);
-    gt += *(const f32x4*)(g.bias + nh + 16);
-  }
-  f32x4 v;
-  for (int i = 0; i < 4; ++i) v[i] = h[i] * gelu_erf(gt[i]);
-  return v;
-}
 
 // GEGLU: h and gate are 4 consecutive packed columns nh.. / nh+16..; output column oc..oc+3
 __device__ __forceinline__ void epi_store_geglu(const GemmArgs& g, int z, int m, int nh, int oc, f32x4 h, f32x4 gt) {
@@ -481,21 +416,27 @@ void launch_gemm(svg_ctx* ctx, const GemmArgs& g, hipStream_t s, int prof_kind) 
   SVG_CHECK((int64_t)g.N * g.ldb < (1LL << 31) && g.ldb % 8 == 0, "gemm: ldb %d unsupported", g.ldb);
   if (g.act == ACT_GEGLU) SVG_CHECK(g.N % 128 == 0, "geglu: packed N must be a multiple of 128");
   if (!SVG_LAUNCHING(ctx)) return;
-  const int bn = pick_bn(g);
-  const int tiles = cdiv(g.M, BM) * cdiv(g.N, bn);
-  dim3 grid(tiles, g.batch, g.splitk > 1 ? g.splitk : 1);
-  ProfScope ps(ctx, prof_kind, s, 2.0 * g.M * (double)g.N * g.K * g.batch,
-               2.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N) * g.batch);
   GemmArgs a = g;
   static const int dbg_env = getenv("SVG_GEMM_DBG") ? atoi(getenv("SVG_GEMM_DBG")) : 0;
   a.dbg = dbg_env;
   if (a.splitk < 1) a.splitk = 1;
   if (a.n_valid <= 0) a.n_valid = a.N;
-  switch (bn) {
-    case 32: launch_bn<32>(a, grid, s); break;
-    case 64: launch_bn<64>(a, grid, s); break;
-    case 128: launch_bn<128>(a, grid, s); break;
-    default: launch_bn<160>(a, grid, s); break;
+  ProfScope ps(ctx, prof_kind, s, 2.0 * g.M * (double)g.N * g.K * g.batch,
+               2.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N) * g.batch);
+  if (conv_halo_supported(a)) {
+    // 16 x 16 pixel blocks x channel tiles; splitk partitions the 64-channel chunks
+    const int blocks = (a.M / 256) * cdiv(a.N, conv_halo_bn(a));
+    launch_conv_halo(a, dim3(blocks, 1, a.splitk), s);
+  } else {
+    const int bn = pick_bn(a);
+    const int tiles = cdiv(a.M, BM) * cdiv(a.N, bn);
+    dim3 grid(tiles, a.batch, a.splitk);
+    switch (bn) {
+      case 32: launch_bn<32>(a, grid, s); break;
+      case 64: launch_bn<64>(a, grid, s); break;
+      case 128: launch_bn<128>(a, grid, s); break;
+      default: launch_bn<160>(a, grid, s); break;
+    }
   }
   check_launch("igemm");
   if (a.splitk > 1) {
@@ -507,6 +448,24 @@ void launch_gemm(svg_ctx* ctx, const GemmArgs& g, hipStream_t s, int prof_kind) 
 }
 
 void gemm_auto(svg_ctx* ctx, GemmArgs g, hipStream_t s, int prof_kind) {
+  if (g.n_valid <= 0) g.n_valid = g.N;
+  g.splitk = 1;
+  if (conv_halo_supported(g)) {
+    const int64_t blocks = (int64_t)(g.M / 256) * cdiv(g.N, conv_halo_bn(g));
+    const int CC = g.Cin / 64;
+    int sk = 1;
+    if (blocks < 192 && CC >= 4) sk = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((320 + blocks - 1) / blocks, CC / 2), 8));
+    g.splitk = sk;
+    if (sk > 1) {
+      ctx->arena.push();
+      g.slabs = ctx->arena.get<float>((int64_t)sk * g.M * g.N);
+      launch_gemm(ctx, g, s, prof_kind);
+      ctx->arena.pop();
+    } else {
+      launch_gemm(ctx, g, s, prof_kind);
+    }
+    return;
+  }
   const int bn = pick_bn(g);
   const int64_t blocks = (int64_t)cdiv(g.M, BM) * cdiv(g.N, bn) * g.batch;
   const int KT = cdiv(g.K, BK);

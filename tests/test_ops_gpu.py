@@ -109,7 +109,11 @@ def conv_ref(x_nhwc, w, b, mode):
     (1, 16, 16, 64, 64, 0), (2, 8, 8, 128, 320, 0), (1, 32, 32, 320, 320, 0), (3, 5, 7, 64, 128, 0),
     (2, 16, 16, 64, 64, 1), (1, 8, 8, 128, 128, 1), (2, 16, 16, 64, 64, 2), (1, 12, 12, 128, 64, 2),
     (2, 8, 8, 64, 64, 3), (1, 6, 10, 128, 128, 3), (2, 16, 16, 8, 128, 0), (1, 64, 64, 8, 320, 0),
-    (1, 8, 8, 1280, 1280, 0), (1, 16, 16, 64, 4, 0), (2, 16, 16, 128, 8, 0)])
+    (1, 8, 8, 1280, 1280, 0), (1, 16, 16, 64, 4, 0), (2, 16, 16, 128, 8, 0),
+    # halo kernel (stride 1, H and W multiples of 16, Cout >= 128): one block, several blocks, ragged channel tile, split over chunks
+    (1, 16, 16, 64, 128, 0), (2, 32, 32, 128, 160, 0), (1, 16, 48, 64, 320, 0), (1, 64, 64, 320, 320, 0), (2, 16, 16, 1280, 1280, 0),
+    (3, 32, 16, 192, 192, 0), (1, 48, 32, 64, 256, 0), (8, 64, 64, 320, 320, 0), (16, 32, 32, 128, 640, 0), (4, 128, 128, 64, 128, 0),
+    (25, 16, 16, 64, 1280, 0)])
 def test_conv3x3(ctx, B, H, W, Cin, Cout, mode):
     g = torch.Generator(device="cuda").manual_seed(B + H * 3 + Cin + Cout + mode)
     x = bf(torch.randn(B, H, W, Cin, device="cuda", generator=g))
@@ -234,6 +238,20 @@ def test_xf_gemm_integer_exact(ctx):
     Y = torch.empty(M, N, device="cuda")
     ctx.check(ctx.lib.svg_op_xf_gemm(ctx.h, X.data_ptr(), W.data_ptr(), None, Y.data_ptr(), M, N, K, 0, stream()), "xf_gemm")
     assert torch.equal(Y, X @ W.t())
+
+
+def test_conv3x3_halo_integer_exact(ctx):
+    """halo kernel on integer data: patch gather, image borders, block seams and the tap shifts checked bit for bit."""
+    g = torch.Generator(device="cuda").manual_seed(6)
+    # >= 192 workgroups (16x16-pixel blocks x channel tiles) so that the halo kernel is the one dispatched
+    for (B, H, W, Cin, Cout) in [(12, 16, 32, 64, 1024), (6, 32, 32, 128, 1280), (16, 16, 16, 192, 1600)]:
+        x = bf(torch.randint(-2, 3, (B, H, W, Cin), device="cuda", generator=g).float())
+        w = torch.randint(-2, 3, (Cout, Cin, 3, 3), device="cuda", generator=g).float()
+        b = torch.randint(-3, 4, (Cout,), device="cuda", generator=g).float()
+        ref = conv_ref(x, w, b, 0)
+        out = torch.empty(ref.shape, device="cuda", dtype=torch.bfloat16)
+        ctx.check(ctx.lib.svg_op_conv3x3(ctx.h, u16(x), w.data_ptr(), b.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout, 0, stream()), "conv")
+        assert torch.equal(out.float(), ref.to(torch.bfloat16).float()), (B, H, W, Cin, Cout)   # sums are exact; only the bf16 store rounds
 
 
 def test_resize_nearest_u8(ctx):
