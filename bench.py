@@ -220,7 +220,7 @@ def main():
         if denoise:
             dom = rep["conv3x3"]
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            line["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel<*, conv3x3> (implicit-GEMM 3x3 conv, all UNet/VAE shapes of one step)",
+            line["roofline"] = {"bound": "mfma", "kernel": "conv3x3 family: conv_halo_kernel<BN> + igemm_kernel<BN, conv modes> (every 3x3 conv of the UNet / VAE in one step)",
                                 "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": ach / (PEAK_BF16 / 1e12),
                                 "traffic": None, "launches": dom["calls"], "avg_launch_ms": dom["ms"] / dom["calls"],
                                 "algorithmic_flop_per_launch": dom["flops"] / dom["calls"]}
