@@ -56,7 +56,8 @@ const char* svg_version(void);
 
 /* ---- models: configure -> load every tensor by state_dict name -> finalize ------------------ */
 /* `kv`: "key=v[,v...];key=v" e.g. "block_out=320,640,1280,1280;layers=2;heads=8;ctx_dim=768".
- * Transformer keys: d_lat, d_model, heads, enc_layers, dec_layers, ffn (default 2048).
+ * Transformer keys: d_lat, d_model, heads, enc_layers, dec_layers, ffn (default 2048), text_dim (0; 384 for the
+ *   text-conditioned variant, whose first layer is named project_image_embedding instead of embedding).
  * VAE keys: block_out (128,256,512,512), layers (2), groups (32), latent (4).
  * UNet keys: block_out (320,640,1280,1280), layers (2), heads (8), ctx_dim (768), groups (32),
  *            in_ch (4), out_ch (4), attn (1,1,1,0: cross-attention per down block). */
@@ -75,6 +76,12 @@ int svg_finalize(svg_ctx* ctx, int model, int64_t* n_params);
  * sampling passes zeros so every clip sees PE(0) exactly as at batch 1). */
 int svg_transformer_forward(svg_ctx* ctx, const float* src, const float* tgt, int B, int Ts, int Tt,
                             const float* mask, const int32_t* pe_row, float* out, void* stream);
+
+/* text-conditioned variant (models/transformer_text.py:71-111; configure text_dim=384): `text` (B,text_dim) f32 is the
+ * class-name embedding (an INPUT: SentenceTransformer('all-MiniLM-L6-v2').encode(cls_list), transformer_text.py:82-83);
+ * token = cat(project_image_embedding(x), text[b]) * sqrt(d_model) + PE, d_model = DIM_MODEL + text_dim. */
+int svg_transformer_forward_text(svg_ctx* ctx, const float* src, const float* tgt, const float* text, int B, int Ts,
+                                 int Tt, const float* mask, const int32_t* pe_row, float* out, void* stream);
 
 /* ---- VAE ------------------------------------------------------------------------------------ */
 /* img: u8 NHWC (N,srcH,srcW,3); nearest-resized to (H,W) on the fly when they differ.

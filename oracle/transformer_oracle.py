@@ -85,11 +85,22 @@ def count_layers(sd, stem):
     return n
 
 
-def forward(sd, src, tgt, num_heads, tgt_mask=None):
-    """transformer.py:47-68.  src/tgt (B,T,D_lat) -> (T_tgt,B,D_lat).  eval mode (no dropout)."""
-    d = sd["embedding.weight"].shape[0]
+def forward(sd, src, tgt, num_heads, tgt_mask=None, txt=None):
+    """transformer.py:47-68.  src/tgt (B,T,D_lat) -> (T_tgt,B,D_lat).  eval mode (no dropout).
+    With `txt` (B,384): the text-conditioned variant, models/transformer_text.py:71-111 — the embedding layer is
+    `project_image_embedding` and every token is cat(proj(x), txt[b]) * sqrt(d), d = DIM_MODEL + 384 (:33-35,:82-92).
+    (That file cannot be imported here — sentence_transformers is missing — so this branch is pinned through its exact
+    equivalence with the pinned base path: tests/test_oracle_transformer.py::test_text_variant_equivalence.)"""
+    if txt is None:
+        d = sd["embedding.weight"].shape[0]
+        emb = lambda x: F.linear(x, sd["embedding.weight"], sd["embedding.bias"]) * math.sqrt(d)
+    else:
+        d = sd["project_image_embedding.weight"].shape[0] + txt.shape[-1]
+
+        def emb(x):
+            e = F.linear(x, sd["project_image_embedding.weight"], sd["project_image_embedding.bias"])
+            return torch.cat((e, txt.unsqueeze(1).repeat(1, x.shape[1], 1)), dim=-1) * math.sqrt(d)
     pe = sd.get("positional_encoder.pos_encoding", positional_table(d))
-    emb = lambda x: F.linear(x, sd["embedding.weight"], sd["embedding.bias"]) * math.sqrt(d)
     s = emb(src)
     t = emb(tgt)
     # positional_encoding.py:33-35 — slices by dim 0 of the batch-first tensor (quirk §9.1)
@@ -113,10 +124,10 @@ def forward(sd, src, tgt, num_heads, tgt_mask=None):
     return F.linear(t, sd["out.weight"], sd["out.bias"])
 
 
-def predict(sd, input_sequence, num_heads):
-    """prediction/predict.py:16-42 -> (D_lat,)."""
+def predict(sd, input_sequence, num_heads, txt=None):
+    """prediction/predict.py:16-42 (and predict_text.py:48-74 with `txt`) -> (D_lat,)."""
     mask = get_tgt_mask(input_sequence.size(1))
-    pred = forward(sd, input_sequence, input_sequence, num_heads, mask)
+    pred = forward(sd, input_sequence, input_sequence, num_heads, mask, txt)
     return pred.permute(1, 0, 2)[0, -1]
 
 

@@ -28,6 +28,7 @@ SIGNATURES = {
     "svg_load_weight": [_vp, _i, C.c_char_p, _vp, C.POINTER(_i64), _i],
     "svg_finalize": [_vp, _i, C.POINTER(_i64)],
     "svg_transformer_forward": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "svg_transformer_forward_text": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "svg_vae_encode": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "svg_vae_decode": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp],
     "svg_unet_forward": [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp],
@@ -138,7 +139,7 @@ class Context:
         return n.value
 
     # ---- hot path ----------------------------------------------------------------------------
-    def transformer_forward(self, src, tgt, mask=None, pe_row=None):
+    def transformer_forward(self, src, tgt, mask=None, pe_row=None, text=None):
         B, Ts, D = src.shape
         Tt = tgt.shape[1]
         src = src.contiguous().float()
@@ -146,6 +147,12 @@ class Context:
         out = torch.empty((Tt, B, D), device=src.device, dtype=torch.float32)
         mask = mask.contiguous().float() if mask is not None else None
         pe_row = pe_row.to(device=src.device, dtype=torch.int32).contiguous() if pe_row is not None else None
+        if text is not None:
+            text = text.to(device=src.device, dtype=torch.float32).contiguous()
+            assert text.shape[0] == B
+            self.check(self.lib.svg_transformer_forward_text(self.h, _ptr(src), _ptr(tgt_c), _ptr(text), B, Ts, Tt, _ptr(mask),
+                                                             _ptr(pe_row), _ptr(out), _stream()), "svg_transformer_forward_text")
+            return out
         self.check(self.lib.svg_transformer_forward(self.h, _ptr(src), _ptr(tgt_c), B, Ts, Tt, _ptr(mask), _ptr(pe_row),
                                                     _ptr(out), _stream()), "svg_transformer_forward")
         return out

@@ -125,8 +125,9 @@ void xf_gemm(svg_ctx* ctx, const float* X, const float* W, const float* bias, fl
 void xf_add_ln(const float* x, const float* r, const float* g, const float* b, float* y, int M, int d,
                float eps, hipStream_t s);
 // emb (B*T,d) -> (T,B,d): y[t][b] = emb[b][t]*sqrt(d) + pe[pe_row[b]]
-void xf_embed_post(const float* emb, const float* pe, const int32_t* pe_row, float* y, int B, int T, int d,
-                   float scale, hipStream_t s);
+// text (B,d_txt) or null: channels >= d - d_txt of every token come from text[b] instead of emb (emb rows are d - d_txt wide)
+void xf_embed_post(const float* emb, const float* pe, const int32_t* pe_row, const float* text, int d_txt, float* y, int B, int T,
+                   int d, float scale, hipStream_t s);
 // seq-first MHA core on packed projections: q (Tq,B,ldq) k,v (Tk,B,ldk) -> o (Tq,B,d); mask (Tq,Tk) or null
 void xf_attention(const float* q, int ldq, const float* k, const float* v, int ldk, const float* mask,
                   float* o, int Tq, int Tk, int B, int heads, int hd, hipStream_t s);

@@ -7,7 +7,7 @@ void XfModel::configure(const char* kv) {
   auto m = parse_kv(kv);
   auto geti = [&](const char* k, int& dst) { if (m.count(k)) dst = (int)m[k][0]; };
   geti("d_lat", d_lat); geti("d_model", d_model); geti("heads", heads);
-  geti("enc_layers", enc_layers); geti("dec_layers", dec_layers); geti("ffn", ffn);
+  geti("enc_layers", enc_layers); geti("dec_layers", dec_layers); geti("ffn", ffn); geti("text_dim", text_dim);
   ready = false;
 }
 
@@ -16,7 +16,9 @@ void XfModel::finalize(svg_ctx* ctx, int64_t* n_params) {
   SVG_CHECK(d_model % heads == 0 && d_model % 16 == 0 && d_lat % 16 == 0 && ffn % 16 == 0,
             "transformer: d_model %d / d_lat %d / ffn %d must be multiples of 16 (and d_model of heads)", d_model, d_lat, ffn);
   const int64_t d = d_model;
-  ws.get("embedding.weight", {d, d_lat}); ws.get("embedding.bias", {d});
+  SVG_CHECK(text_dim >= 0 && text_dim < d_model, "transformer: text_dim %d out of range", text_dim);
+  const char* emb_name = text_dim ? "project_image_embedding" : "embedding";     // transformer_text.py:60 vs transformer.py:37
+  ws.get(std::string(emb_name) + ".weight", {d - text_dim, d_lat}); ws.get(std::string(emb_name) + ".bias", {d - text_dim});
   ws.get("out.weight", {d_lat, d}); ws.get("out.bias", {d_lat});
   auto check_mha = [&](const std::string& p) {
     ws.get(p + "in_proj_weight", {3 * d, d}); ws.get(p + "in_proj_bias", {3 * d});
@@ -73,6 +75,7 @@ void XfModel::finalize(svg_ctx* ctx, int64_t* n_params) {
 namespace {
 struct XfRun {
   svg_ctx* ctx; XfModel* m; hipStream_t s; int B;
+  const float* text = nullptr;   // (B, text_dim) for the text-conditioned variant
   const float* W(const std::string& n) { return m->ws.get(n).f32; }
   float* gemm(const float* X, const std::string& w, const std::string& b, int M, int N, int K, int relu_in = 0,
               int64_t woff = 0, int64_t boff = 0) {
@@ -112,12 +115,13 @@ struct XfRun {
     return gemm(h, p + "linear2.weight", p + "linear2.bias", M, m->d_model, m->ffn, /*relu_in=*/1);
   }
   float* embed(const float* x, int T, const int32_t* pe_row) {
-    const int d = m->d_model;
-    float* e = gemm(x, "embedding.weight", "embedding.bias", B * T, d, m->d_lat);
+    const int d = m->d_model, d_img = d - m->text_dim;
+    const std::string en = m->text_dim ? "project_image_embedding" : "embedding";
+    float* e = gemm(x, en + ".weight", en + ".bias", B * T, d_img, m->d_lat);
     float* y = ctx->arena.get<float>((int64_t)B * T * d);
     if (SVG_LAUNCHING(ctx)) {
       ProfScope ps(ctx, PK_XF_MISC, s, 0, 8.0 * B * T * d);
-      xf_embed_post(e, m->pe, pe_row, y, B, T, d, sqrtf((float)d), s);
+      xf_embed_post(e, m->pe, pe_row, text, m->text_dim, y, B, T, d, sqrtf((float)d), s);
     }
     return y;
   }
@@ -126,8 +130,9 @@ struct XfRun {
 
 // One chunk of batch rows (B*max(Ts,Tt) <= 64).  pe_row must be non-null here.
 static void xf_forward_chunk(svg_ctx* ctx, XfModel* m, const float* src, const float* tgt, int B, int Ts, int Tt,
-                             const float* mask, const int32_t* pe_row, float* out_tb, hipStream_t s) {
+                             const float* mask, const int32_t* pe_row, float* out_tb, hipStream_t s, const float* text) {
   XfRun r{ctx, m, s, B};
+  r.text = text;
   float* xs = r.embed(src, Ts, pe_row);
   float* xt = (tgt == src && Ts == Tt) ? xs : r.embed(tgt, Tt, pe_row);
   const int Ms = Ts * B, Mt = Tt * B;
@@ -148,8 +153,9 @@ static void xf_forward_chunk(svg_ctx* ctx, XfModel* m, const float* src, const f
 }
 
 void XfModel::forward(svg_ctx* ctx, const float* src, const float* tgt, int B, int Ts, int Tt, const float* mask,
-                      const int32_t* pe_row, float* out, hipStream_t s) {
+                      const int32_t* pe_row, float* out, hipStream_t s, const float* text) {
   SVG_CHECK(ready, "transformer: svg_finalize has not been called");
+  SVG_CHECK((text_dim > 0) == (text != nullptr), "transformer: the text-conditioned variant needs (and only it takes) a text embedding");
   SVG_CHECK(B >= 1 && Ts >= 1 && Tt >= 1 && Ts <= 16 && Tt <= 16, "transformer: B=%d Ts=%d Tt=%d unsupported", B, Ts, Tt);
   SVG_CHECK(pe_row || B <= 64, "transformer: batch %d > max_len 64 of the positional table", B);
   const int Tmax = std::max(Ts, Tt);
@@ -163,7 +169,7 @@ void XfModel::forward(svg_ctx* ctx, const float* src, const float* tgt, int B, i
       rows = r;
     }
     if (B <= Bc) {
-      xf_forward_chunk(ctx, this, src, tgt, B, Ts, Tt, mask, rows, out, s);
+      xf_forward_chunk(ctx, this, src, tgt, B, Ts, Tt, mask, rows, out, s, text);
     } else {
       for (int b0 = 0; b0 < B; b0 += Bc) {
         const int bc = std::min(Bc, B - b0);
@@ -171,7 +177,7 @@ void XfModel::forward(svg_ctx* ctx, const float* src, const float* tgt, int B, i
         float* tmp = ctx->arena.get<float>((int64_t)Tt * bc * d_lat);
         const float* srcc = src + (int64_t)b0 * Ts * d_lat;
         const float* tgtc = (tgt == src) ? srcc : tgt + (int64_t)b0 * Tt * d_lat;
-        xf_forward_chunk(ctx, this, srcc, tgtc, bc, Ts, Tt, mask, rows + b0, tmp, s);
+        xf_forward_chunk(ctx, this, srcc, tgtc, bc, Ts, Tt, mask, rows + b0, tmp, s, text ? text + (int64_t)b0 * text_dim : nullptr);
         if (SVG_LAUNCHING(ctx))
           HIP_OK(hipMemcpy2DAsync(out + (int64_t)b0 * d_lat, (size_t)B * d_lat * sizeof(float), tmp,
                                   (size_t)bc * d_lat * sizeof(float), (size_t)bc * d_lat * sizeof(float), Tt,
@@ -180,6 +186,18 @@ void XfModel::forward(svg_ctx* ctx, const float* src, const float* tgt, int B, i
       }
     }
   });
+}
+
+extern "C" int svg_transformer_forward_text(svg_ctx* ctx, const float* src, const float* tgt, const float* text, int B, int Ts, int Tt,
+                                            const float* mask, const int32_t* pe_row, float* out, void* stream) {
+  try {
+    SVG_CHECK(ctx && ctx->xf, "transformer: model not configured");
+    ctx->xf->forward(ctx, src, tgt, B, Ts, Tt, mask, pe_row, out, (hipStream_t)stream, text);
+    return 0;
+  } catch (const std::exception& e) {
+    if (ctx) ctx->err = e.what();
+    return -1;
+  }
 }
 
 extern "C" int svg_transformer_forward(svg_ctx* ctx, const float* src, const float* tgt, int B, int Ts, int Tt, const float* mask,

@@ -41,6 +41,7 @@ struct PackedLinear {
 struct XfModel {
   WeightStore ws;
   int d_lat = 0, d_model = 0, heads = 8, enc_layers = 0, dec_layers = 0, ffn = 2048;
+  int text_dim = 0;   // > 0: text-conditioned variant (models/transformer_text.py): d_model = DIM_MODEL + text_dim
   bool ready = false;
   float* pe = nullptr;   // (64, d_model)
   int pe_d = 0;
@@ -48,7 +49,7 @@ struct XfModel {
   void configure(const char* kv);
   void finalize(svg_ctx* ctx, int64_t* n_params);
   void forward(svg_ctx* ctx, const float* src, const float* tgt, int B, int Ts, int Tt, const float* mask,
-               const int32_t* pe_row, float* out, hipStream_t s);
+               const int32_t* pe_row, float* out, hipStream_t s, const float* text = nullptr);
 };
 
 // ---- SD VAE -------------------------------------------------------------------------------------------

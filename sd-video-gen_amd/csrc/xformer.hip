@@ -122,16 +122,19 @@ __global__ void __launch_bounds__(256) xf_add_ln_kernel(const float* __restrict_
   }
 }
 
-// emb rows are (b,t) batch-first; out rows are (t,b) sequence-first; PE row chosen per batch row
+// emb rows are (b,t) batch-first (d - d_txt wide); out rows are (t,b) sequence-first; PE row chosen per batch row;
+// the last d_txt channels of every token are the per-clip text embedding (models/transformer_text.py:82-92)
 __global__ void xf_embed_post_kernel(const float* __restrict__ emb, const float* __restrict__ pe, const int32_t* __restrict__ pe_row,
-                                     float* __restrict__ y, int B, int T, int d, float scale) {
+                                     const float* __restrict__ text, int d_txt, float* __restrict__ y, int B, int T, int d, float scale) {
+  const int d_img = d - d_txt;
   const int64_t total = (int64_t)B * T * d;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(idx % d);
     const int t = (int)((idx / d) % T);
     const int b = (int)(idx / ((int64_t)d * T));
     const int pr = pe_row ? pe_row[b] : b;
-    y[((int64_t)t * B + b) * d + c] = emb[idx] * scale + pe[(int64_t)pr * d + c];
+    const float v = (c < d_img) ? emb[((int64_t)b * T + t) * d_img + c] : text[(int64_t)b * d_txt + (c - d_img)];
+    y[((int64_t)t * B + b) * d + c] = v * scale + pe[(int64_t)pr * d + c];
   }
 }
 
@@ -200,9 +203,11 @@ void xf_add_ln(const float* x, const float* r, const float* g, const float* b, f
   check_launch("xf_add_ln");
 }
 
-void xf_embed_post(const float* emb, const float* pe, const int32_t* pe_row, float* y, int B, int T, int d, float scale, hipStream_t s) {
+void xf_embed_post(const float* emb, const float* pe, const int32_t* pe_row, const float* text, int d_txt, float* y, int B, int T, int d,
+                   float scale, hipStream_t s) {
   const int64_t total = (int64_t)B * T * d;
-  hipLaunchKernelGGL(xf_embed_post_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 2048)), dim3(256), 0, s, emb, pe, pe_row, y, B, T, d, scale);
+  hipLaunchKernelGGL(xf_embed_post_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 2048)), dim3(256), 0, s, emb, pe, pe_row, text,
+                     d_txt, y, B, T, d, scale);
   check_launch("xf_embed_post");
 }
 

@@ -8,13 +8,16 @@ frame dropped from the emitted clip.  The clip-batched loop runs C independent c
 import torch
 
 
-def predict(model, input_sequence, pe_row=None):
-    """prediction/predict.py:16-42 -> (D_lat,) for batch row 0 (or (B,D_lat) rows when ``pe_row`` is given)."""
+def predict(model, input_sequence, pe_row=None, cls_list=None):
+    """prediction/predict.py:16-42 -> (D_lat,) for batch row 0 (or (B,D_lat) rows when ``pe_row`` is given).
+    With ``cls_list`` (class names or a (B,384) tensor) the model is the text-conditioned one and the call is
+    prediction/predict_text.py:48-74."""
     model.eval()
     with torch.no_grad():
         tgt_mask = model.get_tgt_mask(input_sequence.size(1)).to(input_sequence.device)
-        pred = model(input_sequence, input_sequence, tgt_mask, pe_row=pe_row) if pe_row is not None \
-            else model(input_sequence, input_sequence, tgt_mask)
+        lead = (input_sequence,) if cls_list is None else (input_sequence, cls_list)
+        pred = model(*lead, input_sequence, tgt_mask, pe_row=pe_row) if pe_row is not None \
+            else model(*lead, input_sequence, tgt_mask)
         pred = pred.permute(1, 0, 2)                       # (B, T, D)
     if pe_row is not None:
         return pred[:, -1]
@@ -28,7 +31,8 @@ def clip_noise(seeds, shape, device):
 
 
 def sample_clips(model, sd_utils, clips_u8, pred_frames, denoise=False, start_step=40, seeds=None,
-                 text_embeddings=None, num_inference_steps=50, guidance_scale=0.0, return_frames=False, res=512):
+                 text_embeddings=None, num_inference_steps=50, guidance_scale=0.0, return_frames=False, res=512,
+                 cls_list=None):
     """The per-clip loop of prediction/predict.py:117-197 for C independent clips in lock step, device resident.
 
     clips_u8: (C,5,F,F,3) uint8 conditioning frames on the device.  Every stage is batched over clips; a clip's
@@ -36,7 +40,9 @@ def sample_clips(model, sd_utils, clips_u8, pred_frames, denoise=False, start_st
     draws follow the reference's order: VAE sample of the 5 conditioning frames; then per predicted frame the VAE
     sample @512, add_noise (start_step>0), the VAE sample @F.  The four host crossings per frame of the reference
     (decode -> numpy -> tensor -> interpolate, twice) become fused on-device uint8 nearest resizes with identical
-    rounding.  Returns all_latents (C, 4+N, D_lat) f32 [and the decoded frames (C,4+N,F,F,3) uint8].
+    rounding.  ``cls_list`` (one class name per clip, or a (C,384) tensor) selects the text-conditioned loop of
+    prediction/predict_text.py:186-262 (same loop, `predict(model, X, cls_list)`); the names are encoded once.
+    Returns all_latents (C, 4+N, D_lat) f32 [and the decoded frames (C,4+N,F,F,3) uint8].
     """
     ctx = sd_utils.ctx
     dev = clips_u8.device
@@ -54,6 +60,8 @@ def sample_clips(model, sd_utils, clips_u8, pred_frames, denoise=False, start_st
         X = torch.cat((sd_utils.SOS_token.repeat(C, 1, 1), z), dim=1)
         inputs = z                                                                          # :136-141
         pe0 = torch.zeros(C, dtype=torch.int32, device=dev)
+        if cls_list is not None and not isinstance(cls_list, torch.Tensor):
+            cls_list = model.encode_classes(cls_list).to(dev)
         preds = []
         if denoise:
             emb = text_embeddings if text_embeddings is not None else sd_utils.encode_text([""])   # :148 (constant: hoisted)
@@ -62,7 +70,7 @@ def sample_clips(model, sd_utils, clips_u8, pred_frames, denoise=False, start_st
                 emb = torch.cat([emb[:1].repeat(C, 1, 1), emb[1:].repeat(C, 1, 1)])
         all_latents = None
         for _ in range(pred_frames):
-            pred = predict(model, X, pe_row=pe0)                                            # :144  (C, D)
+            pred = predict(model, X, pe_row=pe0, cls_list=cls_list)                         # :144  (C, D)
             if denoise:
                 noisy_img = ctx.vae_decode(pred.reshape(C, 4, L, L))                        # :149-153 (uint8, on device)
                 e512 = clip_noise(gens, (4, res // 8, res // 8), dev)

@@ -1,0 +1,107 @@
+"""Host-side mirror of the reference's text-conditioned latent Transformer (models/transformer_text.py:15-137,
+BASELINE config 5): every token is ``cat(Linear(D_lat -> DIM_MODEL)(x), class_embedding_384) * sqrt(d)`` with
+``d = DIM_MODEL + 384`` (transformer_text.py:33-35,82-92); the rest is the base model at width d.
+
+The class-name embedding comes from ``SentenceTransformer('all-MiniLM-L6-v2').encode(cls_list)`` in the reference —
+an INPUT of this path whose weights are hub-only.  ``encode_classes`` uses a caller-supplied encoder when given, else a
+seeded per-string stand-in (equal strings -> equal vectors, unit norm like MiniLM's normalised output)."""
+import zlib
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .config import parse_config_args
+from .transformer import PositionalEncoding
+
+TEXT_EMBED_DIM = 384
+
+
+class Transformer(nn.Module):
+    def __init__(self, num_tokens=0, dim_model=256, num_heads=8, num_encoder_layers=6, num_decoder_layers=6,
+                 dropout_p=0.1, text_encoder=None):
+        super().__init__()
+        self.config, self.args = parse_config_args()
+        self.text_embed_dim = TEXT_EMBED_DIM
+        self.dim_model = dim_model + self.text_embed_dim
+        self.img_embed_dim = dim_model
+        self.num_heads = num_heads
+        self.num_encoder_layers = num_encoder_layers
+        self.num_decoder_layers = num_decoder_layers
+        self.height = self.width = self.config.FRAME_SIZE
+        self.compression = 8
+        self.d_lat = self.height // 8 * self.width // 8 * 4
+        self.text_encoder = text_encoder          # callable(list[str]) -> (n, 384) array / tensor, or None
+        # parameter containers in the reference's construction order (transformer_text.py:48-69)
+        self.positional_encoder = PositionalEncoding(dim_model=self.dim_model, dropout_p=dropout_p, max_len=64)
+        self.project_image_embedding = nn.Linear(self.d_lat, self.img_embed_dim)
+        self.transformer = nn.Transformer(d_model=self.dim_model, nhead=num_heads, num_encoder_layers=num_encoder_layers,
+                                          num_decoder_layers=num_decoder_layers, dropout=dropout_p)
+        self.out = nn.Linear(self.dim_model, self.d_lat)
+        self._ctx = None
+        self._uploaded_version = None
+
+    def encode_classes(self, cls_list):
+        if self.text_encoder is not None:
+            return torch.as_tensor(self.text_encoder(list(cls_list)), dtype=torch.float32)
+        out = []
+        for c in cls_list:
+            g = torch.Generator().manual_seed(zlib.crc32(str(c).encode()) % (2 ** 31))
+            v = torch.randn(TEXT_EMBED_DIM, generator=g)
+            out.append(v / v.norm())
+        return torch.stack(out)
+
+    def use_context(self, ctx):
+        self._bound_ctx = ctx
+        self._uploaded_version = None
+        return self
+
+    def _version(self):
+        return tuple(int(p._version) for p in self.parameters()) + (id(self._ctx),)
+
+    def _sync_weights(self):
+        ctx = getattr(self, "_bound_ctx", None) or _lib.default_context()
+        if self._ctx is ctx and self._uploaded_version == self._version():
+            return ctx
+        self._ctx = ctx
+        ctx.configure(_lib.SVG_TRANSFORMER, d_lat=self.d_lat, d_model=self.dim_model, heads=self.num_heads,
+                      enc_layers=self.num_encoder_layers, dec_layers=self.num_decoder_layers, text_dim=self.text_embed_dim,
+                      ffn=self.transformer.encoder.layers[0].linear1.out_features if self.num_encoder_layers else 2048)
+        ctx.load_state_dict(_lib.SVG_TRANSFORMER, self.state_dict())
+        self.n_params = ctx.finalize(_lib.SVG_TRANSFORMER)
+        self._uploaded_version = self._version()
+        return ctx
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._uploaded_version = None
+        return r
+
+    def forward(self, src, cls_list, tgt, tgt_mask=None, src_pad_mask=None, tgt_pad_mask=None, pe_row=None):
+        """transformer_text.py:71-111.  ``cls_list``: class names (one per batch row) or a (B,384) tensor."""
+        if self.training and self.positional_encoder.dropout_p > 0:
+            raise RuntimeError("the HIP path implements eval-mode sampling (dropout off); call model.eval()")
+        if src_pad_mask is not None or tgt_pad_mask is not None:
+            raise NotImplementedError("key-padding masks are not on the sampling path")
+        if not src.is_cuda:
+            raise RuntimeError("Transformer.forward runs on the HIP library and needs CUDA tensors; there is no CPU fallback")
+        txt = cls_list if isinstance(cls_list, torch.Tensor) else self.encode_classes(cls_list)
+        ctx = self._sync_weights()
+        return ctx.transformer_forward(src, tgt, tgt_mask, pe_row, text=txt)
+
+    def get_tgt_mask(self, size):
+        mask = torch.tril(torch.ones(size, size) == 1).float()
+        mask = mask.masked_fill(mask == 0, float("-inf"))
+        return mask.masked_fill(mask == 1, float(0.0))
+
+    def create_pad_mask(self, matrix, pad_token):
+        return matrix == pad_token
+
+
+def predict(model, input_sequence, cls_list):
+    """prediction/predict_text.py:48-74 -> (D_lat,)."""
+    model.eval()
+    with torch.no_grad():
+        tgt_mask = model.get_tgt_mask(input_sequence.size(1)).to(input_sequence.device)
+        pred = model(input_sequence, cls_list, input_sequence, tgt_mask).permute(1, 0, 2)
+    return pred[0, -1]

@@ -94,3 +94,23 @@ def test_errors(ctx):
         m(torch.zeros(1, 5, 256), torch.zeros(1, 5, 256))        # CPU tensors: no fallback
     with pytest.raises((RuntimeError, ValueError)):
         m(torch.zeros(1, 40, 256).cuda(), torch.zeros(1, 40, 256).cuda())   # T > 16 unsupported
+
+
+def test_text_conditioned_variant(ctx):
+    """a14 / BASELINE config 5 shape family: d = DIM_MODEL + 384 (head dim not a power of two), clip-batched."""
+    from sd_video_gen_amd import config as svg_config
+    from sd_video_gen_amd.transformer_text import Transformer as TextTransformer, predict as predict_text
+    svg_config.set_args(["--dataset", "ucf", "--config", "model_10_26"])
+    torch.manual_seed(4)
+    m = TextTransformer(dim_model=128, num_heads=8, num_encoder_layers=2, num_decoder_layers=2).eval()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    X = torch.randn(3, 6, 256)
+    names = ["WallPushups", "PlayingGuitar", "WallPushups"]
+    txt = m.encode_classes(names)
+    out = m(X.cuda(), names, X.cuda(), m.get_tgt_mask(6).cuda()).cpu()
+    assert out.shape == (6, 3, 256)
+    assert rel_l2(out, TO.forward(sd, X, X, 8, TO.get_tgt_mask(6), txt=txt)) < TOL
+    p = predict_text(m, X[:1].cuda(), names[:1]).cpu()
+    assert rel_l2(p, TO.predict(sd, X[:1], 8, txt=txt[:1])) < TOL
+    with pytest.raises((RuntimeError, ValueError)):
+        ctx.transformer_forward(X.cuda(), X.cuda(), None, None)          # text model called without a text embedding
