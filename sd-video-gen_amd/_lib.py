@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsvg_hip.so")
+LIB_PATH = os.environ.get("SVG_LIB") or os.path.join(_HERE, "libsvg_hip.so")   # $SVG_LIB: A/B another build of the same ABI
 
 SVG_TRANSFORMER, SVG_VAE, SVG_UNET = 0, 1, 2
 

@@ -36,11 +36,37 @@ __device__ __forceinline__ void dma16(v4i srd, unsigned voff, int soff, unsigned
 // needs 16-aligned windows; the tap-shifted patch reads here start anywhere: it measured 25 % conflict cycles.)
 __device__ __forceinline__ int lds_off7(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
+// compile-time ablation switch for tools/abl_halo.sh (-DHALO_ABL=n): 1 no stores, 2 no MFMA, 3 no DMA, 4 no fragment reads, 6 no barrier
+#ifndef HALO_ABL
+#define HALO_ABL 0
+#endif
+constexpr int ABL = HALO_ABL;
 constexpr int PW = 18;                 // patch width / height in pixels
 constexpr int PPIX = PW * PW;          // 324
 constexpr int NPD = 6;                 // patch DMA instructions per wave: 8 waves * 64 lanes * 6 = 3072 >= 324 * 8 chunks
 
-template <int BN>
+// wave-uniform counted wait (the count has to be an immediate)
+__device__ __forceinline__ void wait_vm(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+  }
+}
+// raw barrier that the compiler may not move LDS accesses across
+__device__ __forceinline__ void bar() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// PP = ping-pong schedule: the 8 waves run as two groups of four (one wave of each group per SIMD) staggered by one
+// barrier, so that while one group multiplies (20 MFMAs between two barriers, s_setprio 1) the other issues its fragment
+// reads and DMAs — the matrix pipe always has a wave feeding it instead of all eight loading, then all eight multiplying.
+template <int BN, bool PP>
 __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
   constexpr int NT = BN / 32;            // 16-wide channel tiles per wave
   constexpr int MT = 4;                  // image rows per wave
@@ -93,17 +119,22 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
   const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);   // LDS address of smem[0]
 
   // ---- patch DMA map: linear LDS image [pixel][8 chunks]; lane id -> (pp, position); the swizzle rides on the source chunk
-  unsigned p_voff[NPD];
-#pragma unroll
-  for (int i = 0; i < NPD; ++i) {
-    const int id = (i * 8 + wid) * 64 + lane;          // 16-byte slot in the patch buffer
+  auto patch_voff = [&](int i) -> unsigned {
+    int ln = lane;
+    if (PP) asm volatile("" : "+v"(ln));               // keeps LICM from hoisting the six offsets back into registers
+    const int id = (i * 8 + wid) * 64 + ln;            // 16-byte slot in the patch buffer
     const int pp = id >> 3, pos = id & 7;
     const int c = pos ^ (pp & 7);
     const int py = pp / PW, px = pp - py * PW;
     const int yy = y0 - 1 + py, xx = x0 - 1 + px;
     const bool ok = pp < PPIX && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W;
-    p_voff[i] = ok ? (unsigned)(((b * g.H + yy) * g.W + xx) * g.Cin + c * 8) * 2u : INVALID;
-  }
+    return ok ? (unsigned)(((b * g.H + yy) * g.W + xx) * g.Cin + c * 8) * 2u : INVALID;
+  };
+  // the lock-step loop keeps the six offsets in registers; the ping-pong loop (one piece per step, registers are its
+  // scarce resource) recomputes the piece's offset when it issues it
+  unsigned p_voff[NPD];
+#pragma unroll
+  for (int i = 0; i < NPD; ++i) p_voff[i] = PP ? 0u : patch_voff(i);
   // ---- weight DMA map (as gemm.hip): rows r0 + 64 i, chunk swizzled on the source
   const int r0 = tid >> 3;                                // 0..63
   const int cB = (tid & 7) ^ (r0 & 7);
@@ -131,6 +162,16 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
     // other waves into the sink with an out-of-range source.
     const unsigned d5 = (wave_u == 0) ? (dst + (NPD - 1) * 8192) : (lds0 + OFF_DUMMY + wave_u * 1024);
     if (wid != 0 || lane < 32) dma16(srdA, wid == 0 ? p_voff[NPD - 1] : INVALID, soff, d5);
+  };
+  auto dma_patch_piece = [&](int cc, int buf, int i) {      // one of the NPD pieces (i is a compile-time constant after unrolling)
+    const unsigned dst = lds0 + buf * PBUF + wave_u * 1024;
+    const int soff = cc * 128;
+    const unsigned voff = patch_voff(i);
+    if (i < NPD - 1) dma16(srdA, voff, soff, dst + i * 8192);
+    else {
+      const unsigned d5 = (wave_u == 0) ? (dst + (NPD - 1) * 8192) : (lds0 + OFF_DUMMY + wave_u * 1024);
+      if (wid != 0 || lane < 32) dma16(srdA, wid == 0 ? voff : INVALID, soff, d5);
+    }
   };
   auto dma_weights = [&](int cc, int tap, int stage) {
     const unsigned dst = lds0 + OFF_B + stage * B_BYTES + wave_u * 1024;
@@ -162,10 +203,24 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 xf[MT], wf[NT];
+      if (ABL != 4) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) xf[i] = *(const bf16x8*)(sp + lds_off7(pp0[i] + toff, kk * 4 + lq));
 #pragma unroll
       for (int j = 0; j < NT; ++j) wf[j] = *(const bf16x8*)(sb + lds_off7(wn * (BN / 2) + j * 16 + l15, kk * 4 + lq));
+      } else {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) asm volatile("" : "=v"(xf[i]));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) asm volatile("" : "=v"(wf[j]));
+      }
+      if (ABL == 2) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) asm volatile("" :: "v"(xf[i]));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) asm volatile("" :: "v"(wf[j]));
+        continue;
+      }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -174,13 +229,133 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
     }
   };
 
-  // ---- main loop over steps s = (cc, tap): weight slab s lives in stage s % 3; the patch alternates per chunk -------
+  // the operands were read a phase ago (the compiler's own counted lgkmcnt covers them, not the reads just issued)
+  auto mma_phase = [&](const bf16x8 (&xf)[MT], const bf16x8 (&wf)[NT]) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (ABL == 2) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) asm volatile("" :: "v"(xf[i]));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) asm volatile("" :: "v"(wf[j]));
+      return;
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+
+  // ---- ping-pong main loop ------------------------------------------------------------------------------------------
+  // Step s = (cc, tap) is two phases (the k halves of the 64-channel chunk); a phase is
+  //     [issue the fragment reads of the NEXT phase + this phase's share of the DMAs (+ counted wait in phase 0)]
+  //     barrier  [20 MFMAs]  barrier
+  // and group 1 (waves 4-7) runs one barrier behind group 0, so its load segment coincides with group 0's MFMAs.
+  // Fragments are read one phase ahead into the other register set, so an MFMA segment never waits on LDS latency; every
+  // wave drains its own reads (lgkmcnt(0), long since landed) before the barrier that closes its MFMA segment.
+  //   RAW: slab s+1 is retired by every wave's counted vmcnt in the load segment of phase (s,0); its first reads are
+  //        issued in the load segment of phase (s,1), two barriers later for that wave's group, one for the other group.
+  //   WAR: slab s+2 (issued from phase (s,0) on) overwrites the stage of slab s-1, whose last reads were issued in phase
+  //        (s-1,0) and drained before that phase's closing barrier — two barriers earlier for the issuing group, one for
+  //        the other.  The next chunk's patch goes into the other patch buffer one piece per step (taps 0-5).
+  //   DMA issue order per step: phase 0: the first N0 instructions of slab s+2; phase 1: the rest, then a patch piece.
+  //   vmcnt in phase (s,0), after its issues; oldest first: [slab s+1 ...][patch piece of s-1][first N0 of slab s+2].
+  // The load segment has to be shorter than the MFMA segment it hides under, so its address arithmetic is hoisted: the
+  // swizzle key of a patch read is (l15 + d) & 7 with d = (18 i + tap offset) & 7 a compile-time constant, so 8 x 2
+  // precomputed lane addresses + an immediate serve all 72 reads of a chunk; the weight reads need 2.
+  if (PP && cc_begin < cc_end) {
+    constexpr int N0 = (NW + 1) / 2;
+    const int grp = wave_u >> 2;
+#pragma unroll
+    for (int i = 0; i < NPD; ++i) dma_patch_piece(cc_begin, 0, i);
+    dma_weights(cc_begin, 0, 0);
+    dma_weights(cc_begin, 1, 1);
+    wait_vm(NW);
+    bar();
+    if (grp == 1) bar();
+
+    int xaddr[8][2];                     // patch lane address for key offset d and k half (buffer 0; flipped per chunk)
+#pragma unroll
+    for (int d = 0; d < 8; ++d)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        xaddr[d][kk] = (wm * 4 * PW + l15) * 128 + (((kk * 4 + lq) ^ ((l15 + d) & 7)) << 4);
+    int waddr[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) waddr[kk] = OFF_B + (wn * (BN / 2) + l15) * 128 + (((kk * 4 + lq) ^ (l15 & 7)) << 4);
+    auto rd_x = [&](int tap, int kk, bf16x8 (&xf)[MT]) {
+      const int toff = (tap / 3) * PW + (tap % 3);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int rel = i * PW + toff;
+        if (ABL != 4) xf[i] = *(const bf16x8*)(smem + xaddr[rel & 7][kk] + rel * 128);
+      }
+    };
+    auto rd_w = [&](int stage, int kk, bf16x8 (&wf)[NT]) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        if (ABL != 4) wf[j] = *(const bf16x8*)(smem + waddr[kk] + stage * B_BYTES + j * 2048);
+    };
+    auto dma_w_part = [&](int cc, int tap, int stage, int i0, int i1) {     // instructions [i0, i1) of a slab's NW
+      const unsigned dst = lds0 + OFF_B + stage * B_BYTES + wave_u * 1024;
+      const int soff = (tap * g.Cin + cc * 64) * 2;
+#pragma unroll
+      for (int i = i0; i < i1; ++i) {
+        if (i < BIT) dma16(srdB, b_voff[i], soff, dst + i * 8192);
+        else dma16(srdB, b_voff_tail, soff, (wave_u < 4) ? (dst + BIT * 8192) : (lds0 + OFF_DUMMY + wave_u * 1024));
+      }
+    };
+
+    bf16x8 xa[MT], wa[NT], xb[MT], wb[NT];
+    rd_x(0, 0, xa);
+    rd_w(0, 0, wa);
+    for (int cc = cc_begin; cc < cc_end; ++cc) {
+      const int pbuf = (cc - cc_begin) & 1;
+      const int hn = (cc + 1 < cc_end) ? 1 : 0;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const bool more_w = tap < 7 || hn;                    // slab s+2 exists
+        const int wcc = tap < 7 ? cc : cc + 1, wtap = tap < 7 ? tap + 2 : tap - 7, wst = (tap + 2) % NWS;
+        // phase 0: second half of this step's fragments, first share of the DMAs, counted wait
+        rd_x(tap, 1, xb);
+        rd_w(tap % NWS, 1, wb);
+        if (ABL != 3 && more_w) dma_w_part(wcc, wtap, wst, 0, N0);
+        wait_vm(more_w && ABL != 3 ? N0 : 0);
+        bar();
+        mma_phase(xa, wa);
+        bar();
+        // phase 1: first half of the next step's fragments, the rest of the DMAs
+        if (tap == 8) {                                        // the next step reads the other patch buffer
+          const int flip = pbuf ? -PBUF : PBUF;
+#pragma unroll
+          for (int d = 0; d < 8; ++d) { xaddr[d][0] += flip; xaddr[d][1] += flip; }
+        }
+        if (tap < 8 || hn) {
+          rd_x((tap + 1) % 9, 0, xa);
+          rd_w((tap + 1) % NWS, 0, wa);
+        }
+        if (ABL != 3 && more_w) dma_w_part(wcc, wtap, wst, N0, NW);
+        if (ABL != 3 && tap < NPD && hn) dma_patch_piece(cc + 1, pbuf ^ 1, tap);
+        bar();
+        mma_phase(xb, wb);
+        bar();
+      }
+    }
+    if (grp == 0) bar();
+  }
+
+  // ---- lock-step main loop over steps s = (cc, tap): weight slab s lives in stage s % 3; the patch alternates per chunk
   // iteration s:  wait until slab s (and anything older) has landed, leaving only slab s+1 (and a just-issued patch)
   //               in flight -> barrier (everyone's pieces landed; stage (s+2)%3 and, at tap 0, the other patch buffer
   //               were last read in iteration s-1) -> issue patch(cc+1) [tap 0] and slab s+2 -> multiply slab s.
-  if (cc_begin < cc_end) {
+  if (!PP && cc_begin < cc_end) {
     const int nsteps = (cc_end - cc_begin) * 9;
     auto issue_w = [&](int sidx) {
+      if (ABL == 3) return;
       if (sidx < nsteps) dma_weights(cc_begin + sidx / 9, sidx % 9, sidx % NWS);
     };
     dma_patch(cc_begin, 0);
@@ -198,9 +373,9 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
         } else {
           if (NW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();
+        if (ABL != 6) __builtin_amdgcn_s_barrier();
         patch_just_issued = false;
-        if (tap == 0 && cc + 1 < cc_end) { dma_patch(cc + 1, pbuf ^ 1); patch_just_issued = true; }
+        if (tap == 0 && cc + 1 < cc_end && ABL != 3) { dma_patch(cc + 1, pbuf ^ 1); patch_just_issued = true; }
         issue_w(s + 2);
         const int ky = tap / 3, kx = tap - ky * 3;
         compute(pbuf, s % NWS, ky * PW + kx);
@@ -210,6 +385,7 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
   }
 
   // ---- epilogue -----------------------------------------------------------------------------------------------
+  if (ABL == 1 && acc[0][0][0] != 12345.f) return;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = (b * g.H + y0 + wm * 4 + i) * g.W + x0 + l15;
@@ -227,15 +403,15 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
   }
 }
 
-template <int BN>
+template <int BN, bool PP>
 void launch_halo(const GemmArgs& g, dim3 grid, hipStream_t s) {
   constexpr int smem = 2 * PPIX * 128 + 3 * BN * 128 + 8192;
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_OK(hipFuncSetAttribute((const void*)conv_halo_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    HIP_OK(hipFuncSetAttribute((const void*)conv_halo_kernel<BN, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_halo_kernel<BN>), grid, dim3(512), smem, s, g);
+  hipLaunchKernelGGL((conv_halo_kernel<BN, PP>), grid, dim3(512), smem, s, g);
 }
 
 }  // namespace
@@ -266,6 +442,8 @@ int conv_halo_bn(const GemmArgs& g) {
 }
 
 void launch_conv_halo(const GemmArgs& g, dim3 grid, hipStream_t s) {
-  if (conv_halo_bn(g) == 160) launch_halo<160>(g, grid, s);
-  else launch_halo<128>(g, grid, s);
+  static const int pp = getenv("SVG_HALO_PP") ? atoi(getenv("SVG_HALO_PP")) : 1;
+  const bool w160 = conv_halo_bn(g) == 160;
+  if (pp) { if (w160) launch_halo<160, true>(g, grid, s); else launch_halo<128, true>(g, grid, s); }
+  else    { if (w160) launch_halo<160, false>(g, grid, s); else launch_halo<128, false>(g, grid, s); }
 }
