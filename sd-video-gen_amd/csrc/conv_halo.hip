@@ -425,7 +425,8 @@ bool conv_halo_supported(const GemmArgs& g) {
   if (off || g.amode != A_CONV_S1 || g.Cin % 64 != 0 || g.H % 16 != 0 || g.W % 16 != 0 || g.batch != 1 || g.out_f32 ||
       g.act == ACT_GEGLU || g.N < 128 || g.Ho != g.H || g.Wo != g.W)
     return false;
-  return (int64_t)(g.M / 256) * cdiv(g.N, conv_halo_bn(g)) >= 192;
+  static const int min_wg = getenv("SVG_HALO_MIN") ? atoi(getenv("SVG_HALO_MIN")) : 192;
+  return (int64_t)(g.M / 256) * cdiv(g.N, conv_halo_bn(g)) >= min_wg;
 }
 
 // channel-tile width: fewest serial rounds of workgroups (one per CU) times tile width; ties -> fewer padded columns

@@ -454,7 +454,8 @@ void gemm_auto(svg_ctx* ctx, GemmArgs g, hipStream_t s, int prof_kind) {
     const int64_t blocks = (int64_t)(g.M / 256) * cdiv(g.N, conv_halo_bn(g));
     const int CC = g.Cin / 64;
     int sk = 1;
-    if (blocks < 192 && CC >= 4) sk = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((320 + blocks - 1) / blocks, CC / 2), 8));
+    static const int tgt = getenv("SVG_HALO_SPLIT_TGT") ? atoi(getenv("SVG_HALO_SPLIT_TGT")) : 320;
+    if (blocks < 192 && CC >= 4) sk = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((tgt + blocks - 1) / blocks, CC / 2), 8));
     g.splitk = sk;
     if (sk > 1) {
       ctx->arena.push();
@@ -473,6 +474,10 @@ void gemm_auto(svg_ctx* ctx, GemmArgs g, hipStream_t s, int prof_kind) {
   if (blocks < 192 && KT >= 8) {
     sk = (int)std::min<int64_t>((384 + blocks - 1) / blocks, KT / 4);
     sk = std::max(1, std::min(sk, 16));
+  } else if (blocks < 300 && KT >= 64) {
+    // about one workgroup (4 waves) per CU and a long K: a single wave per SIMD cannot hide its own load phases, so
+    // split in two for two co-resident workgroups (same-box A/B at 16 x 16 x 1280 convs: 0.149 -> 0.122 ms)
+    sk = 2;
   }
   g.splitk = sk;
   if (sk > 1) {
