@@ -380,6 +380,8 @@ void launch_bn(const GemmArgs& g, dim3 grid, hipStream_t s) {
 }
 
 int pick_bn(const GemmArgs& g) {
+  static const int force = getenv("SVG_GEMM_BN") ? atoi(getenv("SVG_GEMM_BN")) : 0;
+  if (force && g.act != ACT_GEGLU && g.N > 64) return force;
   if (g.act == ACT_GEGLU) return 128;
   if (g.N <= 32) return 32;
   if (g.N <= 64) return 64;

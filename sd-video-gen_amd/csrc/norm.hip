@@ -1,6 +1,7 @@
 // GroupNorm (+SiLU) on NHWC bf16, LayerNorm over rows, row softmax.  HBM-bound: 16-B vector
 // loads/stores, f32 statistics, wave-shuffle reductions.
 #include "kernels.h"
+#include <cstdlib>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -124,6 +125,59 @@ __global__ void gn_apply_kernel(const bf16* __restrict__ x, int C1, const bf16* 
   }
 }
 
+// ---- GroupNorm for small images (one launch, one read): a workgroup owns one (sample, group) — HW x cpg values that
+// fit its registers (<= 256 x 80 here: the 16 x 16 and 8 x 8 UNet levels, where the two-stage pair above is all launch
+// latency: 22-27 us for 2.6-10 MB).  Values are fetched as 8-byte (4-channel) pieces, so a group may straddle the two
+// sources of a virtual concat.  Deterministic: fixed per-thread order, shuffle + LDS tree.
+typedef __bf16 bf16x4n __attribute__((ext_vector_type(4)));
+template <int MAXCH>
+__global__ void __launch_bounds__(256) gn_small_kernel(const bf16* __restrict__ x, int C1, const bf16* __restrict__ x2, int C2,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       bf16* __restrict__ out, int HW, int groups, float eps, int silu) {
+  __shared__ float red[8];
+  const int C = C1 + C2, cpg = C / groups, nch = cpg >> 2, total = HW * nch;
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  bf16x4n v[MAXCH];
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int id = tid + 256 * i;
+    if (id < total) {
+      const int p = id / nch, c = g * cpg + ((id - p * nch) << 2);
+      const bf16* src = (c < C1) ? x + ((int64_t)b * HW + p) * C1 + c : x2 + ((int64_t)b * HW + p) * C2 + (c - C1);
+      v[i] = *(const bf16x4n*)src;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float f = (float)v[i][j]; s += f; q += f * f; }
+    }
+  }
+  s = wave_sum(s); q = wave_sum(q);
+  if ((tid & 63) == 0) { red[(tid >> 6) * 2] = s; red[(tid >> 6) * 2 + 1] = q; }
+  __syncthreads();
+  s = (red[0] + red[2]) + (red[4] + red[6]);
+  q = (red[1] + red[3]) + (red[5] + red[7]);
+  const float n = (float)cpg * (float)HW;
+  const float mean = s / n;
+  const float rstd = rsqrtf(fmaxf(q / n - mean * mean, 0.f) + eps);
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int id = tid + 256 * i;
+    if (id < total) {
+      const int p = id / nch, c = g * cpg + ((id - p * nch) << 2);
+      const float4 ga = *(const float4*)(gamma + c), be = *(const float4*)(beta + c);
+      const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
+      bf16x4n o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = rstd * gg[j];
+        float f = fmaf((float)v[i][j], a, bb[j] - mean * a);
+        if (silu) f = f * __builtin_amdgcn_rcpf(1.f + __expf(-f));
+        o[j] = (bf16)f;
+      }
+      *(bf16x4n*)(out + ((int64_t)b * HW + p) * C + c) = o;
+    }
+  }
+}
+
 // ---- LayerNorm: one wave per row -------------------------------------------------------------------
 __global__ void __launch_bounds__(256) layernorm_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
                                  const float* __restrict__ beta, bf16* __restrict__ out, int M, int C, float eps) {
@@ -201,6 +255,20 @@ void groupnorm(svg_ctx* ctx, const bf16* x, int C1, const bf16* x2, int C2, cons
   SVG_CHECK(C % groups == 0 && C % 8 == 0 && C1 % 8 == 0 && groups <= 64, "groupnorm: C=%d groups=%d unsupported", C, groups);
   const int CV = C / 8;
   SVG_CHECK(CV <= 1024, "groupnorm: C too large");
+  {
+    const int cpg = C / groups;
+    static const int no_small = getenv("SVG_GN_NOSMALL") ? atoi(getenv("SVG_GN_NOSMALL")) : 0;
+    if (!no_small && HW <= 256 && cpg % 4 == 0 && C1 % 4 == 0 && (int64_t)HW * (cpg / 4) <= 256 * 20) {
+      if (!SVG_LAUNCHING(ctx)) return;
+      ProfScope ps(ctx, PK_GNORM, s, 0, 2.0 * B * HW * C * 2);
+      if ((int64_t)HW * (cpg / 4) <= 256 * 5)
+        hipLaunchKernelGGL(gn_small_kernel<5>, dim3(groups, B), dim3(256), 0, s, x, C1, x2, C2, gamma, beta, out, HW, groups, eps, silu);
+      else
+        hipLaunchKernelGGL(gn_small_kernel<20>, dim3(groups, B), dim3(256), 0, s, x, C1, x2, C2, gamma, beta, out, HW, groups, eps, silu);
+      check_launch("gn_small");
+      return;
+    }
+  }
   const int PL = std::max(1, 256 / CV);
   int nchunk = std::max(1, std::min(64, HW / (PL * 8)));
   // enough blocks to fill the chip at small batch

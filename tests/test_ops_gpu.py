@@ -143,7 +143,7 @@ def test_conv3x3_integer_exact(ctx):
 
 
 @pytest.mark.parametrize("B,HW,C,silu", [(2, 64, 64, 1), (1, 4096, 320, 1), (3, 256, 1280, 0), (2, 1024, 960, 1),
-                                         (1, 64, 2560, 1), (2, 4096, 128, 0), (1, 100, 1920, 1)])
+                                         (1, 64, 2560, 1), (2, 4096, 128, 0), (1, 100, 1920, 1), (2, 256, 2560, 1), (16, 64, 1280, 1)])
 def test_groupnorm(ctx, B, HW, C, silu):
     g = torch.Generator(device="cuda").manual_seed(C + HW)
     x = bf(torch.randn(B, HW, C, device="cuda", generator=g) * 2 + 0.5)
