@@ -31,7 +31,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=2)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--clips", type=int, default=32, help="clips sampled in lock step per GPU")
+    p.add_argument("--clips", type=int, default=56, help="clips sampled in lock step per GPU")
     p.add_argument("--streams", type=int, default=2, help="concurrent clip groups per GPU (own context + stream each)")
     p.add_argument("--pred_frames", type=int, default=1)
     p.add_argument("--start_step", type=int, default=0)

@@ -27,7 +27,13 @@ namespace {
 constexpr int KVT = 64;     // keys per tile
 constexpr int VROW = 136;   // bytes per V^T LDS row (64 kv * 2 B + 8)
 
-template <int D, int QB, int NSTW>  // head dim (multiple of 8); 32-query blocks per wave; LDS stages wanted
+// BC ("bias column", needs >= 3 spare columns in the padded contraction, i.e. d = 40 or 8): the softmax runs VALU-bound
+// (per tile and query block: 32 exp2 + 32 fma + ~25 max + 16 cvt against 14 MFMAs), so the scale-and-shift fma is moved
+// onto the matrix pipe: Q is pre-multiplied by scale*log2(e), the K pad columns d..d+2 hold 1.0 and the matching Q pad
+// elements hold -m (running shift) split into three bf16 pieces (24 bits, exact in the f32 accumulate), so the MFMA
+// delivers S*c - m ready for exp2.  The shift is lazy: it moves only when a score exceeds it by more than 2^TAU (first
+// tile: always), which is exact for the result (softmax is shift invariant; P keeps bf16's relative precision).
+template <int D, int QB, int NSTW, bool BC>  // head dim (multiple of 8); 32-query blocks per wave; LDS stages wanted
 __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
   constexpr int KS = (D + 15) / 16;           // k-steps of the QK^T contraction
   constexpr int DK = KS * 16;
@@ -57,6 +63,8 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
   const bf16* __restrict__ Vt = a.vt + (int64_t)b * a.vtb + (int64_t)head * D * a.ldvt;
 
   // ---- Q^T fragments (B operand): lane (r,h) holds Q[q0+r][16ks + 8h .. +7] -------------------
+  static_assert(!BC || (DK - D >= 3 && (D % 16) == 8), "bias-column form needs the pad columns in lane-half 1 of the last k-step");
+  const float c = a.scale * 1.4426950408889634f;   // exp(x*scale) = exp2(x*c)
   bf16x8 qf[QB][KS];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
@@ -67,6 +75,10 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
       uint4 v = make_uint4(0, 0, 0, 0);
       if (q < a.Sq && col < D) v = *(const uint4*)(Q + (int64_t)q * a.ldq + col);
       qf[qb][ks] = *(bf16x8*)&v;
+      if (BC) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[qb][ks][j] = (bf16)((float)qf[qb][ks][j] * c);
+      }
     }
   }
 
@@ -85,7 +97,8 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
   for (int st = 0; st < NST; ++st) {
     char* const sK = smem + st * STAGE;
     char* const sV = sK + K_BYTES;
-    if (CPR * 8 < DK && tid < KVT) *(uint4*)(sK + tid * KROW + CPR * 16) = make_uint4(0, 0, 0, 0);
+    if (CPR * 8 < DK && tid < KVT)   // BC: columns d, d+1, d+2 = 1.0 (they multiply the three pieces of -m in Q)
+      *(uint4*)(sK + tid * KROW + CPR * 16) = BC ? make_uint4(0x3F803F80u, 0x00003F80u, 0, 0) : make_uint4(0, 0, 0, 0);
     if (ONES && tid < 16) *(uint2*)(sV + D * VROW + tid * 8) = make_uint2(0x3F803F80u, 0x3F803F80u);
   }
 
@@ -118,14 +131,14 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
 
   f32x16 O[QB][DVT];
   float m_run[QB], l_run[QB], mc[QB];
-  const float c = a.scale * 1.4426950408889634f;   // exp(x*scale) = exp2(x*c)
+  constexpr float TAU = 6.f;
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
     for (int i = 0; i < DVT; ++i)
 #pragma unroll
       for (int j = 0; j < 16; ++j) O[qb][i][j] = 0.f;
-    m_run[qb] = -1e30f; l_run[qb] = 0.f; mc[qb] = m_run[qb] * c;
+    m_run[qb] = BC ? 0.f : -1e30f; l_run[qb] = 0.f; mc[qb] = m_run[qb] * c;   // BC: m_run is the shift in the exp2 domain
   }
 
   const int ntiles = (a.Skv + KVT - 1) / KVT;
@@ -178,6 +191,41 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
     }
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) mx[qb] = fmaxf(mx[qb], __shfl_xor(mx[qb], 32));
+    if (BC) {
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        if (t == 0 || __any(mx[qb] > TAU)) {   // wave-uniform and rare: move the shift of the columns that need it
+          const float delta = (t == 0 || mx[qb] > 0.f) ? mx[qb] : 0.f;
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+          m_run[qb] += delta;
+          if (!ONES) l_run[qb] *= alpha;
+#pragma unroll
+          for (int i = 0; i < DVT; ++i)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) O[qb][i][j] *= alpha;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) { S0[qb][j] -= delta; S1[qb][j] -= delta; }
+          // -m as three bf16 pieces in Q columns d, d+1, d+2 (held by lane-half 1 of the last k-step)
+          const float v0 = -m_run[qb];
+          const bf16 p1 = (bf16)v0;
+          const float r1 = v0 - (float)p1;
+          const bf16 p2 = (bf16)r1;
+          const bf16 p3 = (bf16)(r1 - (float)p2);
+          if (h == 1) { qf[qb][KS - 1][0] = p1; qf[qb][KS - 1][1] = p2; qf[qb][KS - 1][2] = p3; }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          S0[qb][j] = __builtin_amdgcn_exp2f(S0[qb][j]);
+          S1[qb][j] = __builtin_amdgcn_exp2f(S1[qb][j]);
+        }
+        if (!ONES) {
+          float psum = 0.f;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) psum += S0[qb][j] + S1[qb][j];
+          l_run[qb] += psum;
+        }
+      }
+    } else {
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       if (__any(mx[qb] > m_run[qb])) {   // wave-uniform: some column's running max grows -> rescale what is accumulated
@@ -205,6 +253,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
         for (int j = 0; j < 16; ++j) psum += S0[qb][j] + S1[qb][j];
         l_run[qb] += psum;
       }
+    }
     }
 
     // ---- O^T += V^T_tile * P^T (V^T fragments shared by the QB query blocks) -----------------------------
@@ -273,15 +322,19 @@ void launch(const AttnArgs& a, hipStream_t s) {
   // 0.67 vs 0.73 ms at 16 x 8 x 4096^2 x 40.  SVG_ATTN_QB=1 forces the single-block form.
   static const int nst_env = getenv("SVG_ATTN_NST") ? atoi(getenv("SVG_ATTN_NST")) : 1;   // same-box A/B: one stage + two barriers is 1-2 % faster than two stages + one barrier
   static const int qb_env = getenv("SVG_ATTN_QB") ? atoi(getenv("SVG_ATTN_QB")) : 2;
+  static const int bc_env = getenv("SVG_ATTN_BC") ? atoi(getenv("SVG_ATTN_BC")) : 1;
   constexpr int QB = (D <= 64) ? 2 : 1;
+  constexpr bool CAN_BC = (D % 16) == 8;        // three spare pad columns in lane-half 1 of the last k-step (d = 8, 40)
   if (QB == 2 && qb_env == 2 && a.Sq >= 512) {
     dim3 grid(cdiv(a.Sq, 256), a.heads, a.B);
-    if (nst_env == 2) hipLaunchKernelGGL((attn_kernel<D, QB, 2>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((attn_kernel<D, QB, 1>), grid, dim3(256), 0, s, a);
+    if (CAN_BC && bc_env) hipLaunchKernelGGL((attn_kernel<D, QB, 1, CAN_BC>), grid, dim3(256), 0, s, a);
+    else if (nst_env == 2) hipLaunchKernelGGL((attn_kernel<D, QB, 2, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_kernel<D, QB, 1, false>), grid, dim3(256), 0, s, a);
   } else {
     dim3 grid(cdiv(a.Sq, 128), a.heads, a.B);
-    if (nst_env == 2) hipLaunchKernelGGL((attn_kernel<D, 1, 2>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((attn_kernel<D, 1, 1>), grid, dim3(256), 0, s, a);
+    if (CAN_BC && bc_env) hipLaunchKernelGGL((attn_kernel<D, 1, 1, CAN_BC>), grid, dim3(256), 0, s, a);
+    else if (nst_env == 2) hipLaunchKernelGGL((attn_kernel<D, 1, 2, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_kernel<D, 1, 1, false>), grid, dim3(256), 0, s, a);
   }
 }
 

@@ -218,6 +218,22 @@ def test_attention_online_rescale(ctx):
     assert rel_l2(out.float(), attention_ref(q, k, v, heads)) < 8e-3
 
 
+def test_attention_large_logits_and_shift_precision(ctx):
+    """d = 40 path carries the running shift -m on the matrix pipe as three bf16 pieces: large logits (|s*scale| up to
+    ~60, shifts far from any bf16 grid point), a first tile whose scores are all very negative, and a late spike."""
+    B, heads, S, d = 2, 2, 1024, 40
+    g = torch.Generator(device="cuda").manual_seed(9)
+    q = bf(torch.randn(B, S, heads * d, device="cuda", generator=g) * 3.0)
+    k = bf(torch.randn(B, S, heads * d, device="cuda", generator=g) * 1.7)
+    v = bf(torch.randn(B, S, heads * d, device="cuda", generator=g))
+    k[:, :64] = -q[:, :64] * 0.9          # tile 0: strongly negative scores for the matching queries
+    k[0, 900, :d] = q[0, 5, :d] * 2.5     # late spike
+    out = run_attention(ctx, q, k, v, heads, S)
+    ref = attention_ref(q, k, v, heads)
+    assert torch.isfinite(out.float()).all()
+    assert rel_l2(out.float(), ref) < 8e-3
+
+
 @pytest.mark.parametrize("M,N,K,relu", [(6, 2048, 256, 0), (5, 6144, 2048, 0), (48, 2048, 2048, 1), (1, 256, 2048, 0),
                                         (64, 96, 32, 0), (17, 1024, 2048, 1), (6, 32, 256, 0)])
 def test_xf_gemm(ctx, M, N, K, relu):
