@@ -16,26 +16,6 @@
 
 namespace {
 
-typedef int v4i __attribute__((ext_vector_type(4)));
-
-// LDS-direct 16-byte buffer load issued from inline asm: hipcc's waitcnt pass does not see it, so it cannot add its own
-// conservative vmcnt(0) in front of the fragment reads (it does for the builtin form here: the stage index is dynamic) —
-// every wait for these DMAs is one of the explicit counted s_waitcnt below.  M0 (LDS base of the wave's 1-KiB piece) is
-// written in the same statement that uses it and restored afterwards.
-__device__ __forceinline__ void dma16(v4i srd, unsigned voff, int soff, unsigned lds_addr) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff), "s"(srd), "s"(soff), "s"(lds_addr)
-               : "memory");
-}
-
-// LDS rows are 128 B; 16-byte chunk c of row r sits at chunk c ^ (r & 7).  For a ds_read_b128 lane group (rows l = 0-3
-// and 12-15 at chunk c0, rows 4-11 at chunk c0+1) over ANY 16 consecutive rows this is conflict free: rows r and r+8 share
-// a key but sit in different chunk classes, and keys of equal parity never differ by exactly 1.  (gemm.hip's (r>>1)&7 key
-// needs 16-aligned windows; the tap-shifted patch reads here start anywhere: it measured 25 % conflict cycles.)
-__device__ __forceinline__ int lds_off7(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
-
 // compile-time ablation switch for tools/abl_halo.sh (-DHALO_ABL=n): 1 no stores, 2 no MFMA, 3 no DMA, 4 no fragment reads, 6 no barrier
 #ifndef HALO_ABL
 #define HALO_ABL 0
@@ -44,24 +24,6 @@ constexpr int ABL = HALO_ABL;
 constexpr int PW = 18;                 // patch width / height in pixels
 constexpr int PPIX = PW * PW;          // 324
 constexpr int NPD = 6;                 // patch DMA instructions per wave: 8 waves * 64 lanes * 6 = 3072 >= 324 * 8 chunks
-
-// wave-uniform counted wait (the count has to be an immediate)
-__device__ __forceinline__ void wait_vm(int n) {
-  switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-  }
-}
-// raw barrier that the compiler may not move LDS accesses across
-__device__ __forceinline__ void bar() {
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
 
 // PP = ping-pong schedule: the 8 waves run as two groups of four (one wave of each group per SIMD) staggered by one
 // barrier, so that while one group multiplies (20 MFMAs between two barriers, s_setprio 1) the other issues its fragment

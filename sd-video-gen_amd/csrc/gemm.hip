@@ -20,6 +20,8 @@
 bool conv_halo_supported(const GemmArgs& g);
 int conv_halo_bn(const GemmArgs& g);
 void launch_conv_halo(const GemmArgs& g, dim3 grid, hipStream_t s);
+bool gemm_pp_supported(const GemmArgs& g);
+void launch_gemm_pp(const GemmArgs& g, hipStream_t s);
 
 namespace {
 
@@ -429,6 +431,8 @@ void launch_gemm(svg_ctx* ctx, const GemmArgs& g, hipStream_t s, int prof_kind) 
     // 16 x 16 pixel blocks x channel tiles; splitk partitions the 64-channel chunks
     const int blocks = (a.M / 256) * cdiv(a.N, conv_halo_bn(a));
     launch_conv_halo(a, dim3(blocks, 1, a.splitk), s);
+  } else if (gemm_pp_supported(a)) {
+    launch_gemm_pp(a, s);
   } else {
     const int bn = pick_bn(a);
     const int tiles = cdiv(a.M, BM) * cdiv(a.N, bn);
@@ -469,6 +473,7 @@ void gemm_auto(svg_ctx* ctx, GemmArgs g, hipStream_t s, int prof_kind) {
     }
     return;
   }
+  if (gemm_pp_supported(g)) { launch_gemm(ctx, g, s, prof_kind); return; }
   const int bn = pick_bn(g);
   const int64_t blocks = (int64_t)cdiv(g.M, BM) * cdiv(g.N, bn) * g.batch;
   const int KT = cdiv(g.K, BK);

@@ -1,0 +1,219 @@
+// Dense NT GEMM for gfx950 with the ping-pong schedule of conv_halo.hip: C[M,N] = A[M,K] * W[N,K]^T (+ epilogue).
+//
+// gemm.hip's 128 x 160 tile with two 4-wave workgroups per CU moves (128 + 160) x 128 B per 640 matrix-pipe cycles
+// through L2 -> LDS — 58 B/clk/CU, the whole L2 rate — and every K step ends in vmcnt(0) + barrier, so it tops out near
+// 0.65-0.85 PFLOP/s.  Here one 8-wave workgroup per CU owns a 256 x BN tile (42 B/clk at BN = 160), operand slabs
+// (64 of K) stream through THREE LDS stages with counted vmcnt, and the two wave groups alternate: while waves 0-3
+// multiply (20 MFMAs between two barriers) waves 4-7 issue the next phase's fragment reads and their share of the DMAs.
+// Used for long K (>= 16 slabs), where the unhidden prologue / epilogue of a tile (one workgroup per CU: nothing else
+// on the CU covers them) is small; short K stays with gemm.hip.
+//   waves 4 (M) x 2 (N); wave tile 64 x BN/2; v_mfma_f32_16x16x32_bf16 with the W fragment as the A operand.
+//   LDS rows are 128 B, chunk c of row r at c ^ (r & 7) (swizzle applied on the DMA source side).
+#include "igemm_epi.h"
+#include <cstdlib>
+
+namespace {
+
+template <int BN>
+__global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs g) {
+  constexpr int NT = BN / 32;            // 16-wide n tiles per wave
+  constexpr int MT = 4;                  // 16-high m tiles per wave
+  constexpr int BMP = 256;
+  constexpr int A_BYTES = BMP * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int NWS = 3;
+  constexpr int NA = 4;                  // A DMA instructions per wave and slab (64 rows each across the 8 waves)
+  constexpr int BIT = BN / 64;
+  constexpr bool B_TAIL = (BN % 64) != 0;
+  constexpr int NB = BIT + (B_TAIL ? 1 : 0);
+  constexpr int NW = NA + NB;            // DMA instructions per wave and slab
+  constexpr int OFF_SINK = NWS * STAGE;  // 1 KiB sink for the padding DMAs of the ragged B group
+  constexpr unsigned INVALID = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wid);
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  const int tiles_n = (g.N + BN - 1) / BN;
+  int tile;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * BMP, n0 = tn * BN;
+  const int KT = g.K >> 6;
+
+  const unsigned a_bytes = (unsigned)(((int64_t)(g.M - 1) * g.lda + g.K) * 2);
+  const unsigned b_bytes = (unsigned)(((int64_t)(g.n_valid - 1) * g.ldb + g.K) * 2);
+  const uint64_t pa = (uint64_t)g.A, pw = (uint64_t)g.Wt;
+  const v4i srdA = {(int)(unsigned)pa, (int)((pa >> 32) & 0xffff), (int)a_bytes, 0x00020000};
+  const v4i srdB = {(int)(unsigned)pw, (int)((pw >> 32) & 0xffff), (int)b_bytes, 0x00020000};
+  const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+
+  // DMA maps: a wave instruction fills 8 LDS rows (64 lanes x 16 B); lane (r0, p) fetches logical chunk p ^ (r0 & 7).
+  // Rows past M / n_valid fall outside the descriptor's range and read as zeros.
+  const int r0 = tid >> 3;                                   // 0..63
+  const int cs = (tid & 7) ^ (r0 & 7);
+  const unsigned a_voff0 = (unsigned)((m0 + r0) * g.lda + cs * 8) * 2u;
+  const unsigned a_step = (unsigned)(64 * g.lda) * 2u;
+  const unsigned b_voff0 = (unsigned)((n0 + r0) * g.ldb + cs * 8) * 2u;
+  const unsigned b_step = (unsigned)(64 * g.ldb) * 2u;
+  // (a row offset past the range stays past it: offsets are < 2^31 by the host-side checks, INVALID is 2^31)
+  auto dma_part = [&](int kt, int stage, int i0, int i1) {   // instructions [i0, i1) of the slab's NW
+    const unsigned dst = lds0 + stage * STAGE + wave_u * 1024;
+    const int soff = kt * 128;
+#pragma unroll
+    for (int i = i0; i < i1; ++i) {
+      if (i < NA) {
+        const int m = m0 + r0 + 64 * i;
+        dma16(srdA, m < g.M ? a_voff0 + i * a_step : INVALID, soff, dst + i * 8192);
+      } else {
+        const int ib = i - NA;
+        const int n = n0 + r0 + 64 * ib;
+        if (ib < BIT) dma16(srdB, n < g.n_valid ? b_voff0 + ib * b_step : INVALID, soff, dst + A_BYTES + ib * 8192);
+        else dma16(srdB, (r0 < 32 && n < g.n_valid) ? b_voff0 + ib * b_step : INVALID, soff,
+                   (wave_u < 4) ? (dst + A_BYTES + BIT * 8192) : (lds0 + OFF_SINK));
+      }
+    }
+  };
+
+  // fragment addresses: the swizzle key of every row a lane reads is l15 & 7 (tile offsets are multiples of 8)
+  int xaddr[2], waddr[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int sw = ((kk * 4 + lq) ^ (l15 & 7)) << 4;
+    xaddr[kk] = (wm * 64 + l15) * 128 + sw;
+    waddr[kk] = A_BYTES + (wn * (BN / 2) + l15) * 128 + sw;
+  }
+  auto rd = [&](int stage, int kk, bf16x8 (&xf)[MT], bf16x8 (&wf)[NT]) {
+    const char* sx = smem + stage * STAGE + xaddr[kk];
+    const char* sw = smem + stage * STAGE + waddr[kk];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) xf[i] = *(const bf16x8*)(sx + i * 2048);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wf[j] = *(const bf16x8*)(sw + j * 2048);
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mma_phase = [&](const bf16x8 (&xf)[MT], const bf16x8 (&wf)[NT]) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+
+  // ---- main loop: same phase structure, RAW / WAR argument and vmcnt accounting as conv_halo.hip's ping-pong loop:
+  // step s (slab s, stage s % 3) = phase 0 [reads of its second k half; first NA DMAs of slab s+2; wait until only those
+  // are in flight -> slab s+1 landed] + phase 1 [reads of the first k half of slab s+1; the other DMAs of slab s+2].
+  {
+    const int grp = wave_u >> 2;
+    dma_part(0, 0, 0, NW);
+    dma_part(1, 1, 0, NW);
+    wait_vm(NW);                              // NW <= 7: slab 0 landed, slab 1 may be in flight
+    bar();
+    if (grp == 1) bar();
+    bf16x8 xa[MT], wa[NT], xb[MT], wb[NT];
+    rd(0, 0, xa, wa);
+    int st = 0;                               // stage of slab s
+    for (int s = 0; s < KT; ++s) {
+      const bool more = s + 2 < KT;
+      const int st2 = st == 0 ? 2 : st - 1;   // (s + 2) % 3
+      const int st1 = st == 2 ? 0 : st + 1;   // (s + 1) % 3
+      rd(st, 1, xb, wb);
+      if (more) dma_part(s + 2, st2, 0, NA);
+      wait_vm(more ? NA : 0);
+      bar();
+      mma_phase(xa, wa);
+      bar();
+      if (s + 1 < KT) rd(st1, 0, xa, wa);
+      if (more) dma_part(s + 2, st2, NA, NW);
+      bar();
+      mma_phase(xb, wb);
+      bar();
+      st = st1;
+    }
+    if (grp == 0) bar();
+  }
+
+  // ---- epilogue (as gemm.hip's direct form) ------------------------------------------------------------------------
+  const bool geglu = g.act == ACT_GEGLU;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + l15;
+    if (m >= g.M) continue;
+    if (geglu) {
+      if constexpr ((NT & 1) == 0) {
+#pragma unroll
+        for (int j = 0; j < NT; j += 2) {
+          const int nh = n0 + wn * (BN / 2) + j * 16 + lq * 4;
+          if (nh >= g.N) continue;
+          const int cl = wn * (BN / 4) + (j >> 1) * 16 + lq * 4;
+          const f32x4 v = geglu_value(g, nh, acc[i][j] * g.alpha, acc[i][j + 1] * g.alpha);
+          *(bf16x4*)((bf16*)g.C + (int64_t)m * g.ldc + (n0 >> 1) + cl) = to_bf16x4(v);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 16 + lq * 4;
+        if (n >= g.N) continue;
+        epi_store(g, 0, m, n, acc[i][j] * g.alpha);
+      }
+    }
+  }
+}
+
+template <int BN>
+void launch_pp(const GemmArgs& g, hipStream_t s) {
+  constexpr int smem = 3 * (256 * 128 + BN * 128) + 1024;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_OK(hipFuncSetAttribute((const void*)gemm_pp_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  const int tiles = cdiv(g.M, 256) * cdiv(g.N, BN);
+  hipLaunchKernelGGL((gemm_pp_kernel<BN>), dim3(tiles), dim3(512), smem, s, g);
+}
+
+}  // namespace
+
+int gemm_pp_bn(const GemmArgs& g) {
+  if (g.act == ACT_GEGLU) return 128;
+  // fewest serial rounds of workgroups (one per CU) x tile width; ties -> fewer padded columns
+  const int64_t tm = cdiv(g.M, 256);
+  int best = 128;
+  int64_t best_cost = -1, best_pad = 0;
+  for (int bn : {128, 160}) {
+    const int64_t tn = cdiv(g.N, bn);
+    const int64_t cost = ((tm * tn + 255) / 256) * bn, pad = tn * bn - g.N;
+    if (best_cost < 0 || cost < best_cost || (cost == best_cost && pad < best_pad)) { best = bn; best_cost = cost; best_pad = pad; }
+  }
+  return best;
+}
+
+// dense, unbatched, K a multiple of 64 and long enough, enough 256-row tiles to give every CU a workgroup
+bool gemm_pp_supported(const GemmArgs& g) {
+  static const int on = getenv("SVG_GEMM_PP") ? atoi(getenv("SVG_GEMM_PP")) : 1;
+  static const int min_kt = getenv("SVG_GEMM_PP_MINKT") ? atoi(getenv("SVG_GEMM_PP_MINKT")) : 16;
+  if (!on || g.amode != A_DENSE || g.batch != 1 || g.splitk > 1 || g.out_f32 || (g.K & 63) != 0 || (g.K >> 6) < min_kt) return false;
+  if (g.lda % 8 != 0 || g.ldb % 8 != 0 || g.bias_row) return false;
+  return (int64_t)cdiv(g.M, 256) * cdiv(g.N, gemm_pp_bn(g)) >= 192;
+}
+
+void launch_gemm_pp(const GemmArgs& g, hipStream_t s) {
+  if (gemm_pp_bn(g) == 160) launch_pp<160>(g, s);
+  else launch_pp<128>(g, s);
+}

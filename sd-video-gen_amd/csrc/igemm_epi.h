@@ -79,4 +79,45 @@ __device__ __forceinline__ f32x4 geglu_value(const GemmArgs& g, int nh, f32x4 h,
   return v;
 }
 
+// ---- helpers of the LDS-DMA pipelines (conv_halo.hip, gemm_pp.hip) ----------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// LDS-direct 16-byte buffer load issued from inline asm: hipcc's waitcnt pass does not see it, so it cannot add its own
+// conservative vmcnt(0) in front of the fragment reads (it does for the builtin form here: the stage index is dynamic) —
+// every wait for these DMAs is one of the explicit counted s_waitcnt below.  M0 (LDS base of the wave's 1-KiB piece) is
+// written in the same statement that uses it and restored afterwards.
+__device__ __forceinline__ void dma16(v4i srd, unsigned voff, int soff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(srd), "s"(soff), "s"(lds_addr)
+               : "memory");
+}
+
+// LDS rows are 128 B; 16-byte chunk c of row r sits at chunk c ^ (r & 7).  For a ds_read_b128 lane group (rows l = 0-3
+// and 12-15 at chunk c0, rows 4-11 at chunk c0+1) over ANY 16 consecutive rows this is conflict free: rows r and r+8 share
+// a key but sit in different chunk classes, and keys of equal parity never differ by exactly 1.  (gemm.hip's (r>>1)&7 key
+// needs 16-aligned windows; the tap-shifted patch reads here start anywhere: it measured 25 % conflict cycles.)
+__device__ __forceinline__ int lds_off7(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+// wave-uniform counted wait (the count has to be an immediate)
+__device__ __forceinline__ void wait_vm(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+  }
+}
+// raw barrier that the compiler may not move LDS accesses across
+__device__ __forceinline__ void bar() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 }  // namespace

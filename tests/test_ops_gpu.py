@@ -48,6 +48,40 @@ def test_gemm_bias_residual(ctx, M, N, K):
     assert rel_l2(out32, A.float() @ W.float().t() + b) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K,act", [(65536, 320, 1280, 0), (50000, 324, 512, 0), (16384, 640, 2560, 1), (4100, 5120, 640, 3),
+                                        (12300, 1280, 1280, 0), (49152, 128, 768, 2)])
+def test_gemm_pingpong_kernel(ctx, M, N, K, act):
+    """long-K problems with >= 192 tiles of 256 rows go to gemm_pp.hip: ragged M and N, bias + residual, activations, GEGLU."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, device="cuda", generator=g))
+    W = bf(torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K))
+    b = torch.randn(N, device="cuda", generator=g)
+    pre = A.float() @ W.float().t() + b
+    if act == 3:
+        out = torch.empty(M, N // 2, device="cuda", dtype=torch.bfloat16)
+        ctx.check(ctx.lib.svg_op_gemm(ctx.h, u16(A), u16(W), b.data_ptr(), None, out.data_ptr(), M, N, K, 3, 0, stream()), "geglu")
+        h, gate = pre.chunk(2, dim=-1)
+        ref = h * F.gelu(gate)
+    else:
+        R = bf(torch.randn(M, N, device="cuda", generator=g))
+        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        ctx.check(ctx.lib.svg_op_gemm(ctx.h, u16(A), u16(W), b.data_ptr(), u16(R), out.data_ptr(), M, N, K, act, 0, stream()), "gemm")
+        pre = pre + R.float()      # epilogue order: bias, residual, activation
+        ref = F.silu(pre) if act == 1 else (F.gelu(pre) if act == 2 else pre)
+    assert rel_l2(out.float(), ref) < BF16_TOL
+
+
+def test_gemm_pingpong_integer_exact(ctx):
+    """integer operands through gemm_pp.hip: every slab, stage and tile seam bit for bit (ragged M / N, K = 9 slabs)."""
+    M, N, K = 49000, 324, 576
+    g = torch.Generator(device="cuda").manual_seed(11)
+    A = bf(torch.randint(-2, 3, (M, K), device="cuda", generator=g).float())
+    W = bf(torch.randint(-2, 3, (N, K), device="cuda", generator=g).float())
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ctx.check(ctx.lib.svg_op_gemm(ctx.h, u16(A), u16(W), None, None, out.data_ptr(), M, N, K, 0, 0, stream()), "gemm")
+    assert torch.equal(out.float(), (A.float() @ W.float().t()).to(torch.bfloat16).float())
+
+
 def test_gemm_integer_exact(ctx):
     """small-integer operands: every product and partial sum is exact in f32 -> bit-exact result;
     asymmetric W so a row/col swap in the C write cannot hide (guide: A=I check with asymmetric B)."""
