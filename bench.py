@@ -224,6 +224,16 @@ def main():
                                 "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": ach / (PEAK_BF16 / 1e12),
                                 "traffic": None, "launches": dom["calls"], "avg_launch_ms": dom["ms"] / dom["calls"],
                                 "algorithmic_flop_per_launch": dom["flops"] / dom["calls"]}
+            line["roofline"]["algorithmic_bytes_per_launch"] = dom["bytes"] / dom["calls"]
+            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_summary.json")
+            if os.path.exists(pmc):
+                # HBM bytes per launch of the same family from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, collected
+                # offline with rocprofv3 on one 28-clip group: counters cannot be read from inside this process)
+                with open(pmc) as f:
+                    fam_pmc = json.load(f)["families"].get("conv3x3")
+                if fam_pmc and fam_pmc["launches"] == dom["calls"]:
+                    line["roofline"]["traffic"] = fam_pmc["hbm_bytes_per_launch"] * (max(1, C // args.streams) / 28.0)
+                    line["roofline"]["traffic_source"] = "profiles/r01_pmc_summary.json (28-clip group, scaled by clips per group)"
             tot_ms = sum(v["ms"] for v in rep.values())
             line["roofline"]["whole_frame_frac_of_mfma_peak"] = FRAME_FLOP * max(1, C // args.streams) * args.pred_frames / (tot_ms * 1e-3) / PEAK_BF16
             line["roofline"]["instrumented_pass"] = "one stream group (%d clips) run alone with hipEvent brackets around every launch" % max(1, C // args.streams)

@@ -425,8 +425,10 @@ void launch_gemm(svg_ctx* ctx, const GemmArgs& g, hipStream_t s, int prof_kind) 
   a.dbg = dbg_env;
   if (a.splitk < 1) a.splitk = 1;
   if (a.n_valid <= 0) a.n_valid = a.N;
+  // algorithmic bytes: every operand once (a conv reads its image once, not once per tap)
+  const double a_elems = g.amode == A_DENSE ? (double)g.M * g.K : (double)(g.M / (g.Ho * g.Wo)) * g.H * g.W * g.Cin;
   ProfScope ps(ctx, prof_kind, s, 2.0 * g.M * (double)g.N * g.K * g.batch,
-               2.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N) * g.batch);
+               2.0 * (a_elems + (double)g.N * g.K + (double)g.M * g.N) * g.batch);
   if (conv_halo_supported(a)) {
     // 16 x 16 pixel blocks x channel tiles; splitk partitions the 64-channel chunks
     const int blocks = (a.M / 256) * cdiv(a.N, conv_halo_bn(a));
