@@ -348,20 +348,18 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
 
   // ---- epilogue -----------------------------------------------------------------------------------------------
   if (ABL == 1 && acc[0][0][0] != 12345.f) return;
+  const int mr = (b * g.H + y0 + wm * 4) * g.W + x0 + l15;      // image row i of the wave adds i * W
+  const int nc = n0 + wn * (BN / 2) + lq * 4;
+  if (g.splitk > 1) {
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int m = (b * g.H + y0 + wm * 4 + i) * g.W + x0 + l15;
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + wn * (BN / 2) + j * 16 + lq * 4;
-      if (n >= g.N) continue;
-      if (g.splitk > 1) {
-        float* sl = g.slabs + ((int64_t)ks * g.M + m) * g.N + n;
-        *(f32x4*)sl = acc[i][j];
-      } else {
-        epi_store(g, 0, m, n, acc[i][j] * g.alpha);
+      for (int j = 0; j < NT; ++j) {
+        const int n = nc + j * 16;
+        if (n < g.N) *(f32x4*)(g.slabs + ((int64_t)ks * g.M + mr + i * g.W) * g.N + n) = acc[i][j];
       }
-    }
+  } else {
+    epi_tile<MT, NT>(g, 0, mr, g.W, nc, acc);
   }
 }
 

@@ -28,7 +28,7 @@ namespace {
 // GEGLU: h and gate are 4 consecutive packed columns nh.. / nh+16..; output column oc..oc+3
 __device__ __forceinline__ void epi_store_geglu(const GemmArgs& g, int z, int m, int nh, int oc, f32x4 h, f32x4 gt) {
   int64_t o = (int64_t)z * g.sC + (int64_t)m * g.ldc + oc;
-  *(bf16x4*)((bf16*)g.C + o) = to_bf16x4(geglu_value(g, nh, h, gt));
+  *(bf16x4*)((bf16*)g.C + o) = to_bf16x4(geglu_value(g, m, nh, h, gt));
 }
 
 template <int BN, int AMODE>
@@ -251,51 +251,8 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const GemmArgs g) {
     }
     return;
   }
-  // Optional LDS-staged epilogue (SVG_GEMM_DBG=5): the tile is parked in LDS and written as whole rows with 16-byte
-  // stores.  Same-box A/B: no faster than the direct 8-byte stores below (0.032 vs 0.029 ms at 65536x320x320, equal
-  // end to end) — L2 merges the partial lines — so the direct form is the default.
-  const bool staged = g.dbg == 5 && !g.out_f32 && (n_out & 7) == 0 && (g.ldc & 7) == 0;
-  const int ow = geglu ? (BN / 2) : BN;                 // tile width in output columns
-  const int rowb = ow * 2 + 16;                         // LDS bytes per tile row (pad keeps the 8-byte writes conflict free)
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int rl = wm * 64 + i * 16 + l15;
-    const int m = m0 + rl;
-    if (m >= g.M) continue;
-    if (geglu) {
-      if constexpr ((NT & 1) == 0) {
-#pragma unroll
-        for (int j = 0; j < NT; j += 2) {
-          const int nh = n0 + wn * (BN / 2) + j * 16 + lq * 4;
-          if (nh >= g.N) continue;
-          const int cl = wn * (BN / 4) + (j >> 1) * 16 + lq * 4;
-          const f32x4 v = geglu_value(g, nh, acc[i][j] * g.alpha, acc[i][j + 1] * g.alpha);
-          if (staged) *(bf16x4*)(smem + rl * rowb + cl * 2) = to_bf16x4(v);
-          else *(bf16x4*)((bf16*)g.C + (int64_t)z * g.sC + (int64_t)m * g.ldc + (n0 >> 1) + cl) = to_bf16x4(v);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int cl = wn * (BN / 2) + j * 16 + lq * 4;
-        const int n = n0 + cl;
-        if (n >= g.N) continue;
-        if (staged) *(bf16x4*)(smem + rl * rowb + cl * 2) = to_bf16x4(epi_value(g, z, m, n, acc[i][j] * g.alpha));
-        else epi_store(g, z, m, n, acc[i][j] * g.alpha);
-      }
-    }
-  }
-  if (staged) {
-    __syncthreads();
-    const int cpr = ow >> 3;                            // 16-byte chunks per tile row
-    const int nc0 = geglu ? (n0 >> 1) : n0;
-    bf16* Cp = (bf16*)g.C + (int64_t)z * g.sC;
-    for (int id = tid; id < BM * cpr; id += 256) {
-      const int row = id / cpr, ch = id - row * cpr;
-      const int m = m0 + row, n = nc0 + ch * 8;
-      if (m < g.M && n < n_out) *(u32x4*)(Cp + (int64_t)m * g.ldc + n) = *(const u32x4*)(smem + row * rowb + ch * 16);
-    }
-  }
+  // (an LDS-staged, 16-byte coalesced store variant measured no faster: L2 merges the 8-byte pieces)
+  epi_tile<MT, NT>(g, z, m0 + wm * 64 + l15, 16, n0 + wn * (BN / 2) + lq * 4, acc);
 }
 
 // sums the split-K slabs and applies the epilogue
@@ -316,12 +273,16 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmArgs g) {
         gt += *(const f32x4*)(sl + 16);
       }
       const int oc = (n >> 5) * 16 + (n & 15);
-      epi_store_geglu(g, z, m, n, oc, h * g.alpha, gt * g.alpha);
+      h = h * g.alpha; gt = gt * g.alpha;
+      if (g.ln_rs) { h = ln_fold(g, z, m, n, h); gt = ln_fold(g, z, m, n + 16, gt); }
+      epi_store_geglu(g, z, m, n, oc, h, gt);
     } else {
       f32x4 v = {0, 0, 0, 0};
       for (int s = 0; s < g.splitk; ++s)
         v += *(const f32x4*)(g.slabs + ((int64_t)(s * g.batch + z) * g.M + m) * g.N + n);
-      epi_store(g, z, m, n, v * g.alpha);
+      v = v * g.alpha;
+      if (g.ln_rs) v = ln_fold(g, z, m, n, v);
+      epi_store(g, z, m, n, v);
     }
   }
 }

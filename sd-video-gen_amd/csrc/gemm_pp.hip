@@ -148,32 +148,8 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs g) {
     if (grp == 0) bar();
   }
 
-  // ---- epilogue (as gemm.hip's direct form) ------------------------------------------------------------------------
-  const bool geglu = g.act == ACT_GEGLU;
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + l15;
-    if (m >= g.M) continue;
-    if (geglu) {
-      if constexpr ((NT & 1) == 0) {
-#pragma unroll
-        for (int j = 0; j < NT; j += 2) {
-          const int nh = n0 + wn * (BN / 2) + j * 16 + lq * 4;
-          if (nh >= g.N) continue;
-          const int cl = wn * (BN / 4) + (j >> 1) * 16 + lq * 4;
-          const f32x4 v = geglu_value(g, nh, acc[i][j] * g.alpha, acc[i][j + 1] * g.alpha);
-          *(bf16x4*)((bf16*)g.C + (int64_t)m * g.ldc + (n0 >> 1) + cl) = to_bf16x4(v);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 16 + lq * 4;
-        if (n >= g.N) continue;
-        epi_store(g, 0, m, n, acc[i][j] * g.alpha);
-      }
-    }
-  }
+  // ---- epilogue ---------------------------------------------------------------------------------------------------
+  epi_tile<MT, NT>(g, 0, m0 + wm * 64 + l15, 16, n0 + wn * (BN / 2) + lq * 4, acc);
 }
 
 template <int BN>

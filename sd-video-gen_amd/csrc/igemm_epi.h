@@ -33,6 +33,67 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 }
 
 // bias / per-sample bias / residual / activation for 4 consecutive columns n..n+3 of row m
+// folded LayerNorm: acc -> rstd * acc - rstd * mean * s (see GemmArgs)
+__device__ __forceinline__ f32x4 ln_fold(const GemmArgs& g, int z, int m, int n, f32x4 v) {
+  if (g.ln_swapped) {
+    const float sm = g.ln_s[m];
+    const int64_t t = z * g.ln_zstride + n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = n + i < g.n_valid;
+      const float rs = ok ? g.ln_rs[t + i] : 0.f, rm = ok ? g.ln_rm[t + i] : 0.f;
+      v[i] = v[i] * rs - rm * sm;
+    }
+    return v;
+  }
+  const float rs = g.ln_rs[m], rm = g.ln_rm[m];
+  const f32x4 sv = *(const f32x4*)(g.ln_s + n);
+  return v * rs - sv * rm;
+}
+
+// the same for a wave's whole accumulator tile (rows mr + 16 i, columns nc + 16 j .. +3), statistics and column sums
+// loaded once up front: inside the store loop they would be re-fetched after every store (possible aliasing with C)
+template <int MT_, int NT_>
+__device__ __forceinline__ void ln_fold_tile(const GemmArgs& g, int z, int mr, int mstep, int nc, float alpha, f32x4 (&acc)[MT_][NT_]) {
+  if (g.ln_swapped) {
+    float sm[MT_];
+    f32x4 rs[NT_], rm[NT_];
+#pragma unroll
+    for (int i = 0; i < MT_; ++i) sm[i] = (mr + mstep * i < g.M) ? g.ln_s[mr + mstep * i] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NT_; ++j) {
+      const int n = nc + 16 * j;
+      const int64_t t = z * g.ln_zstride + n;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = n + e < g.n_valid;
+        rs[j][e] = ok ? g.ln_rs[t + e] : 0.f;
+        rm[j][e] = ok ? g.ln_rm[t + e] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MT_; ++i)
+#pragma unroll
+      for (int j = 0; j < NT_; ++j) acc[i][j] = acc[i][j] * alpha * rs[j] - rm[j] * sm[i];
+  } else {
+    float rs[MT_], rm[MT_];
+    f32x4 sv[NT_];
+#pragma unroll
+    for (int i = 0; i < MT_; ++i) {
+      const bool ok = mr + mstep * i < g.M;
+      rs[i] = ok ? g.ln_rs[mr + mstep * i] : 0.f;
+      rm[i] = ok ? g.ln_rm[mr + mstep * i] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NT_; ++j) sv[j] = (nc + 16 * j < g.N) ? *(const f32x4*)(g.ln_s + nc + 16 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < MT_; ++i)
+#pragma unroll
+      for (int j = 0; j < NT_; ++j) acc[i][j] = acc[i][j] * (alpha * rs[i]) - sv[j] * rm[i];
+  }
+}
+
+// (the kernels fold LayerNorm into their accumulators with ln_fold_tile before calling this; the split-K reduce with ln_fold)
 __device__ __forceinline__ f32x4 epi_value(const GemmArgs& g, int z, int m, int n, f32x4 v) {
   if (g.bias) {
     if (g.bias_row) {
@@ -69,7 +130,7 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, int z, int m, int n
   if (g.out_f32) *(f32x4*)((float*)g.C + o) = v;
   else *(bf16x4*)((bf16*)g.C + o) = to_bf16x4(v);
 }
-__device__ __forceinline__ f32x4 geglu_value(const GemmArgs& g, int nh, f32x4 h, f32x4 gt) {
+__device__ __forceinline__ f32x4 geglu_value(const GemmArgs& g, int m, int nh, f32x4 h, f32x4 gt) {
   if (g.bias) {
     h += *(const f32x4*)(g.bias + nh);
     gt += *(const f32x4*)(g.bias + nh + 16);
@@ -77,6 +138,110 @@ __device__ __forceinline__ f32x4 geglu_value(const GemmArgs& g, int nh, f32x4 h,
   f32x4 v;
   for (int i = 0; i < 4; ++i) v[i] = h[i] * gelu_erf(gt[i]);
   return v;
+}
+
+// The epilogue of a wave's whole accumulator tile: rows mr + mstep * i (i < MT_), columns nc + 16 j .. +3 (j < NT_).
+// Every load (bias, per-sample bias, residual, LayerNorm statistics) is issued BEFORE the first store: written as a
+// per-fragment loop of load -> use -> store, each load has to wait behind the previous store (the compiler cannot prove
+// that C does not alias them), i.e. one exposed L2 round trip per fragment and operand — 40-60 of them per tile, more
+// than the whole K loop of a short-K GEMM.
+template <int MT_, int NT_>
+__device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int mstep, int nc, f32x4 (&acc)[MT_][NT_]) {
+  const bool geglu = g.act == ACT_GEGLU;
+  float alpha = g.alpha;
+  if (g.ln_rs) { ln_fold_tile<MT_, NT_>(g, z, mr, mstep, nc, alpha, acc); alpha = 1.f; }
+  // ---- loads
+  f32x4 bj[NT_];
+  float bi[MT_];
+#pragma unroll
+  for (int j = 0; j < NT_; ++j) {
+    const int n = nc + 16 * j;
+    bj[j] = (g.bias && !g.bias_row && n < g.N) ? *(const f32x4*)(g.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int i = 0; i < MT_; ++i) {
+    const int m = mr + mstep * i;
+    bi[i] = (g.bias && g.bias_row && m < g.M) ? g.bias[m] : 0.f;
+  }
+  const bool has_bbn = g.bias_bn != nullptr, has_res = g.residual != nullptr && !geglu;
+  const int ldbn = g.bias_bn_ld ? g.bias_bn_ld : g.N;
+  // two row groups: halves the registers the prefetched operands need (one more exposed round trip, not twenty)
+  constexpr int RG = (MT_ + 1) / 2;
+#pragma unroll
+  for (int i0 = 0; i0 < MT_; i0 += RG) {
+    f32x4 ex[RG][NT_];        // per-sample bias + residual of this row group (one array: a conv has one or the other)
+#pragma unroll
+    for (int ii = 0; ii < RG; ++ii)
+#pragma unroll
+      for (int j = 0; j < NT_; ++j) ex[ii][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (has_bbn) {
+#pragma unroll
+      for (int ii = 0; ii < RG; ++ii) {
+        const int m = mr + mstep * (i0 + ii);
+        const float* row = g.bias_bn + (int64_t)(m / g.rows_per_batch) * ldbn;
+#pragma unroll
+        for (int j = 0; j < NT_; ++j) {
+          const int n = nc + 16 * j;
+          if (i0 + ii < MT_ && m < g.M && n < g.N) ex[ii][j] = *(const f32x4*)(row + n);
+        }
+      }
+    }
+    if (has_res) {
+#pragma unroll
+      for (int ii = 0; ii < RG; ++ii) {
+        const int m = mr + mstep * (i0 + ii);
+#pragma unroll
+        for (int j = 0; j < NT_; ++j) {
+          const int n = nc + 16 * j;
+          if (i0 + ii < MT_ && m < g.M && n < g.N) {
+            const bf16x4 r = *(const bf16x4*)(g.residual + (int64_t)z * g.sC + (int64_t)m * g.ldr + n);
+            ex[ii][j][0] += (float)r[0]; ex[ii][j][1] += (float)r[1]; ex[ii][j][2] += (float)r[2]; ex[ii][j][3] += (float)r[3];
+          }
+        }
+      }
+    }
+    // ---- arithmetic and stores of this row group
+#pragma unroll
+    for (int ii = 0; ii < RG; ++ii) {
+      const int i = i0 + ii;
+      if (i >= MT_) continue;
+      const int m = mr + mstep * i;
+      if (m >= g.M) continue;
+      if (geglu) {
+        if constexpr ((NT_ & 1) == 0) {
+#pragma unroll
+          for (int j = 0; j < NT_; j += 2) {
+            const int nh = nc + 16 * j;                       // packed column of the h tile; the gate tile follows
+            if (nh >= g.N) continue;
+            const f32x4 h = acc[i][j] * alpha + bj[j], gt = acc[i][j + 1] * alpha + bj[j + 1];
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = h[e] * gelu_erf(gt[e]);
+            const int oc = (nh >> 5) * 16 + (nh & 15);
+            *(bf16x4*)((bf16*)g.C + (int64_t)z * g.sC + (int64_t)m * g.ldc + oc) = to_bf16x4(v);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NT_; ++j) {
+          const int n = nc + 16 * j;
+          if (n >= g.N) continue;
+          f32x4 v = acc[i][j] * alpha + bj[j] + bi[i];
+          v += ex[ii][j];
+          if (g.act == ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+          } else if (g.act == ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+          }
+          const int64_t o = (int64_t)z * g.sC + (int64_t)m * g.ldc + n;
+          if (g.out_f32) *(f32x4*)((float*)g.C + o) = v;
+          else *(bf16x4*)((bf16*)g.C + o) = to_bf16x4(v);
+        }
+      }
+    }
+  }
 }
 
 // ---- helpers of the LDS-DMA pipelines (conv_halo.hip, gemm_pp.hip) ----------------------------------------------

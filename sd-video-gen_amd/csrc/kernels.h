@@ -38,6 +38,14 @@ struct GemmArgs {
   int ldr = 0;
   int act = ACT_NONE;
   int out_f32 = 0;
+  // LayerNorm folded into the GEMM (W' = W * gamma, b' = b + W beta packed at load): the epilogue turns acc = x W'^T into
+  // rstd[m] * acc - (rstd[m] * mean[m]) * s[n] with s[n] = sum_k W'[n][k]; applied before bias / residual / activation.
+  // ln_swapped: the normalised operand is the B side (V^T = Wv * x^T): statistics per column (token z*ln_zstride + n), s per row.
+  const float* ln_rs = nullptr;      // rstd per token
+  const float* ln_rm = nullptr;      // rstd * mean per token
+  const float* ln_s = nullptr;       // row sums of the packed bf16 weights
+  int ln_swapped = 0;
+  int64_t ln_zstride = 0;
   // split-K (0/1 = off). slabs: f32 [splitk][M][N] workspace
   int splitk = 1;
   float* slabs = nullptr;
@@ -51,6 +59,11 @@ void gemm_auto(svg_ctx* ctx, GemmArgs g, hipStream_t s, int prof_kind);
 // weight packing (device): f32 OIHW -> bf16 [Opad][ky][kx][Ipad]; f32 [N][K] -> bf16 [Npad][K]
 void pack_conv3x3(const float* w_oihw, bf16* out, int O, int I, int Opad, int Ipad, hipStream_t s);
 void pack_linear(const float* w, bf16* out, int N, int K, int Npad, hipStream_t s);
+// LayerNorm folding (load time): bias_out[n] = bias_in[n] + sum_k W[n][k] beta[k]; then W[n][k] *= gamma[k] in place
+void fold_ln_weights(float* w, const float* bias_in, const float* gamma, const float* beta, float* bias_out, int N, int K, hipStream_t s);
+void rowsum_bf16(const bf16* w, float* out, int N, int K, hipStream_t s);
+// per-row LayerNorm statistics of x[M][C]: rs = rstd, rm = rstd * mean
+void ln_stats(svg_ctx* ctx, const bf16* x, float* rs, float* rm, int M, int C, float eps, hipStream_t s);
 // GEGLU: rows [h(0..F-1); gate(0..F-1)] -> 16-row tiles alternating h / gate; bias likewise
 void pack_geglu(const float* w, const float* b, bf16* wout, float* bout, int F, int K, hipStream_t s);
 

@@ -34,6 +34,7 @@ inline void run_planned(svg_ctx* ctx, F&& body) {
 struct PackedLinear {
   bf16* w = nullptr;
   float* b = nullptr;
+  float* ln_s = nullptr;     // row sums of w when a LayerNorm (gamma, beta) has been folded into w / b at load
   int N = 0, K = 0, n_valid = 0;
 };
 
@@ -121,7 +122,9 @@ void destroy_models(svg_ctx* ctx);
 
 // shared graph pieces (sdnet.cpp)
 ConvW load_conv3x3(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int Cin, int Cout, hipStream_t s);
-PackedLinear load_linear(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int N, int K, bool bias, hipStream_t s);
+// fold != nullptr: the LayerNorm (gamma, beta) in front of this projection is folded into the packed weights (GemmArgs::ln_*)
+PackedLinear load_linear(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int N, int K, bool bias, hipStream_t s,
+                         const NormW* fold = nullptr);
 NormW load_norm(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int C);
 float* keep_f32(svg_ctx* ctx, WeightStore& ws, const std::string& name, int64_t numel);
 // out (B,Ho,Wo,Cout) = conv3x3(x) + bias [+ per-sample bias] [+ residual]
@@ -129,4 +132,4 @@ void conv3x3(svg_ctx* ctx, const bf16* x, const ConvW& cw, void* out, int B, int
              int bias_bn_ld, const bf16* residual, int out_f32, hipStream_t s);
 // C[M,N] = act(A[M,K] W^T + b) [+ residual]
 void linear(svg_ctx* ctx, const bf16* A, int lda, const PackedLinear& pl, void* C, int ldc, int M, int act, const bf16* residual,
-            int ldr, int out_f32, hipStream_t s);
+            int ldr, int out_f32, hipStream_t s, const float* ln_rs = nullptr, const float* ln_rm = nullptr);

@@ -224,6 +224,69 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const bf16* __restrict__
   }
 }
 
+// ---- LayerNorm statistics only (the normalisation itself is folded into the consuming GEMM) ---------------------------
+__global__ void __launch_bounds__(256) ln_stats_kernel(const bf16* __restrict__ x, float* __restrict__ rs, float* __restrict__ rm,
+                                                       int M, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int CV = C / 8;
+  const bf16* xr = x + (int64_t)row * C;
+  bf16x8 v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cv = lane + 64 * i;
+    if (cv < CV) {
+      v[i] = *(const bf16x8*)(xr + cv * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (float)v[i][j];
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cv = lane + 64 * i;
+    if (cv < CV) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float d = (float)v[i][j] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0) { rs[row] = rstd; rm[row] = rstd * mean; }
+}
+
+// ---- LayerNorm folding at load time --------------------------------------------------------------------------------
+// one block per output row: bias_out[n] = bias_in[n] + sum_k W[n][k] beta[k], then W[n][k] *= gamma[k]
+__global__ void __launch_bounds__(256) fold_ln_kernel(float* __restrict__ w, const float* __restrict__ bin, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ bout, int K) {
+  __shared__ float red[4];
+  const int n = blockIdx.x;
+  float* wr = w + (int64_t)n * K;
+  float acc = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float v = wr[k];
+    acc += v * beta[k];
+    wr[k] = v * gamma[k];
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) bout[n] = (bin ? bin[n] : 0.f) + ((red[0] + red[1]) + (red[2] + red[3]));
+}
+__global__ void __launch_bounds__(256) rowsum_bf16_kernel(const bf16* __restrict__ w, float* __restrict__ out, int K) {
+  __shared__ float red[4];
+  const int n = blockIdx.x;
+  const bf16* wr = w + (int64_t)n * K;
+  float acc = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) acc += (float)wr[k];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[n] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // ---- row softmax: f32 scores -> bf16 probabilities, one block per row ------------------------------
 __global__ void __launch_bounds__(256) softmax_rows_kernel(const float* __restrict__ sin, bf16* __restrict__ pout, int cols,
                                     int ld_in, int ld_out, float scale) {
@@ -305,6 +368,23 @@ void layernorm(svg_ctx* ctx, const bf16* x, const float* gamma, const float* bet
   ProfScope ps(ctx, PK_LNORM, s, 0, 4.0 * M * C);
   hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, x, gamma, beta, out, M, C, eps);
   check_launch("layernorm");
+}
+
+void ln_stats(svg_ctx* ctx, const bf16* x, float* rs, float* rm, int M, int C, float eps, hipStream_t s) {
+  SVG_CHECK(C % 8 == 0 && C <= 2048, "ln_stats: C=%d unsupported", C);
+  if (!SVG_LAUNCHING(ctx)) return;
+  ProfScope ps(ctx, PK_LNORM, s, 0, 2.0 * M * C);
+  hipLaunchKernelGGL(ln_stats_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, x, rs, rm, M, C, eps);
+  check_launch("ln_stats");
+}
+
+void fold_ln_weights(float* w, const float* bias_in, const float* gamma, const float* beta, float* bias_out, int N, int K, hipStream_t s) {
+  hipLaunchKernelGGL(fold_ln_kernel, dim3(N), dim3(256), 0, s, w, bias_in, gamma, beta, bias_out, K);
+  check_launch("fold_ln");
+}
+void rowsum_bf16(const bf16* w, float* out, int N, int K, hipStream_t s) {
+  hipLaunchKernelGGL(rowsum_bf16_kernel, dim3(N), dim3(256), 0, s, w, out, K);
+  check_launch("rowsum_bf16");
 }
 
 void softmax_rows(svg_ctx* ctx, const float* s_in, bf16* p_out, int64_t rows, int cols, int ld_in, int ld_out, float scale,

@@ -25,17 +25,26 @@ ConvW load_conv3x3(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int
   return cw;
 }
 
-PackedLinear load_linear(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int N, int K, bool bias, hipStream_t s) {
+PackedLinear load_linear(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int N, int K, bool bias, hipStream_t s,
+                         const NormW* fold) {
   const Weight& w = ws.get(prefix + ".weight");
   SVG_CHECK(w.numel == (int64_t)N * K && w.shape[0] == N, "weight %s.weight: expected [%d,%d(,1,1)]", prefix.c_str(), N, K);
   PackedLinear pl;
   pl.N = (int)align_up(N, 4); pl.K = K; pl.n_valid = N;
   pl.w = (bf16*)ctx->dalloc((int64_t)pl.N * K * sizeof(bf16));
-  pack_linear(w.f32, pl.w, N, K, pl.N, s);
-  if (bias) {
+  if (bias || fold) {
     pl.b = (float*)ctx->dalloc(pl.N * sizeof(float));
     HIP_OK(hipMemsetAsync(pl.b, 0, pl.N * sizeof(float), s));
-    HIP_OK(hipMemcpyAsync(pl.b, keep_f32(ctx, ws, prefix + ".bias", N), N * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (bias) HIP_OK(hipMemcpyAsync(pl.b, keep_f32(ctx, ws, prefix + ".bias", N), N * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  if (fold) {   // b += W beta, W *= gamma (on the f32 copy, which is released below), before the bf16 rounding
+    SVG_CHECK(fold->C == K, "fold: norm width %d != K %d", fold->C, K);
+    fold_ln_weights(w.f32, pl.b, fold->g, fold->b, pl.b, N, K, s);
+  }
+  pack_linear(w.f32, pl.w, N, K, pl.N, s);
+  if (fold) {
+    pl.ln_s = (float*)ctx->dalloc(pl.N * sizeof(float));
+    rowsum_bf16(pl.w, pl.ln_s, pl.N, K, s);
   }
   HIP_OK(hipStreamSynchronize(s));
   ws.release(prefix + ".weight");
@@ -72,8 +81,10 @@ void conv3x3(svg_ctx* ctx, const bf16* x, const ConvW& cw, void* out, int B, int
 }
 
 void linear(svg_ctx* ctx, const bf16* A, int lda, const PackedLinear& pl, void* C, int ldc, int M, int act, const bf16* residual,
-            int ldr, int out_f32, hipStream_t s) {
+            int ldr, int out_f32, hipStream_t s, const float* ln_rs, const float* ln_rm) {
   GemmArgs g;
+  SVG_CHECK((pl.ln_s != nullptr) == (ln_rs != nullptr), "linear: LayerNorm-folded weights need the row statistics (and only they)");
+  g.ln_rs = ln_rs; g.ln_rm = ln_rm; g.ln_s = pl.ln_s;
   g.A = A; g.lda = lda; g.Wt = pl.w; g.ldb = pl.K; g.M = M; g.N = pl.N; g.K = pl.K; g.n_valid = pl.N;
   g.bias = pl.b; g.act = act; g.residual = residual; g.ldr = ldr; g.C = C; g.ldc = ldc; g.out_f32 = out_f32;
   gemm_auto(ctx, g, s, PK_GEMM);

@@ -40,14 +40,14 @@ ResW load_res_t(svg_ctx* ctx, WeightStore& ws, const std::string& p, int cin, in
 
 // rows [W0; W1; ...] of same K packed into one bf16 matrix
 PackedLinear load_stacked(svg_ctx* ctx, WeightStore& ws, const std::vector<std::string>& names, const std::vector<int>& ns, int K,
-                          bool bias, hipStream_t s) {
+                          bool bias, hipStream_t s, const NormW* fold = nullptr) {
   PackedLinear pl;
   int N = 0;
   for (int n : ns) N += n;
   pl.N = (int)align_up(N, 4); pl.K = K; pl.n_valid = N;
   pl.w = (bf16*)ctx->dalloc((int64_t)pl.N * K * sizeof(bf16));
   HIP_OK(hipMemsetAsync(pl.w, 0, (size_t)pl.N * K * sizeof(bf16), s));
-  if (bias) {
+  if (bias || fold) {
     pl.b = (float*)ctx->dalloc(pl.N * sizeof(float));
     HIP_OK(hipMemsetAsync(pl.b, 0, pl.N * sizeof(float), s));
   }
@@ -55,19 +55,31 @@ PackedLinear load_stacked(svg_ctx* ctx, WeightStore& ws, const std::vector<std::
   for (size_t i = 0; i < names.size(); ++i) {
     const Weight& w = ws.get(names[i] + ".weight");
     SVG_CHECK(w.numel == (int64_t)ns[i] * K, "weight %s.weight: expected [%d,%d]", names[i].c_str(), ns[i], K);
-    pack_linear(w.f32, pl.w + (int64_t)off * K, ns[i], K, ns[i], s);
     if (bias)
       HIP_OK(hipMemcpyAsync(pl.b + off, keep_f32(ctx, ws, names[i] + ".bias", ns[i]), ns[i] * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (fold) fold_ln_weights(w.f32, pl.b + off, fold->g, fold->b, pl.b + off, ns[i], K, s);
+    pack_linear(w.f32, pl.w + (int64_t)off * K, ns[i], K, ns[i], s);
     off += ns[i];
+  }
+  if (fold) {
+    pl.ln_s = (float*)ctx->dalloc(pl.N * sizeof(float));
+    rowsum_bf16(pl.w, pl.ln_s, pl.N, K, s);
   }
   HIP_OK(hipStreamSynchronize(s));
   for (auto& n : names) ws.release(n + ".weight");
   return pl;
 }
 
+// SVG_LN_FOLD=0 keeps the three LayerNorms of a transformer block as separate kernels (A/B and debugging)
+bool ln_fold_enabled() {
+  static const int on = getenv("SVG_LN_FOLD") ? atoi(getenv("SVG_LN_FOLD")) : 1;
+  return on != 0;
+}
+
 XfBlockW load_xf(svg_ctx* ctx, WeightStore& ws, const std::string& p, int C, int ctx_dim, hipStream_t s) {
   XfBlockW b;
   b.C = C;
+  const bool fold = ln_fold_enabled();
   b.gn = load_norm(ctx, ws, p + ".norm", C);
   b.proj_in = load_linear(ctx, ws, p + ".proj_in", C, C, true, s);
   b.proj_out = load_linear(ctx, ws, p + ".proj_out", C, C, true, s);
@@ -75,10 +87,10 @@ XfBlockW load_xf(svg_ctx* ctx, WeightStore& ws, const std::string& p, int C, int
   b.ln1 = load_norm(ctx, ws, t + ".norm1", C);
   b.ln2 = load_norm(ctx, ws, t + ".norm2", C);
   b.ln3 = load_norm(ctx, ws, t + ".norm3", C);
-  b.qk1 = load_stacked(ctx, ws, {t + ".attn1.to_q", t + ".attn1.to_k"}, {C, C}, C, false, s);
-  b.v1 = load_linear(ctx, ws, t + ".attn1.to_v", C, C, false, s);
+  b.qk1 = load_stacked(ctx, ws, {t + ".attn1.to_q", t + ".attn1.to_k"}, {C, C}, C, false, s, fold ? &b.ln1 : nullptr);
+  b.v1 = load_linear(ctx, ws, t + ".attn1.to_v", C, C, false, s, fold ? &b.ln1 : nullptr);
   b.o1 = load_linear(ctx, ws, t + ".attn1.to_out.0", C, C, true, s);
-  b.q2 = load_linear(ctx, ws, t + ".attn2.to_q", C, C, false, s);
+  b.q2 = load_linear(ctx, ws, t + ".attn2.to_q", C, C, false, s, fold ? &b.ln2 : nullptr);
   b.k2 = load_linear(ctx, ws, t + ".attn2.to_k", C, ctx_dim, false, s);
   b.v2 = load_linear(ctx, ws, t + ".attn2.to_v", C, ctx_dim, false, s);
   b.o2 = load_linear(ctx, ws, t + ".attn2.to_out.0", C, C, true, s);
@@ -89,8 +101,20 @@ XfBlockW load_xf(svg_ctx* ctx, WeightStore& ws, const std::string& p, int C, int
     b.ff1.N = 2 * F; b.ff1.K = C; b.ff1.n_valid = 2 * F;
     b.ff1.w = (bf16*)ctx->dalloc((int64_t)2 * F * C * sizeof(bf16));
     b.ff1.b = (float*)ctx->dalloc(2 * F * sizeof(float));
-    pack_geglu(w.f32, keep_f32(ctx, ws, t + ".ff.net.0.proj.bias", 2 * F), b.ff1.w, b.ff1.b, F, C, s);
+    float* bias = keep_f32(ctx, ws, t + ".ff.net.0.proj.bias", 2 * F);
+    float* btmp = nullptr;
+    if (fold) {   // fold LayerNorm 3 on the unpacked rows, then pack weights and bias together
+      HIP_OK(hipMalloc(&btmp, (size_t)2 * F * sizeof(float)));
+      fold_ln_weights(w.f32, bias, b.ln3.g, b.ln3.b, btmp, 2 * F, C, s);
+      bias = btmp;
+    }
+    pack_geglu(w.f32, bias, b.ff1.w, b.ff1.b, F, C, s);
+    if (fold) {
+      b.ff1.ln_s = (float*)ctx->dalloc((size_t)2 * F * sizeof(float));
+      rowsum_bf16(b.ff1.w, b.ff1.ln_s, 2 * F, C, s);
+    }
     HIP_OK(hipStreamSynchronize(s));
+    if (btmp) HIP_OK(hipFree(btmp));
     ws.release(t + ".ff.net.0.proj.weight");
   }
   b.ff2 = load_linear(ctx, ws, t + ".ff.net.2", C, 4 * C, true, s);
@@ -227,17 +251,24 @@ struct UnetRun {
   }
 
   // V^T[b] (C x SkvPad) = Wv * src_b^T
-  void vt_proj_into(const PackedLinear& wv, const bf16* src, int rows, int rows_pad, int K, bf16* vt) {
+  void vt_proj_into(const PackedLinear& wv, const bf16* src, int rows, int rows_pad, int K, bf16* vt,
+                    const float* ln_rs = nullptr, const float* ln_rm = nullptr) {
     const int C = wv.N;
     GemmArgs g;
     g.A = wv.w; g.lda = K; g.Wt = src; g.ldb = K; g.M = C; g.N = rows_pad; g.n_valid = rows; g.K = K;
     g.batch = N; g.sA = 0; g.sB = (int64_t)rows * K; g.sC = (int64_t)C * rows_pad;
     g.C = vt; g.ldc = rows_pad;
+    SVG_CHECK((wv.ln_s != nullptr) == (ln_rs != nullptr), "vt_proj: LayerNorm-folded weights need the token statistics");
+    if (ln_rs) {   // the normalised tokens are the B operand here: statistics per column, sums / bias per row
+      g.ln_rs = ln_rs; g.ln_rm = ln_rm; g.ln_s = wv.ln_s; g.ln_swapped = 1; g.ln_zstride = rows;
+      g.bias = wv.b; g.bias_row = 1;
+    }
     gemm_auto(ctx, g, s, PK_GEMM);
   }
-  bf16* vt_proj(const PackedLinear& wv, const bf16* src, int rows, int rows_pad, int K) {
+  bf16* vt_proj(const PackedLinear& wv, const bf16* src, int rows, int rows_pad, int K, const float* ln_rs = nullptr,
+                const float* ln_rm = nullptr) {
     bf16* vt = ctx->arena.get<bf16>((int64_t)N * wv.N * rows_pad);
-    vt_proj_into(wv, src, rows, rows_pad, K, vt);
+    vt_proj_into(wv, src, rows, rows_pad, K, vt, ln_rs, ln_rm);
     return vt;
   }
 
@@ -251,27 +282,36 @@ struct UnetRun {
     groupnorm(ctx, x, C, nullptr, 0, b.gn.g, b.gn.b, n0, N, HW, m->groups, 1e-6f, 0, s);
     bf16* h = ctx->arena.get<bf16>(P * C);
     linear(ctx, n0, C, b.proj_in, h, C, M, ACT_NONE, nullptr, 0, 0, s);
-    bf16* ln = ctx->arena.get<bf16>(P * C);
+    // LayerNorms: folded into the consuming projections (row statistics only) unless SVG_LN_FOLD=0
+    const bool fold = b.qk1.ln_s != nullptr;
+    bf16* ln = fold ? nullptr : ctx->arena.get<bf16>(P * C);
+    float* rs = fold ? ctx->arena.get<float>(M + 8) : nullptr;
+    float* rm = fold ? ctx->arena.get<float>(M + 8) : nullptr;
+    auto norm = [&](const bf16* src, const NormW& n) -> const bf16* {
+      if (fold) { ln_stats(ctx, src, rs, rm, M, C, 1e-5f, s); return src; }
+      layernorm(ctx, src, n.g, n.b, ln, M, C, 1e-5f, s);
+      return ln;
+    };
     bf16* ao = ctx->arena.get<bf16>(P * C);
     // ---- self-attention
-    layernorm(ctx, h, b.ln1.g, b.ln1.b, ln, M, C, 1e-5f, s);
+    const bf16* a1 = norm(h, b.ln1);
     {
       ctx->arena.push();
       const int HWp = (int)align_up(HW, 8);
       bf16* qk = ctx->arena.get<bf16>(P * 2 * C);
-      linear(ctx, ln, C, b.qk1, qk, 2 * C, M, ACT_NONE, nullptr, 0, 0, s);
-      bf16* vt = vt_proj(b.v1, ln, HW, HWp, C);
+      linear(ctx, a1, C, b.qk1, qk, 2 * C, M, ACT_NONE, nullptr, 0, 0, s, rs, rm);
+      bf16* vt = vt_proj(b.v1, a1, HW, HWp, C, rs, rm);
       attn_core(qk, 2 * C, qk + C, 2 * C, (int64_t)HW * 2 * C, vt, HWp, (int64_t)C * HWp, ao, C, HW, HW);
       ctx->arena.pop();
     }
     bf16* h1 = ctx->arena.get<bf16>(P * C);
     linear(ctx, ao, C, b.o1, h1, C, M, ACT_NONE, h, C, 0, s);
     // ---- cross-attention
-    layernorm(ctx, h1, b.ln2.g, b.ln2.b, ln, M, C, 1e-5f, s);
+    const bf16* a2 = norm(h1, b.ln2);
     {
       ctx->arena.push();
       bf16* q = ctx->arena.get<bf16>(P * C);
-      linear(ctx, ln, C, b.q2, q, C, M, ACT_NONE, nullptr, 0, 0, s);
+      linear(ctx, a2, C, b.q2, q, C, M, ACT_NONE, nullptr, 0, 0, s, rs, rm);
       const int idx = xf_idx++;
       const int64_t kn = (int64_t)N * L * C, vn = (int64_t)N * C * Lp;
       bf16 *k, *vt;
@@ -294,11 +334,11 @@ struct UnetRun {
     bf16* h2 = ctx->arena.get<bf16>(P * C);
     linear(ctx, ao, C, b.o2, h2, C, M, ACT_NONE, h1, C, 0, s);
     // ---- GEGLU feed-forward
-    layernorm(ctx, h2, b.ln3.g, b.ln3.b, ln, M, C, 1e-5f, s);
+    const bf16* a3 = norm(h2, b.ln3);
     {
       ctx->arena.push();
       bf16* g = ctx->arena.get<bf16>(P * 4 * C);
-      linear(ctx, ln, C, b.ff1, g, 4 * C, M, ACT_GEGLU, nullptr, 0, 0, s);
+      linear(ctx, a3, C, b.ff1, g, 4 * C, M, ACT_GEGLU, nullptr, 0, 0, s, rs, rm);
       linear(ctx, g, 4 * C, b.ff2, h, C, M, ACT_NONE, h2, C, 0, s);   // h is free again: reuse as h3
       ctx->arena.pop();
     }
