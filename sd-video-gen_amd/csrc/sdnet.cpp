@@ -1,6 +1,7 @@
 // Shared pieces of the SD networks (VAE, UNet): weight packing by state_dict name and the
 // conv / linear / resnet building blocks over NHWC bf16 activations.
 #include "models.h"
+#include <algorithm>
 
 float* keep_f32(svg_ctx* ctx, WeightStore& ws, const std::string& name, int64_t numel) {
   const Weight& w = ws.get(name);
@@ -61,6 +62,27 @@ NormW load_norm(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int C)
 
 void conv3x3(svg_ctx* ctx, const bf16* x, const ConvW& cw, void* out, int B, int H, int W, int amode, const float* bias_bn,
              int bias_bn_ld, const bf16* residual, int out_f32, hipStream_t s) {
+  // the kernels address an operand with 32-bit byte offsets: an input or output of 2^31 elements or more (the 512 x 512
+  // VAE levels beyond ~30 images) is processed in batch chunks
+  {
+    const int up = amode == A_CONV_UP2 ? 4 : 1;
+    const int64_t per_img = std::max<int64_t>((int64_t)H * W * std::max(cw.Cin, 8), (int64_t)H * W * up * cw.Opad);
+    const int64_t lim = (1LL << 31) - 1;
+    if ((int64_t)B * per_img > lim && B > 1) {
+      const int chunk = (int)std::max<int64_t>(1, lim / per_img);
+      const int Ho = amode == A_CONV_UP2 ? 2 * H : ((amode == A_CONV_S2P1 || amode == A_CONV_S2ASYM) ? H / 2 : H);
+      const int Wo = amode == A_CONV_UP2 ? 2 * W : ((amode == A_CONV_S2P1 || amode == A_CONV_S2ASYM) ? W / 2 : W);
+      const int cin = cw.Cin;
+      for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = std::min(chunk, B - b0);
+        const int64_t o = (int64_t)b0 * Ho * Wo * cw.Opad;
+        conv3x3(ctx, x + (int64_t)b0 * H * W * cin, cw, out_f32 ? (void*)((float*)out + o) : (void*)((bf16*)out + o), nb, H, W, amode,
+                bias_bn ? bias_bn + (int64_t)b0 * (bias_bn_ld ? bias_bn_ld : cw.Opad) : nullptr, bias_bn_ld,
+                residual ? residual + o : nullptr, out_f32, s);
+      }
+      return;
+    }
+  }
   GemmArgs g;
   g.A = x; g.H = H; g.W = W; g.Cin = cw.Cin;
   g.amode = (cw.Cin == 8) ? A_CONV_SMALLC : amode;
@@ -82,8 +104,20 @@ void conv3x3(svg_ctx* ctx, const bf16* x, const ConvW& cw, void* out, int B, int
 
 void linear(svg_ctx* ctx, const bf16* A, int lda, const PackedLinear& pl, void* C, int ldc, int M, int act, const bf16* residual,
             int ldr, int out_f32, hipStream_t s, const float* ln_rs, const float* ln_rm) {
-  GemmArgs g;
   SVG_CHECK((pl.ln_s != nullptr) == (ln_rs != nullptr), "linear: LayerNorm-folded weights need the row statistics (and only they)");
+  {   // 32-bit operand offsets in the kernels: split very tall problems (1 x 1 convs on the 512 x 512 VAE levels) by rows
+    const int64_t lim = (1LL << 31) - 1;
+    const int64_t per_row = std::max<int64_t>(lda, std::max(ldc, ldr));
+    if ((int64_t)M * per_row > lim && M > 1) {
+      const int chunk = (int)(lim / per_row) & ~255;
+      const int csz = out_f32 ? 4 : 2;
+      for (int m0 = 0; m0 < M; m0 += chunk)
+        linear(ctx, A + (int64_t)m0 * lda, lda, pl, (char*)C + (int64_t)m0 * ldc * csz, ldc, std::min(chunk, M - m0), act,
+               residual ? residual + (int64_t)m0 * ldr : nullptr, ldr, out_f32, s, ln_rs ? ln_rs + m0 : nullptr, ln_rm ? ln_rm + m0 : nullptr);
+      return;
+    }
+  }
+  GemmArgs g;
   g.ln_rs = ln_rs; g.ln_rm = ln_rm; g.ln_s = pl.ln_s;
   g.A = A; g.lda = lda; g.Wt = pl.w; g.ldb = pl.K; g.M = M; g.N = pl.N; g.K = pl.K; g.n_valid = pl.N;
   g.bias = pl.b; g.act = act; g.residual = residual; g.ldr = ldr; g.C = C; g.ldc = ldc; g.out_f32 = out_f32;
