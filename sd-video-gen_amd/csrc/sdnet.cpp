@@ -2,6 +2,17 @@
 // conv / linear / resnet building blocks over NHWC bf16 activations.
 #include "models.h"
 #include <algorithm>
+#include <cstdlib>
+
+// elements one kernel launch may address per operand (32-bit byte offsets); $SVG_CHUNK_LIMIT lowers it so that the tests can
+// drive the batch / row chunking of conv3x3() and linear() at small sizes (read per call: the tests toggle it in-process)
+static int64_t chunk_limit() {
+  const char* e = getenv("SVG_CHUNK_LIMIT");
+  const int64_t full = (1LL << 31) - 1;
+  if (!e) return full;
+  const int64_t v = atoll(e);
+  return v > 0 && v < full ? v : full;
+}
 
 float* keep_f32(svg_ctx* ctx, WeightStore& ws, const std::string& name, int64_t numel) {
   const Weight& w = ws.get(name);
@@ -67,7 +78,7 @@ void conv3x3(svg_ctx* ctx, const bf16* x, const ConvW& cw, void* out, int B, int
   {
     const int up = amode == A_CONV_UP2 ? 4 : 1;
     const int64_t per_img = std::max<int64_t>((int64_t)H * W * std::max(cw.Cin, 8), (int64_t)H * W * up * cw.Opad);
-    const int64_t lim = (1LL << 31) - 1;
+    const int64_t lim = chunk_limit();
     if ((int64_t)B * per_img > lim && B > 1) {
       const int chunk = (int)std::max<int64_t>(1, lim / per_img);
       const int Ho = amode == A_CONV_UP2 ? 2 * H : ((amode == A_CONV_S2P1 || amode == A_CONV_S2ASYM) ? H / 2 : H);
@@ -106,7 +117,7 @@ void linear(svg_ctx* ctx, const bf16* A, int lda, const PackedLinear& pl, void* 
             int ldr, int out_f32, hipStream_t s, const float* ln_rs, const float* ln_rm) {
   SVG_CHECK((pl.ln_s != nullptr) == (ln_rs != nullptr), "linear: LayerNorm-folded weights need the row statistics (and only they)");
   {   // 32-bit operand offsets in the kernels: split very tall problems (1 x 1 convs on the 512 x 512 VAE levels) by rows
-    const int64_t lim = (1LL << 31) - 1;
+    const int64_t lim = chunk_limit();
     const int64_t per_row = std::max<int64_t>(lda, std::max(ldc, ldr));
     if ((int64_t)M * per_row > lim && M > 1) {
       const int chunk = (int)(lim / per_row) & ~255;

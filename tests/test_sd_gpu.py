@@ -84,6 +84,30 @@ def test_vae_decode(ctx, cfg, N, h):
     assert mean <= 1.0 and within2 >= 0.97, (mean, within2, mx)
 
 
+def test_vae_batch_chunking(ctx):
+    """conv3x3() / linear() split a problem whose operand would pass 2^31 elements (the 512 x 512 VAE levels beyond ~30
+    images) into batch / row chunks; $SVG_CHUNK_LIMIT lowers the limit so the chunked path runs at test size."""
+    cfg = MID_VAE
+    sd = load_vae(ctx, cfg, 14)
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(5, 4, 16, 16, generator=g) * 0.18215 * 3
+    img0, fl0 = ctx.vae_decode(z.cuda(), return_float=True)
+    imgs = torch.randint(0, 256, (5, 64, 64, 3), dtype=torch.uint8, generator=g)
+    z0 = ctx.vae_encode(imgs.cuda())
+    os.environ["SVG_CHUNK_LIMIT"] = str(2 * 128 * 128 * 64)      # two images of the widest level per launch
+    try:
+        img1, fl1 = ctx.vae_decode(z.cuda(), return_float=True)
+        z1 = ctx.vae_encode(imgs.cuda())
+    finally:
+        del os.environ["SVG_CHUNK_LIMIT"]
+    # the chunks may pick other tile shapes than the whole batch (accumulation order): equal up to bf16 rounding
+    assert rel_l2(fl1, fl0) < 1.5e-2 and rel_l2(z1, z0) < 1.5e-2   # other tile shapes per chunk: bf16 roundings differ layer by layer
+    ref_img, ref_fl = SO.decode_img_latents(sd, z, cfg, return_float=True)
+    assert rel_l2(fl1.cpu(), ref_fl) < NET_TOL
+    mean, within2, mx = img_close(img1.cpu(), ref_img)
+    assert mean <= 1.0 and within2 >= 0.97, (mean, within2, mx)
+
+
 def test_vae_resize_fused(ctx):
     """the uint8 nearest resizes of predict.py:158,178 folded into encode (input side) and decode (output side)."""
     cfg = TINY_VAE

@@ -67,8 +67,10 @@ def main():
             A = torch.randn(M, K, device="cuda").to(bf)
             W = (torch.randn(N, K, device="cuda") / math.sqrt(K)).to(bf)
             out = torch.empty(M, N // 2 if act == 3 else N, device="cuda", dtype=bf)
+            bias = torch.randn(N, device="cuda")                      # as in the network: bias everywhere, residual on the C -> C projections
+            res = torch.randn(M, N, device="cuda").to(bf) if (act == 0 and N <= K) else None
             ms, fl, _ = timeit(ctx, "gemm", lambda: ctx.check(ctx.lib.svg_op_gemm(
-                ctx.h, A.data_ptr(), W.data_ptr(), None, None, out.data_ptr(), M, N, K, act, 0, stream()), "gemm"))
+                ctx.h, A.data_ptr(), W.data_ptr(), bias.data_ptr(), res.data_ptr() if res is not None else None, out.data_ptr(), M, N, K, act, 0, stream()), "gemm"))
             print("%7d %6d %6d %d  %8.3f ms  %7.1f TF" % (M, N, K, act, ms, fl / ms / 1e9))
     if "attn" in a.what:
         print("== attention (B=%d): Sq Skv d  ms  TFLOP/s" % B)
