@@ -55,8 +55,21 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int b = blockIdx.z, head = blockIdx.y;
-  const int q0 = blockIdx.x * (128 * QB) + wid * (32 * QB);
+  // 1-D grid, XCD-aware: workgroups are dealt to the 8 XCDs round robin (bid % 8), and the query tiles of one (sample,
+  // head) all stream the same K / V^T — give each XCD a contiguous run of logical ids (query tile fastest) so that they
+  // share one L2 instead of fetching K / V^T eight times (PMC: 1.25 GB fetched per launch against 0.22 GB of Q, K, V).
+  int b, head, qt;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
+    const int w = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int nqt = (a.Sq + 128 * QB - 1) / (128 * QB);
+    qt = w % nqt;
+    const int bh = w / nqt;
+    head = bh % a.heads;
+    b = bh / a.heads;
+  }
+  const int q0 = qt * (128 * QB) + wid * (32 * QB);
 
   const bf16* __restrict__ Q = a.q + (int64_t)b * a.qb + head * D;
   const bf16* __restrict__ Kp = a.k + (int64_t)b * a.kb + head * D;
@@ -326,12 +339,12 @@ void launch(const AttnArgs& a, hipStream_t s) {
   constexpr int QB = (D <= 64) ? 2 : 1;
   constexpr bool CAN_BC = (D % 16) == 8;        // three spare pad columns in lane-half 1 of the last k-step (d = 8, 40)
   if (QB == 2 && qb_env == 2 && a.Sq >= 512) {
-    dim3 grid(cdiv(a.Sq, 256), a.heads, a.B);
+    dim3 grid(cdiv(a.Sq, 256) * a.heads * a.B);
     if (CAN_BC && bc_env) hipLaunchKernelGGL((attn_kernel<D, QB, 1, CAN_BC>), grid, dim3(256), 0, s, a);
     else if (nst_env == 2) hipLaunchKernelGGL((attn_kernel<D, QB, 2, false>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((attn_kernel<D, QB, 1, false>), grid, dim3(256), 0, s, a);
   } else {
-    dim3 grid(cdiv(a.Sq, 128), a.heads, a.B);
+    dim3 grid(cdiv(a.Sq, 128) * a.heads * a.B);
     if (CAN_BC && bc_env) hipLaunchKernelGGL((attn_kernel<D, 1, 1, CAN_BC>), grid, dim3(256), 0, s, a);
     else if (nst_env == 2) hipLaunchKernelGGL((attn_kernel<D, 1, 2, false>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((attn_kernel<D, 1, 1, false>), grid, dim3(256), 0, s, a);
