@@ -59,8 +59,13 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int tn = tile % tiles_n;
-  int pb = tile / tiles_n;
+  int tn, pb;
+  if (g.tn_major) {   // weight-heavy (small images): the XCD's run of tiles keeps one channel tile's weights in its L2
+    const int npb = gridDim.x / tiles_n;
+    tn = tile / npb; pb = tile - tn * npb;
+  } else {
+    tn = tile % tiles_n; pb = tile / tiles_n;
+  }
   const int bx = pb % bx_n; pb /= bx_n;
   const int by = pb % by_n;
   const int b = pb / by_n;

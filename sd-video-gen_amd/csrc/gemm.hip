@@ -53,7 +53,13 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const GemmArgs g) {
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  int tm, tn;
+  if (g.tn_major) {   // weight-heavy problem: the XCD's run of tiles walks the rows for a fixed column tile
+    const int tiles_m = (g.M + BM - 1) / BM;
+    tn = tile / tiles_m; tm = tile - tn * tiles_m;
+  } else {
+    tm = tile / tiles_n; tn = tile - tm * tiles_n;
+  }
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int KT = (g.K + BK - 1) / BK;
@@ -386,6 +392,15 @@ void launch_gemm(svg_ctx* ctx, const GemmArgs& g, hipStream_t s, int prof_kind) 
   a.dbg = dbg_env;
   if (a.splitk < 1) a.splitk = 1;
   if (a.n_valid <= 0) a.n_valid = a.N;
+  {
+    // Each XCD has its own L2: with the A rows adjacent every XCD streams ALL the weights (8 x N*K*2 bytes per launch),
+    // with the weights adjacent every XCD streams all of A.  Pick the cheaper (16 x 16 / 8 x 8 convs: 30 MB of weights
+    // against 5-18 MB of image).
+    static const int tn_env = getenv("SVG_TN_MAJOR") ? atoi(getenv("SVG_TN_MAJOR")) : -1;
+    const double a_bytes_phys = (a.amode == A_DENSE ? (double)a.M * a.K : (double)(a.M / (a.Ho * a.Wo)) * a.H * a.W * a.Cin) * 2.0;
+    const double w_bytes = (double)a.N * a.K * 2.0;
+    a.tn_major = tn_env >= 0 ? tn_env : (a.batch == 1 && w_bytes > a_bytes_phys);
+  }
   // algorithmic bytes: every operand once (a conv reads its image once, not once per tap)
   const double a_elems = g.amode == A_DENSE ? (double)g.M * g.K : (double)(g.M / (g.Ho * g.Wo)) * g.H * g.W * g.Cin;
   ProfScope ps(ctx, prof_kind, s, 2.0 * g.M * (double)g.N * g.K * g.batch,

@@ -49,6 +49,7 @@ struct GemmArgs {
   // split-K (0/1 = off). slabs: f32 [splitk][M][N] workspace
   int splitk = 1;
   float* slabs = nullptr;
+  int tn_major = 0;                  // tile order inside an XCD's run: 0 = tiles sharing the A rows adjacent, 1 = tiles sharing the weights adjacent
   int dbg = 0;                       // ablation switch (SVG_GEMM_DBG): 1 no stores, 2 no MFMA, 3 no DMA, 5 LDS-staged epilogue
 };
 
