@@ -18,8 +18,9 @@ from . import transformer_oracle as TO
 
 
 def sample_clip(xf_sd, num_heads, vae_sd, clip_u8, pred_frames, noise, denoise=False, start_step=40, unet_sd=None,
-                text_emb=None, vae_cfg=SO.SD_VAE, unet_cfg=SO.SD_UNET, res=512, num_inference_steps=50):
-    """clip_u8 (5,F,F,3) uint8 -> all_latents (1, 4+N, D_lat)."""
+                text_emb=None, vae_cfg=SO.SD_VAE, unet_cfg=SO.SD_UNET, res=512, num_inference_steps=50, txt=None):
+    """clip_u8 (5,F,F,3) uint8 -> all_latents (1, 4+N, D_lat).  `txt` (1,384): the class embedding of the
+    text-conditioned loop (prediction/predict_text.py:186-262 — the same loop with predict(model, X, cls_list))."""
     T, F = clip_u8.shape[0], clip_u8.shape[1]
     down = 2 ** (len(vae_cfg["block_out"]) - 1)
     L = F // down
@@ -30,7 +31,7 @@ def sample_clip(xf_sd, num_heads, vae_sd, clip_u8, pred_frames, noise, denoise=F
     preds = torch.zeros(1, 0, D)
     all_latents = None
     for k in range(pred_frames):
-        pred = TO.predict(xf_sd, X, num_heads)
+        pred = TO.predict(xf_sd, X, num_heads, txt=txt)
         if denoise:
             img = SO.decode_img_latents(vae_sd, pred.reshape(1, 4, L, L), vae_cfg)
             big = SO.resize_nearest_u8(img, res, res)

@@ -6,6 +6,9 @@
 void XfModel::configure(const char* kv) {
   auto m = parse_kv(kv);
   auto geti = [&](const char* k, int& dst) { if (m.count(k)) dst = (int)m[k][0]; };
+  // a configure call describes the whole model: keys it leaves out go back to their defaults (a context that held a
+  // text-conditioned model must not keep its text_dim for the next, plain one)
+  d_lat = 0; d_model = 0; heads = 8; enc_layers = 0; dec_layers = 0; ffn = 2048; text_dim = 0;
   geti("d_lat", d_lat); geti("d_model", d_model); geti("heads", heads);
   geti("enc_layers", enc_layers); geti("dec_layers", dec_layers); geti("ffn", ffn); geti("text_dim", text_dim);
   ready = false;

@@ -62,6 +62,29 @@ def test_loop_no_denoise_matches_oracle(ctx):
     assert rel_l2(alone.cpu(), lat[1:2].cpu()) < 2e-3
 
 
+def test_text_conditioned_loop_matches_oracle(ctx):
+    """prediction/predict_text.py loop (config 5 family): clip-batched, one class name per clip, no denoise."""
+    from sd_video_gen_amd.predict import sample_clips, bouncing_ball_clips
+    from sd_video_gen_amd.transformer_text import Transformer as TextTransformer
+    sdu, _, vsd, _ = build(False)
+    torch.manual_seed(8)
+    m = TextTransformer(dim_model=64, num_heads=8, num_encoder_layers=1, num_decoder_layers=1).eval()
+    clips = bouncing_ball_clips(2, 64, 5, seed=9)
+    names = ["WallPushups", "PlayingGuitar"]
+    seeds = [21, 22]
+    lat = sample_clips(m, sdu, clips.cuda(), 3, seeds=seeds, cls_list=names)
+    assert lat.shape == (2, 7, 256)
+    xsd = {k: v.cpu() for k, v in m.state_dict().items()}
+    txt = m.encode_classes(names)
+    for c in range(2):
+        noise = clip_noise_cpu(seeds[c], 512, 64, 0, 0)
+        ref = loop_oracle.sample_clip(xsd, 8, vsd, clips[c], 3, noise, vae_cfg=VCFG, txt=txt[c:c + 1])
+        assert rel_l2(lat[c:c + 1].cpu(), ref) < 3e-2
+    # the class changes the prediction
+    other = sample_clips(m, sdu, clips.cuda(), 3, seeds=seeds, cls_list=names[::-1])
+    assert rel_l2(other[:, 4:].cpu(), lat[:, 4:].cpu()) > 1e-3
+
+
 def test_loop_denoise_matches_oracle(ctx):
     """denoise round trip at a reduced resolution (128 instead of 512) and 3 DDIM steps so the CPU oracle stays short."""
     from sd_video_gen_amd.predict import sample_clips, bouncing_ball_clips
