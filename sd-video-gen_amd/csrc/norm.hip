@@ -39,8 +39,22 @@ __global__ void gn_stats_kernel(const bf16* __restrict__ x, int C1, const bf16* 
     const int c0 = cv * 8;
     const bf16* src; int ld, coff;
     if (c0 < C1) { src = x; ld = C1; coff = c0; } else { src = x2; ld = C2; coff = c0 - C1; }
-    for (int p = p_begin + pl; p < p_end; p += PL) {
-      bf16x8 v = *(const bf16x8*)(src + ((int64_t)b * HW + p) * ld + coff);
+    // four pixels per trip: four independent 16-byte loads in flight per thread (a one-load-per-trip loop is a chain of
+    // exposed memory latencies: ~10 trips x ~1 us)
+    const bf16* sp = src + ((int64_t)b * HW + p_begin + pl) * ld + coff;
+    const int64_t st = (int64_t)PL * ld;
+    int p = p_begin + pl;
+    for (; p + 3 * PL < p_end; p += 4 * PL, sp += 4 * st) {
+      const bf16x8 v0 = *(const bf16x8*)sp, v1 = *(const bf16x8*)(sp + st), v2 = *(const bf16x8*)(sp + 2 * st), v3 = *(const bf16x8*)(sp + 3 * st);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f0 = (float)v0[j], f1 = (float)v1[j], f2 = (float)v2[j], f3 = (float)v3[j];
+        s[j] += (f0 + f1) + (f2 + f3);
+        q[j] += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
+      }
+    }
+    for (; p < p_end; p += PL, sp += st) {
+      const bf16x8 v = *(const bf16x8*)sp;
 #pragma unroll
       for (int j = 0; j < 8; ++j) { float f = (float)v[j]; s[j] += f; q[j] += f * f; }
     }
@@ -112,8 +126,7 @@ __global__ void gn_apply_kernel(const bf16* __restrict__ x, int C1, const bf16* 
   const bf16* sp = src + ((int64_t)b * HW + p_begin + pl) * ld + coff;
   bf16* dp = out + ((int64_t)b * HW + p_begin + pl) * C + c0;
   const int64_t sstep = (int64_t)PL * ld, dstep = (int64_t)PL * C;
-  for (int p = p_begin + pl; p < p_end; p += PL, sp += sstep, dp += dstep) {
-    const bf16x8 v = *(const bf16x8*)sp;
+  auto apply = [&](const bf16x8& v) -> bf16x8 {
     bf16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -121,8 +134,18 @@ __global__ void gn_apply_kernel(const bf16* __restrict__ x, int C1, const bf16* 
       if (silu) f = f * __builtin_amdgcn_rcpf(1.f + __expf(-f));
       o[j] = (bf16)f;
     }
-    *(bf16x8*)dp = o;
+    return o;
+  };
+  int p = p_begin + pl;
+  // four pixels per trip: the four loads are issued together (see gn_stats_kernel)
+  for (; p + 3 * PL < p_end; p += 4 * PL, sp += 4 * sstep, dp += 4 * dstep) {
+    const bf16x8 v0 = *(const bf16x8*)sp, v1 = *(const bf16x8*)(sp + sstep), v2 = *(const bf16x8*)(sp + 2 * sstep), v3 = *(const bf16x8*)(sp + 3 * sstep);
+    *(bf16x8*)dp = apply(v0);
+    *(bf16x8*)(dp + dstep) = apply(v1);
+    *(bf16x8*)(dp + 2 * dstep) = apply(v2);
+    *(bf16x8*)(dp + 3 * dstep) = apply(v3);
   }
+  for (; p < p_end; p += PL, sp += sstep, dp += dstep) *(bf16x8*)dp = apply(*(const bf16x8*)sp);
 }
 
 // ---- GroupNorm for small images (one launch, one read): a workgroup owns one (sample, group) — HW x cpg values that
