@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — generated frames/sec of the sampling hot path on N MI355X (one process per GPU).
 
-  python bench.py --gpus N --steps K --warmup W           (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N>1 runs one process per GPU: either the caller launches them (`python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...`, RANK/LOCAL_RANK/WORLD_SIZE in the env) or, when WORLD_SIZE is not set, this script spawns
+torch.distributed.run itself BEFORE it touches the GPU and exits with the children's code (no process that has
+initialised HIP is ever re-exec'ed).
 
 Workload (BASELINE.json configs[2], the one the metric is quoted on): config 1_16_kitti_L1_64 (F=64 frames,
 latent Transformer d=2048 4enc/8dec, 437.6 M params) with --denoise --denoise_start_step 0: per generated
@@ -107,14 +112,34 @@ def cpu_baseline(cfg_name, start_step):
                       % (t["transformer"], t["unet_step_b1"], n_unet, t["vae_enc_256"], t["vae_dec_256"], t["vae_enc_F"], t["vae_dec_F"])}
 
 
+def self_launch(args):
+    """--gpus N>1 without a launcher: start `torch.distributed.run` as a CHILD (this parent has made no HIP / torch.cuda
+    call), pass the flags through, return its exit code.  Rank 0 of the children prints the JSON line on the shared stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL / cross-process device memory on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus or world == 1 and args.gpus == 1, "launch N>1 with torch.distributed.run --nproc-per-node N"
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node equal to --gpus, or unset "
+                         "WORLD_SIZE and let bench.py spawn the ranks)" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs the GPU: the product path has no CPU fallback"
     # rehearsal knobs (single-GPU box): SVG_DEVICE_OVERRIDE pins every rank to one device, SVG_DIST_BACKEND=gloo
     # replaces RCCL (two ranks cannot share a GPU under RCCL); the driver's multi-GPU runs use neither.
@@ -142,7 +167,7 @@ def main():
     cfg = svg_config.load_config(args.config)
     dev = torch.device("cuda", local_rank)
     torch.manual_seed(0)
-    sd_utils = SDUtils(seed=0, verbose=(rank == 0))
+    sd_utils = SDUtils(weights="synthetic", seed=0, verbose=(rank == 0))
     torch.manual_seed(0)
     model = Transformer(num_tokens=0, dim_model=cfg.DIM_MODEL[0], num_heads=cfg.NUM_HEADS[0],
                         num_encoder_layers=cfg.NUM_ENCODER_LAYERS[0], num_decoder_layers=cfg.NUM_DECODER_LAYERS[0],
@@ -159,7 +184,7 @@ def main():
     for _ in range(1, args.streams):
         c2 = _lib.Context(local_rank)
         torch.manual_seed(0)
-        sdu2 = SDUtils(seed=0, verbose=False, ctx=c2)
+        sdu2 = SDUtils(weights="synthetic", seed=0, verbose=False, ctx=c2)
         torch.manual_seed(0)
         m2 = Transformer(num_tokens=0, dim_model=cfg.DIM_MODEL[0], num_heads=cfg.NUM_HEADS[0],
                          num_encoder_layers=cfg.NUM_ENCODER_LAYERS[0], num_decoder_layers=cfg.NUM_DECODER_LAYERS[0],

@@ -24,7 +24,9 @@
  *                             load_state_dict: tensors are handed over by their state_dict names)
  *
  * Conventions
- *   - every function returns 0 on success, <0 on error; svg_last_error() gives the message.
+ *   - every function returns 0 on success, <0 on error (SVG_ERR_INVALID: the arguments / shapes / call order are
+ *     not acceptable — the Python facade raises ValueError; SVG_ERR_RUNTIME: a HIP call or kernel launch failed —
+ *     RuntimeError); svg_last_error() gives the message.
  *   - all device pointers are caller-owned HBM (e.g. torch tensors); the library owns packed
  *     weights and one workspace arena per context, sized at svg_finalize()/first call; no
  *     allocation in steady state.  The library never frees caller memory.
@@ -47,6 +49,7 @@ extern "C" {
 typedef struct svg_ctx svg_ctx;
 
 enum svg_model { SVG_TRANSFORMER = 0, SVG_VAE = 1, SVG_UNET = 2 };
+enum svg_status { SVG_OK = 0, SVG_ERR_RUNTIME = -1, SVG_ERR_INVALID = -2 };
 
 /* ---- context ------------------------------------------------------------------------------ */
 int svg_create(int device_id, svg_ctx** out);

@@ -81,6 +81,8 @@ def main():
     for cfg, kw, dlat, seed in [
         ("config_test", dict(dim_model=256, num_heads=8, num_encoder_layers=6, num_decoder_layers=6, dropout_p=0.1), 1024, 11),
         ("1_16_kitti_L1_64", dict(dim_model=2048, num_heads=8, num_encoder_layers=4, num_decoder_layers=8, dropout_p=0.1), 256, 12),
+        # BASELINE configs[3]: UCF-101, F=128 -> D_lat 1024, d=2048
+        ("11_27_ucf_final", dict(dim_model=2048, num_heads=8, num_encoder_layers=4, num_decoder_layers=8, dropout_p=0.1), 1024, 13),
     ]:
         for mod in [k for k in sys.modules if k.startswith("models") or k.startswith("utils")]:
             del sys.modules[mod]

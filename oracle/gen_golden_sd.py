@@ -1,0 +1,109 @@
+"""Generates tests/golden/sd_*.pt: long CPU-oracle runs of the SD side at the FULL sizes of BASELINE.json's configs, kept
+as small fixtures so that the GPU parity tests need not spend minutes of CPU per run.  These fixtures are outputs of
+THIS repository's oracle (oracle/sd_oracle.py — parity unpinned, see its header: the reference holds no SD fixtures and
+diffusers is not installable here), on seeded weights and CPU-generator noise; nothing of the reference is involved.
+
+    python oracle/gen_golden_sd.py [cfg2] [cfg1] [cfg3]          (~25 min of 8 CPU threads in total)
+
+  sd_cfg2_frame.pt    configs[2]: 1_16_kitti_L1_64, F=64, one clip, ONE predicted frame, --denoise_start_step 0:
+                      50 DDIM steps of the SD-v1.4 UNet at 64x64 latents between the 512x512 VAE passes; keeps the
+                      latent entering the loop and the loop's history at selected steps (per-step drift table)
+  sd_cfg1_rollout.pt  configs[1]: same model, 8 predicted frames, --denoise_start_step 25 (25 steps per frame)
+  sd_cfg3_rollout.pt  configs[3]: 11_27_ucf_final, F=128, 16 predicted frames, start step 48 (2 steps per frame: the
+                      full 50 would be 800 UNet calls)
+
+Conventions shared with tests/test_configs_gpu.py (which rebuilds the same inputs from the same seeds):
+  UNet / VAE weights   SO.seeded_weights(shapes, 31) / (…, 32)
+  latent Transformer   torch.manual_seed(XF_SEED); sd_video_gen_amd.transformer.Transformer(...) (host module: parameters only)
+  clip                 bouncing_ball_clips(1, F, 5, seed=CLIP_SEED)[0]
+  noise                loop_noise(NOISE_SEED, ...) below: one CPU generator per clip, draws in the reference's order
+  text embedding       text_emb(): randn(1,77,768) from a CPU generator, used for uncond and cond ('' twice)
+The oracle's duplicated-batch UNet call (sd_utils.py:249: cat([latents]*2)) is evaluated once and repeated: rows of a
+batch are independent in every op of the oracle, so this is exact and halves the CPU time.
+"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import loop_oracle, sd_oracle as SO  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+HIST_STEPS = [0, 1, 2, 3, 5, 10, 15, 20, 25, 30, 35, 40, 45, 50]
+UNET_SEED, VAE_SEED, XF_SEED, CLIP_SEED, NOISE_SEED, EMB_SEED = 31, 32, 7, 4, 5, 123
+
+
+def loop_noise(seed, F, pred_frames, start_step, res=512, down=8):
+    """the draws of one clip in the order of sample_clips / predict.py: cond; per frame e512, add (S>0), eF"""
+    g = torch.Generator().manual_seed(seed)
+    L = F // down
+    n = {"cond": torch.randn((5, 4, L, L), generator=g), "e512": [], "add": [], "eF": []}
+    for _ in range(pred_frames):
+        n["e512"].append(torch.randn((4, res // 8, res // 8), generator=g))
+        if start_step > 0:
+            n["add"].append(torch.randn((4, res // 8, res // 8), generator=g))
+        n["eF"].append(torch.randn((4, L, L), generator=g))
+    return n
+
+
+def text_emb(seed=EMB_SEED):
+    e = torch.randn((1, 77, 768), generator=torch.Generator().manual_seed(seed))
+    return torch.cat([e, e])
+
+
+def build_transformer(cfg_name, seed=XF_SEED):
+    from sd_video_gen_amd import config as svg_config
+    from sd_video_gen_amd.transformer import Transformer
+    svg_config.set_args(["--dataset", "synthetic-ball", "--config", cfg_name])
+    cfg = svg_config.load_config(cfg_name)
+    torch.manual_seed(seed)
+    m = Transformer(dim_model=cfg.DIM_MODEL[0], num_heads=cfg.NUM_HEADS[0], num_encoder_layers=cfg.NUM_ENCODER_LAYERS[0],
+                    num_decoder_layers=cfg.NUM_DECODER_LAYERS[0], dropout_p=cfg.DROPOUT_P[0]).eval()
+    return m, cfg
+
+
+def run(cfg_name, pred_frames, start_step, out_name, keep_hist):
+    from sd_video_gen_amd.predict import bouncing_ball_clips
+    t0 = time.time()
+    usd = SO.seeded_weights(SO.unet_shapes(), UNET_SEED)
+    vsd = SO.seeded_weights(SO.vae_shapes(), VAE_SEED)
+    m, cfg = build_transformer(cfg_name)
+    xsd = {k: v.detach() for k, v in m.state_dict().items()}
+    F = cfg.FRAME_SIZE
+    clip = bouncing_ball_clips(1, F, 5, seed=CLIP_SEED)[0]
+    noise = loop_noise(NOISE_SEED, F, pred_frames, start_step)
+    emb = text_emb()
+    calls = [0]
+
+    def unet_once(x, t, c):
+        calls[0] += 1
+        e = SO.unet_forward(usd, x[:1], t, c[:1])
+        print("  unet call %d (t=%d) %.0fs" % (calls[0], t, time.time() - t0), flush=True)
+        return torch.cat([e, e])
+    trace = []
+    with torch.no_grad():
+        lat = loop_oracle.sample_clip(xsd, cfg.NUM_HEADS[0], vsd, clip, pred_frames, noise, denoise=True, start_step=start_step,
+                                      unet_sd=usd, text_emb=emb, unet=unet_once, trace=trace)
+    rec = {"config": cfg_name, "pred_frames": pred_frames, "start_step": start_step, "all_latents": lat,
+           "seeds": dict(unet=UNET_SEED, vae=VAE_SEED, xf=XF_SEED, clip=CLIP_SEED, noise=NOISE_SEED, emb=EMB_SEED),
+           "pred": torch.stack([t["pred"] for t in trace]), "unet_calls": calls[0]}
+    if keep_hist:
+        h = trace[0]["hist"]
+        steps = [s for s in HIST_STEPS if s < h.shape[0]]
+        rec.update(lat0=trace[0]["lat0"], hist_steps=steps, hist=h[steps].clone())
+    torch.save(rec, os.path.join(OUT, out_name))
+    print("%s: %d UNet calls, %.0f s, |lat| %.4f" % (out_name, calls[0], time.time() - t0, float(lat.abs().mean())), flush=True)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "6")))
+    which = sys.argv[1:] or ["cfg2", "cfg1", "cfg3"]
+    if "cfg2" in which:
+        run("1_16_kitti_L1_64", 1, 0, "sd_cfg2_frame.pt", True)
+    if "cfg3" in which:
+        run("11_27_ucf_final", 16, 48, "sd_cfg3_rollout.pt", False)
+    if "cfg1" in which:
+        run("1_19_ball_complex_L1_64", 8, 25, "sd_cfg1_rollout.pt", False)

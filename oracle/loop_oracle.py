@@ -18,9 +18,13 @@ from . import transformer_oracle as TO
 
 
 def sample_clip(xf_sd, num_heads, vae_sd, clip_u8, pred_frames, noise, denoise=False, start_step=40, unet_sd=None,
-                text_emb=None, vae_cfg=SO.SD_VAE, unet_cfg=SO.SD_UNET, res=512, num_inference_steps=50, txt=None):
+                text_emb=None, vae_cfg=SO.SD_VAE, unet_cfg=SO.SD_UNET, res=512, num_inference_steps=50, txt=None,
+                guidance_scale=0.0, unet=None, trace=None):
     """clip_u8 (5,F,F,3) uint8 -> all_latents (1, 4+N, D_lat).  `txt` (1,384): the class embedding of the
-    text-conditioned loop (prediction/predict_text.py:186-262 — the same loop with predict(model, X, cls_list))."""
+    text-conditioned loop (prediction/predict_text.py:186-262 — the same loop with predict(model, X, cls_list)).
+    `guidance_scale`: 0 at predict.py:169, 7.5 at evaluation/predict_fvd2_denoise.py:228.  `unet(x, t, ctx)` may stand in
+    for the oracle UNet (fixture generation runs the duplicated batch once).  `trace` (a list) receives, per predicted
+    frame, a dict with the Transformer prediction, the latent entering the DDIM loop and the loop's latent history."""
     T, F = clip_u8.shape[0], clip_u8.shape[1]
     down = 2 ** (len(vae_cfg["block_out"]) - 1)
     L = F // down
@@ -36,8 +40,12 @@ def sample_clip(xf_sd, num_heads, vae_sd, clip_u8, pred_frames, noise, denoise=F
             img = SO.decode_img_latents(vae_sd, pred.reshape(1, 4, L, L), vae_cfg)
             big = SO.resize_nearest_u8(img, res, res)
             lat = SO.encode_img(vae_sd, big, noise["e512"][k][None], vae_cfg)
-            den = SO.gen_i2i_latents(unet_sd, text_emb, lat, num_inference_steps, 0.0, start_step,
-                                     noise=noise["add"][k][None] if start_step > 0 else None, cfg=unet_cfg)
+            hist = SO.gen_i2i_latents(unet_sd, text_emb, lat, num_inference_steps, guidance_scale, start_step,
+                                      noise=noise["add"][k][None] if start_step > 0 else None, cfg=unet_cfg,
+                                      return_all_latents=True, unet=unet)
+            den = hist[-1:]
+            if trace is not None:
+                trace.append({"pred": pred.clone(), "lat0": lat.clone(), "hist": hist.clone()})
             img2 = SO.decode_img_latents(vae_sd, den, vae_cfg)
             small = SO.resize_nearest_u8(img2, F, F)
             pred = SO.encode_img(vae_sd, small, noise["eF"][k][None], vae_cfg).flatten()

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVG_LIB") or os.path.join(_HERE, "libsvg_hip.so")   # $SVG_LIB: A/B another build of the same ABI
 
 SVG_TRANSFORMER, SVG_VAE, SVG_UNET = 0, 1, 2
+SVG_ERR_RUNTIME, SVG_ERR_INVALID = -1, -2        # enum svg_status
 
 _lib = None
 
@@ -97,6 +98,20 @@ class Context:
         if self.lib.svg_create(device_index, C.byref(h)) != 0:
             raise RuntimeError("svg_create: " + self.lib.svg_last_error(None).decode())
         self.h = h
+        self._owner = {}          # model slot -> weakref of the host object whose weights the slot holds
+
+    # ---- slot ownership --------------------------------------------------------------------------
+    # A context has ONE slot per model id; svg_model_configure replaces what is in it.  Host objects that upload
+    # weights claim the slot and check the claim before every forward, so two models sharing a context re-upload
+    # (latent Transformers: the parameters live on the host) or refuse (SD networks) instead of computing with each
+    # other's weights.
+    def claim(self, model, obj):
+        import weakref
+        self._owner[model] = weakref.ref(obj)
+
+    def owner(self, model):
+        r = self._owner.get(model)
+        return r() if r is not None else None
 
     def close(self):
         if getattr(self, "h", None):
@@ -112,9 +127,9 @@ class Context:
     def check(self, rc, what):
         if rc != 0:
             msg = self.lib.svg_last_error(self.h).decode()
-            if "shape" in msg or "missing weight" in msg or "unsupported" in msg or "must be" in msg:
-                raise ValueError("%s: %s" % (what, msg))
-            raise RuntimeError("%s: %s" % (what, msg))
+            # SVG_ERR_INVALID: arguments / shapes / call order (ValueError, like torch's shape errors in the reference);
+            # anything else is a HIP failure
+            raise (ValueError if rc == SVG_ERR_INVALID else RuntimeError)("%s: %s" % (what, msg))
 
     # ---- models ------------------------------------------------------------------------------
     def configure(self, model, **kv):
@@ -122,6 +137,7 @@ class Context:
                      for k, v in kv.items())
         if model == SVG_VAE:
             self.vae_down = 2 ** (len(kv.get("block_out", (128, 256, 512, 512))) - 1)
+        self._owner.pop(model, None)
         self.check(self.lib.svg_model_configure(self.h, model, s.encode()), "svg_model_configure")
 
     def load_state_dict(self, model, sd):

@@ -32,7 +32,7 @@ int svg_model_configure(svg_ctx* ctx, int model, const char* kv) {
     else if (model == SVG_VAE) ctx->vae->configure(kv);
     else ctx->unet->configure(kv);
     return 0;
-  } catch (const std::exception& e) { if (ctx) ctx->err = e.what(); return -1; }
+  } catch (const std::exception& e) { return svg_fail(ctx, e); }
 }
 
 int svg_load_weight(svg_ctx* ctx, int model, const char* name, const float* data, const int64_t* shape, int ndim) {
@@ -45,7 +45,7 @@ int svg_load_weight(svg_ctx* ctx, int model, const char* name, const float* data
     else if (model == SVG_VAE) ctx->vae->ready = false;
     else ctx->unet->ready = false;
     return 0;
-  } catch (const std::exception& e) { if (ctx) ctx->err = e.what(); return -1; }
+  } catch (const std::exception& e) { return svg_fail(ctx, e); }
 }
 
 int svg_finalize(svg_ctx* ctx, int model, int64_t* n_params) {
@@ -62,7 +62,7 @@ int svg_finalize(svg_ctx* ctx, int model, int64_t* n_params) {
     ctx->cur_model = 3;
     HIP_OK(hipDeviceSynchronize());
     return 0;
-  } catch (const std::exception& e) { if (ctx) ctx->err = e.what(); return -1; }
+  } catch (const std::exception& e) { return svg_fail(ctx, e); }
 }
 
 }  // extern "C"

@@ -13,7 +13,13 @@
 typedef __bf16 bf16;
 typedef uint16_t u16;
 
+// SvgError: the caller handed over something the library cannot take (shape, size, missing weight, call order): the
+// C ABI returns SVG_ERR_INVALID (-2) and the Python facade raises ValueError.  SvgHipError: a HIP call or a kernel launch
+// failed: SVG_ERR_RUNTIME (-1), RuntimeError.
 struct SvgError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+struct SvgHipError : std::runtime_error {
   using std::runtime_error::runtime_error;
 };
 
@@ -33,7 +39,7 @@ struct SvgError : std::runtime_error {
       char _b[512];                                                                    \
       snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),  \
                __FILE__, __LINE__);                                                    \
-      throw SvgError(std::string(_b));                                                 \
+      throw SvgHipError(std::string(_b));                                              \
     }                                                                                  \
   } while (0)
 
@@ -115,6 +121,9 @@ struct ProfScope {
   ~ProfScope();
 };
 
+// C-ABI failure path: records the message on the context (or process-wide when there is none) and returns the code
+int svg_fail(svg_ctx* ctx, const std::exception& e);
+
 // Launch guard: in arena-dry mode nothing is launched.
 #define SVG_LAUNCHING(ctx) (!(ctx)->arena.dry)
 
@@ -123,6 +132,6 @@ static inline void check_launch(const char* what) {
   if (e != hipSuccess) {
     char b[256];
     snprintf(b, sizeof(b), "launch of %s failed: %s", what, hipGetErrorString(e));
-    throw SvgError(std::string(b));
+    throw SvgHipError(std::string(b));
   }
 }

@@ -371,11 +371,6 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
 template <int BN, bool PP>
 void launch_halo(const GemmArgs& g, dim3 grid, hipStream_t s) {
   constexpr int smem = 2 * PPIX * 128 + 3 * BN * 128 + 8192;
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_OK(hipFuncSetAttribute((const void*)conv_halo_kernel<BN, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = true;
-  }
   hipLaunchKernelGGL((conv_halo_kernel<BN, PP>), grid, dim3(512), smem, s, g);
 }
 
@@ -405,6 +400,13 @@ int conv_halo_bn(const GemmArgs& g) {
     if (best_cost < 0 || cost < best_cost || (cost == best_cost && pad < best_pad)) { best = bn; best_cost = cost; best_pad = pad; }
   }
   return best;
+}
+
+void conv_halo_init_device() {
+  HIP_OK(hipFuncSetAttribute((const void*)conv_halo_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PPIX * 128 + 3 * 128 * 128 + 8192));
+  HIP_OK(hipFuncSetAttribute((const void*)conv_halo_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PPIX * 128 + 3 * 128 * 128 + 8192));
+  HIP_OK(hipFuncSetAttribute((const void*)conv_halo_kernel<160, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PPIX * 128 + 3 * 160 * 128 + 8192));
+  HIP_OK(hipFuncSetAttribute((const void*)conv_halo_kernel<160, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PPIX * 128 + 3 * 160 * 128 + 8192));
 }
 
 void launch_conv_halo(const GemmArgs& g, dim3 grid, hipStream_t s) {

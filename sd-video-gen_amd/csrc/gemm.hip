@@ -327,11 +327,6 @@ __global__ void pack_geglu_kernel(const float* __restrict__ w, const float* __re
 template <int BN, int AMODE>
 void launch_inst(const GemmArgs& g, dim3 grid, hipStream_t s) {
   constexpr int smem = 2 * (BM * 128 + BN * 128);
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_OK(hipFuncSetAttribute((const void*)igemm_kernel<BN, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = true;
-  }
   hipLaunchKernelGGL((igemm_kernel<BN, AMODE>), grid, dim3(256), smem, s, g);
 }
 
@@ -346,6 +341,18 @@ void launch_bn(const GemmArgs& g, dim3 grid, hipStream_t s) {
     case A_CONV_SMALLC: launch_inst<BN, A_CONV_SMALLC>(g, grid, s); break;
     default: throw SvgError("bad amode");
   }
+}
+
+// dynamic-LDS limits are a per-device function attribute: set for every instantiation when a context is created on a
+// device (svg_create), not lazily behind a process-wide flag (a second device, or two host threads launching at once)
+template <int BN, int AMODE>
+void attr_inst() {
+  HIP_OK(hipFuncSetAttribute((const void*)igemm_kernel<BN, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM * 128 + BN * 128)));
+}
+template <int BN>
+void attr_bn() {
+  attr_inst<BN, A_DENSE>(); attr_inst<BN, A_CONV_S1>(); attr_inst<BN, A_CONV_S2P1>(); attr_inst<BN, A_CONV_S2ASYM>();
+  attr_inst<BN, A_CONV_UP2>(); attr_inst<BN, A_CONV_SMALLC>();
 }
 
 int pick_bn(const GemmArgs& g) {
@@ -371,6 +378,8 @@ int pick_bn(const GemmArgs& g) {
 }
 
 }  // namespace
+
+void gemm_init_device() { attr_bn<32>(); attr_bn<64>(); attr_bn<128>(); attr_bn<160>(); }
 
 void launch_gemm(svg_ctx* ctx, const GemmArgs& g, hipStream_t s, int prof_kind) {
   SVG_CHECK(g.N % 4 == 0 && g.K % 8 == 0, "gemm: N (%d) must be a multiple of 4 and K (%d) of 8", g.N, g.K);

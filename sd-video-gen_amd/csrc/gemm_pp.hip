@@ -155,16 +155,16 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs g) {
 template <int BN>
 void launch_pp(const GemmArgs& g, hipStream_t s) {
   constexpr int smem = 3 * (256 * 128 + BN * 128) + 1024;
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_OK(hipFuncSetAttribute((const void*)gemm_pp_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = true;
-  }
   const int tiles = cdiv(g.M, 256) * cdiv(g.N, BN);
   hipLaunchKernelGGL((gemm_pp_kernel<BN>), dim3(tiles), dim3(512), smem, s, g);
 }
 
 }  // namespace
+
+void gemm_pp_init_device() {
+  HIP_OK(hipFuncSetAttribute((const void*)gemm_pp_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 * 128 + 128 * 128) + 1024));
+  HIP_OK(hipFuncSetAttribute((const void*)gemm_pp_kernel<160>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 * 128 + 160 * 128) + 1024));
+}
 
 int gemm_pp_bn(const GemmArgs& g) {
   if (g.act == ACT_GEGLU) return 128;

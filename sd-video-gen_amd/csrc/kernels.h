@@ -54,6 +54,10 @@ struct GemmArgs {
 };
 
 void launch_gemm(svg_ctx* ctx, const GemmArgs& g, hipStream_t s, int prof_kind);
+// per-device kernel attributes (dynamic LDS limits) of every instantiation; called by svg_create after hipSetDevice
+void gemm_init_device();
+void gemm_pp_init_device();
+void conv_halo_init_device();
 // picks split-K from the shape, allocates slabs from the arena, launches
 void gemm_auto(svg_ctx* ctx, GemmArgs g, hipStream_t s, int prof_kind);
 

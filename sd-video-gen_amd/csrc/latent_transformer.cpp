@@ -197,10 +197,7 @@ extern "C" int svg_transformer_forward_text(svg_ctx* ctx, const float* src, cons
     SVG_CHECK(ctx && ctx->xf, "transformer: model not configured");
     ctx->xf->forward(ctx, src, tgt, B, Ts, Tt, mask, pe_row, out, (hipStream_t)stream, text);
     return 0;
-  } catch (const std::exception& e) {
-    if (ctx) ctx->err = e.what();
-    return -1;
-  }
+  } catch (const std::exception& e) { return svg_fail(ctx, e); }
 }
 
 extern "C" int svg_transformer_forward(svg_ctx* ctx, const float* src, const float* tgt, int B, int Ts, int Tt, const float* mask,
@@ -209,8 +206,5 @@ extern "C" int svg_transformer_forward(svg_ctx* ctx, const float* src, const flo
     SVG_CHECK(ctx && ctx->xf, "transformer: model not configured");
     ctx->xf->forward(ctx, src, tgt, B, Ts, Tt, mask, pe_row, out, (hipStream_t)stream);
     return 0;
-  } catch (const std::exception& e) {
-    if (ctx) ctx->err = e.what();
-    return -1;
-  }
+  } catch (const std::exception& e) { return svg_fail(ctx, e); }
 }

@@ -9,6 +9,11 @@ const char* kProfNames[PK_COUNT] = {"gemm", "conv3x3", "attention", "groupnorm",
 
 static std::string g_err;   // errors without a context
 
+int svg_fail(svg_ctx* ctx, const std::exception& e) {
+  if (ctx) ctx->err = e.what(); else g_err = e.what();
+  return dynamic_cast<const SvgError*>(&e) ? SVG_ERR_INVALID : SVG_ERR_RUNTIME;
+}
+
 void* svg_ctx::dalloc(int64_t bytes) {
   void* p = nullptr;
   HIP_OK(hipMalloc(&p, (size_t)std::max<int64_t>(bytes, 256)));
@@ -133,10 +138,7 @@ std::unordered_map<std::string, std::vector<int64_t>> parse_kv(const char* kv) {
 #define API_END(ctx)                                   \
   return 0;                                            \
   }                                                    \
-  catch (const std::exception& e) {                    \
-    if (ctx) (ctx)->err = e.what(); else g_err = e.what(); \
-    return -1;                                         \
-  }
+  catch (const std::exception& e) { return svg_fail(ctx, e); }
 
 extern "C" {
 
@@ -154,6 +156,9 @@ int svg_create(int device_id, svg_ctx** out) {
   HIP_OK(hipGetDeviceProperties(&prop, device_id));
   SVG_CHECK(std::string(prop.gcnArchName).find("gfx950") != std::string::npos,
             "svg_create: this library is built for gfx950 only, device reports %s", prop.gcnArchName);
+  gemm_init_device();
+  gemm_pp_init_device();
+  conv_halo_init_device();
   ctx = new svg_ctx();
   ctx->device = device_id;
   ctx->prof_entries.resize(PK_COUNT);

@@ -121,6 +121,7 @@ void linear(svg_ctx* ctx, const bf16* A, int lda, const PackedLinear& pl, void* 
     const int64_t per_row = std::max<int64_t>(lda, std::max(ldc, ldr));
     if ((int64_t)M * per_row > lim && M > 1) {
       const int chunk = (int)(lim / per_row) & ~255;
+      SVG_CHECK(chunk >= 256, "linear: a %lld-element operand limit is below one 256-row slab of %lld-wide rows", (long long)lim, (long long)per_row);
       const int csz = out_f32 ? 4 : 2;
       for (int m0 = 0; m0 < M; m0 += chunk)
         linear(ctx, A + (int64_t)m0 * lda, lda, pl, (char*)C + (int64_t)m0 * ldc * csz, ldc, std::min(chunk, M - m0), act,

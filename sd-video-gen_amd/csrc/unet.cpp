@@ -486,7 +486,7 @@ int svg_unet_forward(svg_ctx* ctx, const float* x, int N, int h, int w, const fl
     SVG_CHECK(ctx && ctx->unet, "unet: model not configured");
     run_planned(ctx, [&]() { ctx->unet->forward(ctx, x, N, h, w, timesteps, ctx_emb, ctx_len, eps_out, (hipStream_t)stream); });
     return 0;
-  } catch (const std::exception& e) { if (ctx) ctx->err = e.what(); return -1; }
+  } catch (const std::exception& e) { return svg_fail(ctx, e); }
 }
 int svg_ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const float* text_emb, int ctx_len, int num_steps, int start_step,
                   float guidance, const float* noise, float* hist, void* stream) {
@@ -494,7 +494,7 @@ int svg_ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const float* text
     SVG_CHECK(ctx && ctx->unet, "unet: model not configured");
     ctx->unet->ddim_loop(ctx, z, N, h, w, text_emb, ctx_len, num_steps, start_step, guidance, noise, hist, (hipStream_t)stream);
     return 0;
-  } catch (const std::exception& e) { if (ctx) ctx->err = e.what(); return -1; }
+  } catch (const std::exception& e) { return svg_fail(ctx, e); }
 }
 int svg_ddim_step(svg_ctx* ctx, const float* x, const float* eps, float* prev, int64_t n, int t, int t_prev, void* stream) {
   try {
@@ -503,6 +503,6 @@ int svg_ddim_step(svg_ctx* ctx, const float* x, const float* eps, float* prev, i
     ctx->unet->ddim_coefs(t, t_prev, &sa, &s1a, &sap, &s1ap);
     ddim_step(x, eps, nullptr, 0.f, prev, n, sa, s1a, sap, s1ap, (hipStream_t)stream);
     return 0;
-  } catch (const std::exception& e) { if (ctx) ctx->err = e.what(); return -1; }
+  } catch (const std::exception& e) { return svg_fail(ctx, e); }
 }
 }

@@ -260,7 +260,7 @@ int svg_vae_encode(svg_ctx* ctx, const uint8_t* img, int N, int srcH, int srcW, 
     SVG_CHECK(ctx && ctx->vae, "vae: model not configured");
     ctx->vae->encode(ctx, img, N, srcH, srcW, H, W, eps, z_out, moments_out, (hipStream_t)stream);
     return 0;
-  } catch (const std::exception& e) { if (ctx) ctx->err = e.what(); return -1; }
+  } catch (const std::exception& e) { return svg_fail(ctx, e); }
 }
 int svg_vae_decode(svg_ctx* ctx, const float* z, int N, int h, int w, uint8_t* img_out, int outH, int outW, float* float_out,
                    void* stream) {
@@ -268,6 +268,6 @@ int svg_vae_decode(svg_ctx* ctx, const float* z, int N, int h, int w, uint8_t* i
     SVG_CHECK(ctx && ctx->vae, "vae: model not configured");
     ctx->vae->decode(ctx, z, N, h, w, img_out, outH, outW, float_out, (hipStream_t)stream);
     return 0;
-  } catch (const std::exception& e) { if (ctx) ctx->err = e.what(); return -1; }
+  } catch (const std::exception& e) { return svg_fail(ctx, e); }
 }
 }

@@ -26,13 +26,13 @@ def predict(model, input_sequence, pe_row=None, cls_list=None):
 
 def clip_noise(seeds, shape, device):
     """One standard-normal draw of `shape` per clip from that clip's own generator, stacked: results do not
-    depend on how clips are batched or sharded over ranks."""
-    return torch.stack([torch.randn(shape, generator=g, device=device) for g in seeds])
+    depend on how clips are batched or sharded over ranks.  (Host generators draw on the host and are copied over.)"""
+    return torch.stack([torch.randn(shape, generator=g, device=g.device) for g in seeds]).to(device)
 
 
 def sample_clips(model, sd_utils, clips_u8, pred_frames, denoise=False, start_step=40, seeds=None,
                  text_embeddings=None, num_inference_steps=50, guidance_scale=0.0, return_frames=False, res=512,
-                 cls_list=None):
+                 cls_list=None, cpu_noise=False):
     """The per-clip loop of prediction/predict.py:117-197 for C independent clips in lock step, device resident.
 
     clips_u8: (C,5,F,F,3) uint8 conditioning frames on the device.  Every stage is batched over clips; a clip's
@@ -42,6 +42,8 @@ def sample_clips(model, sd_utils, clips_u8, pred_frames, denoise=False, start_st
     (decode -> numpy -> tensor -> interpolate, twice) become fused on-device uint8 nearest resizes with identical
     rounding.  ``cls_list`` (one class name per clip, or a (C,384) tensor) selects the text-conditioned loop of
     prediction/predict_text.py:186-262 (same loop, `predict(model, X, cls_list)`); the names are encoded once.
+    ``cpu_noise``: the per-clip generators live on the host (bit-reproducible on a machine without the GPU: the committed
+    oracle fixtures of tests/golden/sd_*.pt were drawn that way); default is the device generator, like the reference.
     Returns all_latents (C, 4+N, D_lat) f32 [and the decoded frames (C,4+N,F,F,3) uint8].
     """
     ctx = sd_utils.ctx
@@ -52,7 +54,7 @@ def sample_clips(model, sd_utils, clips_u8, pred_frames, denoise=False, start_st
     D = 4 * L * L
     if seeds is None:
         seeds = list(range(C))
-    gens = [torch.Generator(device=dev).manual_seed(int(s)) for s in seeds]
+    gens = [torch.Generator(device="cpu" if cpu_noise else dev).manual_seed(int(s)) for s in seeds]
     model.eval()
     with torch.no_grad():
         eps = clip_noise(gens, (T, 4, L, L), dev).reshape(C * T, 4, L, L)
@@ -95,7 +97,10 @@ def sample_clips_streams(workers, clips_u8, pred_frames, seeds, **kw):
     """Run `sample_clips` on several (model, sd_utils, stream) workers at once: the clips are split into contiguous
     groups, each group is driven by its own host thread on its own HIP stream and library context (full weight
     replica each), so kernels of different groups can share the GPU (ALU/HBM-bound normalisation and softmax work of
-    one group under the MFMA-bound convs of another).  Results are identical to one call on all clips."""
+    one group under the MFMA-bound convs of another).  Results equal one call on all clips up to the bf16 rounding that a
+    different rows-per-launch count brings (tile width / split-K selection: measured <= 1e-2 rel-L2 on the full-size UNet,
+    tests/test_fullsize_gpu.py); the f32 latent-Transformer part is bitwise equal.  ``text_embeddings`` of per-clip form
+    (2*C rows: [uncond(C); cond(C)]) are sliced per group."""
     import threading
     n = clips_u8.shape[0]
     G = len(workers)
@@ -108,9 +113,16 @@ def sample_clips_streams(workers, clips_u8, pred_frames, seeds, **kw):
         try:
             model, sdu, stream = workers[g]
             a, b = bounds[g], bounds[g + 1]
+            kwg = dict(kw)
+            emb = kwg.get("text_embeddings")
+            if emb is not None and emb.shape[0] == 2 * n and n > 1:      # per-clip embeddings: this group's rows of each half
+                kwg["text_embeddings"] = torch.cat([emb[a:b], emb[n + a:n + b]])
+            cl = kwg.get("cls_list")
+            if cl is not None:
+                kwg["cls_list"] = cl[a:b]
             stream.wait_stream(cur)
             with torch.cuda.stream(stream):
-                out[g] = sample_clips(model, sdu, clips_u8[a:b], pred_frames, seeds=seeds[a:b], **kw)
+                out[g] = sample_clips(model, sdu, clips_u8[a:b], pred_frames, seeds=seeds[a:b], **kwg)
         except Exception as e:      # surfaced on the caller's thread
             errs.append(e)
     threads = [threading.Thread(target=run, args=(g,)) for g in range(G) if bounds[g + 1] > bounds[g]]
@@ -171,6 +183,18 @@ def rollout_latents(model, new_batch, pred_frames, post=None):
     return all_latents, trace
 
 
+def run_sharded(clips, sample_fn, base_seed=0):
+    """The N>1 form of the per-clip loop: rank r samples clips ``shard_range(n, r, W)`` with per-clip seeds
+    ``base_seed + clip`` (world-size invariant) through ``sample_fn(clips_local, seeds) -> tuple of per-clip tensors``,
+    then ONE all-gather reassembles every output in clip order on every rank.  World size 1: no collective."""
+    from . import sharding
+    rank, ws = sharding.world()
+    n = clips.shape[0]
+    a, b = sharding.shard_range(n, rank, ws)
+    out = sample_fn(clips[a:b], sharding.clip_seeds(base_seed, a, b))
+    return sharding.gather_clips_packed(list(out), n)
+
+
 # ---- `python -m prediction.predict` (reference prediction/predict.py:44-247) ---------------------------------------
 def _png_clips(folder, frame_size, n_frames=5):
     """Fixed-length clips of consecutive PNG frames under `folder` (one clip per sub-directory run), BGR like cv2.imread."""
@@ -218,8 +242,10 @@ def main(argv=None):
     config, args = svg_config.parse_config_args()
     if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
+        # SVG_DEVICE_OVERRIDE / SVG_DIST_BACKEND=gloo: rehearsal of the N>1 path on a one-GPU box (as in bench.py)
+        torch.cuda.set_device(int(os.environ.get("SVG_DEVICE_OVERRIDE", os.environ.get("LOCAL_RANK", "0"))))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("SVG_DIST_BACKEND", "nccl"))
     rank, ws = sharding.world()
     sd_utils = SDUtils(verbose=(rank == 0))
     device = sd_utils.device
@@ -227,10 +253,16 @@ def main(argv=None):
                         num_encoder_layers=config.NUM_ENCODER_LAYERS[0], num_decoder_layers=config.NUM_DECODER_LAYERS[0],
                         dropout_p=config.DROPOUT_P[0])
     ckpt = "./checkpoints/" + str(args.config) + "_" + str(args.index) + "_" + str(args.mode) + ".pt"     # predict.py:51
+    from .sd_utils import synthetic_allowed
     if os.path.exists(ckpt):
         model.load_state_dict(torch.load(ckpt, map_location="cpu"))
-    elif rank == 0:
-        print("[sd-video-gen] checkpoint %s not found: sampling with the seeded initial weights" % ckpt)
+        weights_source = ckpt
+    elif synthetic_allowed():
+        weights_source = "initial (seeded) parameters — SVG_ALLOW_SYNTHETIC_WEIGHTS"
+    else:
+        raise FileNotFoundError(ckpt)          # as torch.load(checkpoint_path) does in the reference (predict.py:52)
+    if rank == 0:
+        print("[sd-video-gen] weights: transformer=%s vae=%s unet=%s" % (weights_source, sd_utils.vae_source, sd_utils.unet_source))
     model.eval()
     F = config.FRAME_SIZE
     if args.dataset in ("synthetic-ball", "synthetic"):
@@ -242,11 +274,9 @@ def main(argv=None):
     else:
         raise ValueError("Invalid dataset name")                                                          # predict.py:70
     n = clips.shape[0]
-    a, b = sharding.shard_range(n, rank, ws)
-    out = sample_clips(model, sd_utils, clips[a:b].to(device), args.pred_frames, denoise=bool(args.denoise),
-                       start_step=args.denoise_start_step, seeds=sharding.clip_seeds(0, a, b), return_frames=True)
-    lat = sharding.gather_clips(out[0], n)
-    frames = sharding.gather_clips(out[1], n)
+    lat, frames = run_sharded(clips, lambda c, seeds: sample_clips(
+        model, sd_utils, c.to(device), args.pred_frames, denoise=bool(args.denoise), start_step=args.denoise_start_step,
+        seeds=seeds, return_frames=True))                          # ends in the ONE collective of the path
     if rank == 0:
         print("all_latents shape: ", tuple(lat.shape))
         if args.save_output:

@@ -4,10 +4,10 @@ attributes and method contracts; the numerics run in libsvg_hip.so (HIP, gfx950)
 Weights: the reference fetches 'CompVis/stable-diffusion-v1-4' and 'openai/clip-vit-large-patch14' from the
 HF hub by name (sd_utils.py:52-66) — unreachable offline.  Here, in order: an explicit ``weights=`` dict of
 diffusers-named state_dicts, a local directory in ``$SVG_SD_WEIGHTS`` (``vae/`` and ``unet/`` holding
-``diffusion_pytorch_model.bin|.safetensors``), else seeded synthetic weights of the exact SD v1.4
-architecture (a notice is printed).  The CLIP text encoder produces an INPUT of this path; without its
-weights ``encode_text`` returns a seeded (2n,77,768) stand-in, or real embeddings handed in via
-``text_embeddings=``.
+``diffusion_pytorch_model.bin|.safetensors``).  When neither provides a network the constructor RAISES like the
+reference's failed ``from_pretrained`` — seeded synthetic weights of the exact SD v1.4 architecture are an explicit
+opt-in (``weights='synthetic'``, a ``'synthetic'`` entry in the dict, or ``SVG_ALLOW_SYNTHETIC_WEIGHTS=1``) used by the
+bench, the smoke test and the parity tests; ``vae_source`` / ``unet_source`` record where each network came from.
 """
 import os
 
@@ -31,12 +31,62 @@ def _load_local(dirname, sub):
     return None
 
 
-class _VAE:
-    """Stands where ``SDUtils.vae`` (diffusers AutoencoderKL) stands: encode(x).sample() / decode(z)."""
+def synthetic_allowed():
+    return os.environ.get("SVG_ALLOW_SYNTHETIC_WEIGHTS", "0") not in ("", "0")
+
+
+def _local_arch(dirname, sub):
+    """Architecture overrides from a diffusers-format ``<sub>/config.json`` (what from_pretrained reads), or {}."""
+    import json
+    p = os.path.join(dirname, sub, "config.json")
+    if not os.path.exists(p):
+        return {}
+    with open(p) as f:
+        c = json.load(f)
+    a = {}
+    if "block_out_channels" in c:
+        a["block_out"] = tuple(c["block_out_channels"])
+    if "layers_per_block" in c:
+        a["layers"] = int(c["layers_per_block"])
+    if "norm_num_groups" in c:
+        a["groups"] = int(c["norm_num_groups"])
+    if sub == "vae":
+        if "latent_channels" in c:
+            a["latent"] = int(c["latent_channels"])
+    else:
+        if "attention_head_dim" in c:
+            a["heads"] = int(c["attention_head_dim"])           # diffusers 0.2.x: the NUMBER of heads (SURVEY A.2)
+        if "cross_attention_dim" in c:
+            a["ctx_dim"] = int(c["cross_attention_dim"])
+        if "down_block_types" in c:
+            a["attn"] = tuple(1 if "CrossAttn" in t else 0 for t in c["down_block_types"])
+        for k_json, k in (("in_channels", "in_ch"), ("out_channels", "out_ch")):
+            if k_json in c:
+                a[k] = int(c[k_json])
+    return a
+
+
+class _Slot:
+    """A network living in a model slot of a library context.  The slot holds one model: if someone else configured it
+    since (a second SDUtils handed the same context), calls fail loudly instead of computing with foreign weights."""
+    slot = None
 
     def __init__(self, ctx, n_params):
-        self.ctx = ctx
+        self._ctx = ctx
         self.n_params = n_params
+        ctx.claim(self.slot, self)
+
+    @property
+    def ctx(self):
+        if self._ctx.owner(self.slot) is not self:
+            raise RuntimeError("the %s slot of this library context now holds another model's weights; give each SDUtils "
+                               "its own context (SDUtils(ctx=_lib.Context(dev)))" % type(self).__name__.strip("_"))
+        return self._ctx
+
+
+class _VAE(_Slot):
+    """Stands where ``SDUtils.vae`` (diffusers AutoencoderKL) stands: encode(x).sample() / decode(z)."""
+    slot = _lib.SVG_VAE
 
     class _Posterior:
         def __init__(self, ctx, imgs_u8):
@@ -59,12 +109,9 @@ class _VAE:
         return self.ctx.vae_decode(z * SCALE, return_float=True)[1]
 
 
-class _UNet:
+class _UNet(_Slot):
     in_channels = 4
-
-    def __init__(self, ctx, n_params):
-        self.ctx = ctx
-        self.n_params = n_params
+    slot = _lib.SVG_UNET
 
     def __call__(self, sample, timestep, encoder_hidden_states=None):
         return {"sample": self.ctx.unet_forward(sample, timestep, encoder_hidden_states)}
@@ -76,13 +123,23 @@ class SDUtils():
         self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
         if self.device.type != "cuda":
             raise RuntimeError("SDUtils runs on the HIP library and needs a GPU (gfx950); there is no CPU fallback")
-        self.ctx = ctx if ctx is not None else _lib.default_context()
+        if ctx is None:
+            ctx = _lib.default_context()
+            # the default context's SD slots are taken by a live SDUtils: this instance gets a context of its own
+            # (a full weight replica; 288 GB of HBM make that the cheap answer) instead of replacing the other's weights
+            if ctx.owner(_lib.SVG_VAE) is not None or ctx.owner(_lib.SVG_UNET) is not None:
+                ctx = _lib.Context(ctx.device.index)
+        self.ctx = ctx
         self._seed = seed
         self._verbose = verbose
         self._text_embeddings = text_embeddings
         # `arch` overrides the SD v1.4 widths (reduced-size parity tests): {'vae': {...}, 'unet': {...}}
-        self.vae_arch = dict(sd_layout.SD_VAE, **((arch or {}).get('vae', {})))
-        self.unet_arch = dict(sd_layout.SD_UNET, **((arch or {}).get('unet', {})))
+        # (a local diffusers directory's config.json plays the same role, as it does for from_pretrained)
+        local = os.environ.get("SVG_SD_WEIGHTS")
+        self.vae_arch = dict(sd_layout.SD_VAE, **(_local_arch(local, "vae") if local else {}))
+        self.unet_arch = dict(sd_layout.SD_UNET, **(_local_arch(local, "unet") if local else {}))
+        self.vae_arch.update((arch or {}).get('vae', {}))
+        self.unet_arch.update((arch or {}).get('unet', {}))
         vae, tokenizer, text_encoder, unet, scheduler = self.load_models(weights)
         self.vae = vae
         # sd_utils.py:30 builds a default-size Transformer and throws it away; it consumes CPU RNG, which matters
@@ -97,15 +154,26 @@ class SDUtils():
 
     # ---- sd_utils.py:39-76 ---------------------------------------------------------------------------
     def _weights_for(self, name, given, shapes_fn, seed):
-        if given is not None and name in given:
-            return given[name], "given"
+        synthetic = given == "synthetic" or synthetic_allowed()
+        if isinstance(given, dict) and name in given:
+            if not isinstance(given[name], str):
+                return given[name], "given"
+            if given[name] != "synthetic":
+                raise ValueError("weights['%s'] must be a state_dict or 'synthetic'" % name)
+            synthetic = True
         d = os.environ.get("SVG_SD_WEIGHTS")
         if d:
             sd = _load_local(d, name)
             if sd is not None:
                 return sd, "local:" + d
+        if not synthetic:
+            # the reference's from_pretrained raises here too (sd_utils.py:52-66 with no hub access)
+            raise FileNotFoundError(
+                "no %s weights: set $SVG_SD_WEIGHTS to a diffusers-format directory (%s/diffusion_pytorch_model.safetensors|.bin), "
+                "pass weights={'%s': state_dict}, or opt in to seeded synthetic weights (weights='synthetic' or "
+                "SVG_ALLOW_SYNTHETIC_WEIGHTS=1)" % (name, name, name))
         if self._verbose:
-            print("[sd-video-gen] no %s weights available offline: using seeded synthetic weights (seed %d)" % (name, seed))
+            print("[sd-video-gen] %s: seeded SYNTHETIC weights (seed %d) — outputs are not images" % (name, seed))
         return sd_layout.seeded_weights(shapes_fn(), seed, device=self.device), "synthetic"
 
     def load_models(self, weights=None):
@@ -116,6 +184,7 @@ class SDUtils():
         ctx.load_state_dict(_lib.SVG_VAE, sd)
         vae = _VAE(ctx, ctx.finalize(_lib.SVG_VAE))
         del sd
+        self.unet_source = None
         if not self.args.denoise:
             return vae, None, None, None, None
         c = self.unet_arch
@@ -133,6 +202,10 @@ class SDUtils():
         prompt string ('' included), so equal prompts give equal embeddings as the real encoder would."""
         if self._text_embeddings is not None:
             return self._text_embeddings.to(self.device)
+        if self.unet_source not in (None, "synthetic"):
+            # real UNet weights conditioned on a random stand-in would silently diverge from the reference's CLIP('')
+            raise RuntimeError("encode_text: real UNet weights (%s) need real CLIP embeddings — pass text_embeddings= "
+                               "to SDUtils (the CLIP text model's weights are not available)" % self.unet_source)
         import zlib
 
         def emb(p):

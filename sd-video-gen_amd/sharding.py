@@ -44,3 +44,21 @@ def gather_clips(local, n_clips):
     out = [torch.empty_like(pad) for _ in range(ws)]
     dist.all_gather(out, pad)
     return torch.cat([o[: b - a] for o, (a, b) in zip(out, sizes)]).to(dev)
+
+
+def gather_clips_packed(tensors, n_clips):
+    """Several per-clip tensors (same leading clip dimension, any dtypes) in ONE all_gather: each clip's payloads are
+    viewed as bytes and laid side by side, gathered once, and split back (predict.main: latents f32 + frames u8)."""
+    rank, ws = world()
+    if ws == 1:
+        return list(tensors)
+    c = tensors[0].shape[0]
+    widths = [int(torch.tensor(t.shape[1:]).prod()) * t.element_size() for t in tensors]
+    flat = [t.contiguous().reshape(c, w // t.element_size()).view(torch.uint8) for t, w in zip(tensors, widths)]
+    out = gather_clips(torch.cat(flat, dim=1), n_clips)
+    res, off = [], 0
+    for t, w in zip(tensors, widths):
+        piece = out[:, off:off + w].contiguous().view(t.dtype).reshape((n_clips,) + tuple(t.shape[1:]))
+        res.append(piece)
+        off += w
+    return res

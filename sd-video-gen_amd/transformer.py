@@ -65,7 +65,9 @@ class Transformer(nn.Module):
 
     def _sync_weights(self):
         ctx = getattr(self, "_bound_ctx", None) or _lib.default_context()
-        if self._ctx is ctx and self._uploaded_version == self._version():
+        # the context's Transformer slot may have been taken by another module (another checkpoint, the text variant)
+        # since the last call: upload again unless the slot still holds THIS module's current parameters
+        if self._ctx is ctx and ctx.owner(_lib.SVG_TRANSFORMER) is self and self._uploaded_version == self._version():
             return ctx
         self._ctx = ctx
         ctx.configure(_lib.SVG_TRANSFORMER, d_lat=self.d_lat, d_model=self.dim_model, heads=self.num_heads,
@@ -73,6 +75,7 @@ class Transformer(nn.Module):
                       ffn=self.transformer.encoder.layers[0].linear1.out_features if self.num_encoder_layers else 2048)
         ctx.load_state_dict(_lib.SVG_TRANSFORMER, self.state_dict())
         self.n_params = ctx.finalize(_lib.SVG_TRANSFORMER)
+        ctx.claim(_lib.SVG_TRANSFORMER, self)
         self._uploaded_version = self._version()
         return ctx
 

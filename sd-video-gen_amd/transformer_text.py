@@ -61,7 +61,9 @@ class Transformer(nn.Module):
 
     def _sync_weights(self):
         ctx = getattr(self, "_bound_ctx", None) or _lib.default_context()
-        if self._ctx is ctx and self._uploaded_version == self._version():
+        # the context's Transformer slot may have been taken by another module (another checkpoint, the text variant)
+        # since the last call: upload again unless the slot still holds THIS module's current parameters
+        if self._ctx is ctx and ctx.owner(_lib.SVG_TRANSFORMER) is self and self._uploaded_version == self._version():
             return ctx
         self._ctx = ctx
         ctx.configure(_lib.SVG_TRANSFORMER, d_lat=self.d_lat, d_model=self.dim_model, heads=self.num_heads,
@@ -69,11 +71,17 @@ class Transformer(nn.Module):
                       ffn=self.transformer.encoder.layers[0].linear1.out_features if self.num_encoder_layers else 2048)
         ctx.load_state_dict(_lib.SVG_TRANSFORMER, self.state_dict())
         self.n_params = ctx.finalize(_lib.SVG_TRANSFORMER)
+        ctx.claim(_lib.SVG_TRANSFORMER, self)
         self._uploaded_version = self._version()
         return ctx
 
-    def load_state_dict(self, *a, **k):
-        r = super().load_state_dict(*a, **k)
+    def load_state_dict(self, state_dict, *a, **k):
+        """Reference checkpoints are ``model.state_dict()`` of models/transformer_text.py, whose ``sent_transformer``
+        attribute (transformer_text.py:44) is an nn.Module: they carry ``sent_transformer.*`` keys (the MiniLM weights).
+        Those belong to the class-name encoder — an input of this path — not to this module: they are dropped here
+        (hand them to a ``text_encoder=`` callable instead), so reference checkpoints load under strict=True."""
+        state_dict = {n: t for n, t in state_dict.items() if not n.startswith("sent_transformer.")}
+        r = super().load_state_dict(state_dict, *a, **k)
         self._uploaded_version = None
         return r
 

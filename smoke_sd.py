@@ -1,10 +1,11 @@
-"""smoke() leg for the SD side: one tiny denoised frame (reduced-width VAE/UNet of the SD architecture, 2 DDIM
-steps) through the C ABI on cuda:0, checked against the CPU oracle."""
+"""smoke() leg for the SD side (imported by __graft_entry__.smoke only — it uses the oracle as the checker, so it lives
+outside the product package): one tiny denoised frame (reduced-width VAE/UNet of the SD architecture, 2 DDIM steps)
+through the C ABI on cuda:0, checked against the CPU oracle."""
 import torch
 
 
 def run():
-    from . import _lib
+    from sd_video_gen_amd import _lib
     from oracle import sd_oracle as SO
     ctx = _lib.default_context()
     ucfg = dict(block_out=(64, 128), layers=1, heads=4, ctx_dim=64, groups=32, in_ch=4, out_ch=4, attn=(1, 0))

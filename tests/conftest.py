@@ -27,3 +27,31 @@ def rel_l2(a, b):
     a = a.double().flatten()
     b = b.double().flatten()
     return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+# ---- measured parity margins -----------------------------------------------------------------------------------------
+# Network-level tests report what they measured through `margin(name, err, tol)`: the value is printed (pytest -s / the
+# captured-output section of a failure), asserted against its tolerance, and the whole table is written to
+# gpurun_out/parity_margins.json at the end of the session (copied into profiles/ per round).
+_MARGINS = []
+
+
+def margin(name, err, tol, unit="rel-L2"):
+    err = float(err)
+    _MARGINS.append({"name": name, "measured": err, "tolerance": float(tol), "unit": unit})
+    print("[parity] %-62s %s %.3e   (tolerance %.1e, margin x%.1f)" % (name, unit, err, tol, tol / max(err, 1e-30)))
+    assert err < tol, "%s: %s %.3e >= tolerance %.1e" % (name, unit, err, tol)
+    return err
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _MARGINS:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_margins.json"), "w") as f:
+            json.dump(_MARGINS, f, indent=1)
+    except OSError:
+        pass

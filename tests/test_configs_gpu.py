@@ -1,0 +1,161 @@
+"""GPU: BASELINE.json's configs at FULL size and FULL length against the CPU oracle.
+
+The long oracle runs (50 DDIM steps; 8- and 16-frame autoregressive rollouts with the denoise round trip) were made once
+with oracle/gen_golden_sd.py and are kept as small fixtures (tests/golden/sd_*.pt): these tests rebuild the same seeded
+weights, clip and CPU-generator noise, run the HIP path through the C ABI, and compare.  Every measured error is reported
+through conftest.margin (printed, and collected into gpurun_out/parity_margins.json -> profiles/).
+
+  configs[1]  1_19_ball_complex_L1_64, F=64, 8 predicted frames, --denoise --denoise_start_step 25      sd_cfg1_rollout.pt
+  configs[2]  1_16_kitti_L1_64, F=64, 50-step DDIM at 64x64 latents, 512x512 VAE passes                 sd_cfg2_frame.pt
+  configs[3]  11_27_ucf_final, F=128, 16 predicted frames (start step 48: 2 of the 50 steps per frame)  sd_cfg3_rollout.pt
+  configs[4]  11_27_ucf_text_final: d = 2432 text-conditioned Transformer; guidance_scale 7.5 => the batch-2 UNet call of
+              evaluation/predict_fvd2_denoise.py:227-229 is genuinely needed (in-test oracle, a few UNet calls)
+Tolerances are <= 3x what was measured on MI355X (bf16 storage with f32 accumulation against the fp32 oracle).
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+from conftest import margin, rel_l2
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import gen_golden_sd as GG, sd_oracle as SO, transformer_oracle as TO  # noqa: E402
+from sd_video_gen_amd import _lib  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def gold(name):
+    p = os.path.join(GOLD, name)
+    if not os.path.exists(p):
+        pytest.skip("fixture %s not generated (python oracle/gen_golden_sd.py)" % name)
+    return torch.load(p, weights_only=False)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _threads():
+    n = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    yield
+    torch.set_num_threads(n)
+
+
+@pytest.fixture(scope="module")
+def nets():
+    """the seeded full-size SD v1.4 networks of the fixtures (UNet seed 31, VAE seed 32)"""
+    usd = SO.seeded_weights(SO.unet_shapes(), GG.UNET_SEED)
+    vsd = SO.seeded_weights(SO.vae_shapes(), GG.VAE_SEED)
+    return usd, vsd
+
+
+def _sdu(cfg_name, nets):
+    from sd_video_gen_amd import config as svg_config
+    from sd_video_gen_amd.sd_utils import SDUtils
+    svg_config.set_args(["--dataset", "synthetic-ball", "--config", cfg_name, "--denoise", "1"])
+    usd, vsd = nets
+    return SDUtils(weights={"vae": vsd, "unet": usd}, verbose=False)
+
+
+def _rollout(cfg_name, g, nets):
+    from sd_video_gen_amd.predict import sample_clips, bouncing_ball_clips
+    sdu = _sdu(cfg_name, nets)
+    m, cfg = GG.build_transformer(cfg_name)
+    clip = bouncing_ball_clips(1, cfg.FRAME_SIZE, 5, seed=GG.CLIP_SEED)
+    lat = sample_clips(m, sdu, clip.cuda(), g["pred_frames"], denoise=True, start_step=g["start_step"], seeds=[GG.NOISE_SEED],
+                       text_embeddings=GG.text_emb().cuda(), cpu_noise=True)
+    assert lat.shape == g["all_latents"].shape and torch.isfinite(lat).all()
+    return lat.cpu(), sdu
+
+
+def test_config2_full_frame_50_steps(ctx, nets):
+    """configs[2] end to end for one generated frame, and the per-step drift of the 50-step DDIM loop."""
+    g = gold("sd_cfg2_frame.pt")
+    lat, sdu = _rollout("1_16_kitti_L1_64", g, nets)
+    margin("cfg2 conditioning latents (VAE encode @64)", rel_l2(lat[:, :4], g["all_latents"][:, :4]), 1.5e-2)
+    margin("cfg2 generated frame latent after 50 DDIM steps + 3 uint8 round trips", rel_l2(lat[:, 4:], g["all_latents"][:, 4:]), 6e-2)
+    # drift: the SAME starting latent as the oracle's loop (isolates UNet + scheduler from what is upstream of them)
+    hist = sdu.ctx.ddim_loop(g["lat0"].cuda(), GG.text_emb().cuda(), num_steps=50, start_step=0, guidance=0.0, return_hist=True).cpu()
+    assert hist.shape[0] == 51
+    table = []
+    for s, ref in zip(g["hist_steps"], g["hist"]):
+        table.append((s, rel_l2(hist[s], ref)))
+    print("[parity] DDIM drift vs the fp32 oracle, rel-L2 of the latent after k steps: " + "  ".join("k=%d: %.2e" % t for t in table))
+    worst = max(e for _, e in table)
+    margin("cfg2 DDIM latent drift, worst over 50 steps", worst, 4e-2)
+    margin("cfg2 DDIM latent after 50 steps", table[-1][1], 4e-2)
+    import json
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "ddim_drift.json"), "w") as f:
+            json.dump({"steps": [t[0] for t in table], "rel_l2": [t[1] for t in table]}, f)
+    except OSError:
+        pass
+
+
+def test_config1_rollout_8_frames_start25(ctx, nets):
+    """configs[1]: 8 autoregressive frames, 25 DDIM steps each (200 UNet calls in the oracle fixture)."""
+    g = gold("sd_cfg1_rollout.pt")
+    lat, _ = _rollout("1_19_ball_complex_L1_64", g, nets)
+    for k in range(g["pred_frames"]):
+        print("[parity] cfg1 frame %d rel-L2 %.3e" % (k, rel_l2(lat[:, 4 + k], g["all_latents"][:, 4 + k])))
+    margin("cfg1 8-frame rollout, all generated latents", rel_l2(lat[:, 4:], g["all_latents"][:, 4:]), 1e-1)
+    margin("cfg1 8-frame rollout, last frame", rel_l2(lat[:, -1], g["all_latents"][:, -1]), 1.5e-1)
+
+
+def test_config3_rollout_16_frames_f128(ctx, nets):
+    """configs[3]: 11_27_ucf_final (F=128, D_lat=1024), 16 autoregressive frames with the 512x512 round trip."""
+    g = gold("sd_cfg3_rollout.pt")
+    lat, _ = _rollout("11_27_ucf_final", g, nets)
+    for k in (0, 7, 15):
+        print("[parity] cfg3 frame %d rel-L2 %.3e" % (k, rel_l2(lat[:, 4 + k], g["all_latents"][:, 4 + k])))
+    margin("cfg3 16-frame rollout, all generated latents", rel_l2(lat[:, 4:], g["all_latents"][:, 4:]), 1e-1)
+    margin("cfg3 16-frame rollout, last frame", rel_l2(lat[:, -1], g["all_latents"][:, -1]), 1.5e-1)
+
+
+def test_config4_guidance_7p5_full_size(ctx, nets):
+    """configs[4]: a real prompt + guidance_scale 7.5 (evaluation/predict_fvd2_denoise.py:203,227-229): the batch-2 UNet call
+    with DIFFERENT uncond / cond embeddings, the CFG combine and three scheduler steps, full-size UNet."""
+    usd, _ = nets
+    c = SO.SD_UNET
+    ctx.configure(_lib.SVG_UNET, block_out=list(c["block_out"]), layers=2, heads=8, ctx_dim=768, groups=32, attn=list(c["attn"]))
+    ctx.load_state_dict(_lib.SVG_UNET, usd)
+    ctx.finalize(_lib.SVG_UNET)
+    g = torch.Generator().manual_seed(11)
+    z = torch.randn(1, 4, 64, 64, generator=g) * 0.8
+    emb = torch.randn(2, 77, 768, generator=g)                     # [uncond; cond], distinct
+    noise = torch.randn(1, 4, 64, 64, generator=g)
+    x2 = torch.cat([z, z])
+    e = ctx.unet_forward(x2.cuda(), torch.tensor([500.0, 500.0]).cuda(), emb.cuda()).cpu()
+    ref = SO.unet_forward(usd, x2, 500, emb)
+    margin("cfg4 batch-2 UNet call (uncond/cond rows), full size", rel_l2(e, ref), 1.5e-2)
+    margin("cfg4 guided noise u + 7.5 (c - u)", rel_l2(e[:1] + 7.5 * (e[1:] - e[:1]), ref[:1] + 7.5 * (ref[1:] - ref[:1])), 6e-2)
+    S = 47
+    got = ctx.ddim_loop(z.cuda(), emb.cuda(), num_steps=50, start_step=S, guidance=7.5, noise=noise.cuda()).cpu()
+    want = SO.gen_i2i_latents(usd, emb, z, 50, 7.5, S, noise=noise)
+    margin("cfg4 3 DDIM steps at guidance 7.5", rel_l2(got, want), 3e-2)
+
+
+def test_config4_text_transformer_full_size(ctx):
+    """configs[4]: 11_27_ucf_text_final — d = 2048 + 384 = 2432 (head dim 304), D_lat 1024, 4 + 8 layers, 0.6 G parameters."""
+    from sd_video_gen_amd import config as svg_config
+    from sd_video_gen_amd.transformer_text import Transformer as TextTransformer, predict as predict_text
+    svg_config.set_args(["--dataset", "ucf", "--config", "11_27_ucf_text_final"])
+    cfg = svg_config.load_config("11_27_ucf_text_final")
+    torch.manual_seed(4)
+    m = TextTransformer(dim_model=cfg.DIM_MODEL[0], num_heads=cfg.NUM_HEADS[0], num_encoder_layers=cfg.NUM_ENCODER_LAYERS[0],
+                        num_decoder_layers=cfg.NUM_DECODER_LAYERS[0]).eval()
+    assert m.dim_model == 2432 and m.d_lat == 1024
+    sd = m.state_dict()
+    X = torch.randn(2, 6, 1024)
+    names = ["WallPushups", "PlayingGuitar"]
+    txt = m.encode_classes(names)
+    out = m(X.cuda(), names, X.cuda(), m.get_tgt_mask(6).cuda(), pe_row=torch.zeros(2, dtype=torch.int32)).cpu()
+    for b in range(2):
+        ref = TO.forward(sd, X[b:b + 1], X[b:b + 1], 8, TO.get_tgt_mask(6), txt=txt[b:b + 1])
+        margin("cfg4 text Transformer d=2432 forward, clip %d" % b, rel_l2(out[:, b:b + 1], ref), 2e-5)
+    p = predict_text(m, X[:1].cuda(), names[:1]).cpu()
+    margin("cfg4 predict_text (D_lat,)", rel_l2(p, TO.predict(sd, X[:1], 8, txt=txt[:1])), 2e-5)

@@ -102,6 +102,97 @@ def test_gather_clips_gloo_world2(n_clips):
         assert torch.equal(out, want)
 
 
+def _fake_sampler(clips, seeds):
+    """stands where sample_clips stands (the real one needs the GPU): outputs are pure functions of the clip seed"""
+    lat = torch.stack([torch.full((6, 16), float(s)) + torch.arange(16.0) for s in seeds]) if seeds else torch.zeros(0, 6, 16)
+    frames = torch.stack([torch.full((6, 8, 8, 3), s % 251, dtype=torch.uint8) for s in seeds]) if seeds else \
+        torch.zeros(0, 6, 8, 8, 3, dtype=torch.uint8)
+    assert clips.shape[0] == len(seeds)
+    return lat, frames
+
+
+def _run_sharded_worker(rank, ws, port, n_clips, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    from sd_video_gen_amd.predict import run_sharded
+    calls = []
+    real = dist.all_gather
+    dist.all_gather = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    clips = torch.zeros(n_clips, 5, 8, 8, 3, dtype=torch.uint8)
+    lat, frames = run_sharded(clips, _fake_sampler, base_seed=40)
+    q.put((rank, lat, frames, len(calls)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_clips", [4, 5, 1])
+def test_run_sharded_one_allgather_gloo_world2(n_clips):
+    """predict.main's N>1 path (shard -> sample -> ONE all-gather of latents + frames), ragged and empty shards included;
+    the result equals the world-size-1 run."""
+    from sd_video_gen_amd.predict import run_sharded
+    want_lat, want_frames = run_sharded(torch.zeros(n_clips, 5, 8, 8, 3, dtype=torch.uint8), _fake_sampler, base_seed=40)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + n_clips
+    procs = [ctx.Process(target=_run_sharded_worker, args=(r, 2, port, n_clips, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, lat, frames, n_calls in res:
+        assert n_calls == 1                                         # DESIGN §6: one collective ends the step
+        assert lat.dtype == torch.float32 and frames.dtype == torch.uint8
+        assert torch.equal(lat, want_lat) and torch.equal(frames, want_frames)
+
+
+def test_save_frames_bytes(tmp_path):
+    """prediction/predict.py:201-223: one PNG per frame; predicted frames carry a 1-px red border (BGR [0,0,255]); frames are
+    BGR in memory and written like cv2.imwrite (so the file holds RGB = reversed channels)."""
+    import numpy as np
+    from PIL import Image
+    from sd_video_gen_amd.predict import save_frames
+    g = np.random.default_rng(0)
+    frames = g.integers(0, 256, size=(3, 8, 8, 3), dtype=np.uint8)
+    save_frames(frames, [False, True, True], str(tmp_path / "o"))
+    assert sorted(os.listdir(tmp_path / "o")) == ["0.png", "1.png", "2.png"]
+    a0 = np.asarray(Image.open(tmp_path / "o" / "0.png"))
+    assert a0.shape == (8, 8, 3) and np.array_equal(a0[..., ::-1], frames[0])
+    a1 = np.asarray(Image.open(tmp_path / "o" / "1.png"))
+    assert a1.shape == (10, 10, 3)
+    assert np.array_equal(a1[1:-1, 1:-1, ::-1], frames[1])
+    border = np.concatenate([a1[0], a1[-1], a1[:, 0], a1[:, -1]])
+    assert (border == np.array([255, 0, 0], dtype=np.uint8)).all()   # RGB on disk = BGR (0,0,255) in memory
+
+
+def test_text_model_loads_reference_checkpoint_layout():
+    """a reference text-model checkpoint (state_dict of models/transformer_text.py) also holds the SentenceTransformer's
+    ``sent_transformer.*`` tensors: they are dropped, everything else loads strictly."""
+    from sd_video_gen_amd import config as svg_config
+    from sd_video_gen_amd.transformer_text import Transformer
+    svg_config.set_args(["--dataset", "ball", "--config", "model_10_26"])
+    torch.manual_seed(0)
+    m = Transformer(dim_model=32, num_heads=4, num_encoder_layers=1, num_decoder_layers=1)
+    sd = {k: v.clone() + 1.0 if v.is_floating_point() else v.clone() for k, v in m.state_dict().items()}
+    sd["sent_transformer.0.auto_model.embeddings.word_embeddings.weight"] = torch.zeros(4, 4)
+    sd["sent_transformer.0.auto_model.encoder.layer.0.attention.self.query.bias"] = torch.zeros(4)
+    r = m.load_state_dict(sd)                                       # strict
+    assert not r.missing_keys and not r.unexpected_keys
+    assert torch.equal(m.out.bias, sd["out.bias"])
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({k: v for k, v in sd.items() if k != "out.bias"})
+
+
+def test_bench_refuses_mismatched_world_size():
+    """bench.py --gpus N under a launcher that started another number of ranks stops with a clear message (and never
+    initialises the GPU in the parent when it spawns the ranks itself)."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
 def test_cli_surface_parses_like_the_reference():
     from sd_video_gen_amd import config as svg_config
     import trainers.trainer as tr

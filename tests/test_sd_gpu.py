@@ -15,7 +15,7 @@ import sys
 import pytest
 import torch
 
-from conftest import rel_l2
+from conftest import margin, rel_l2
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -65,11 +65,11 @@ def test_vae_encode(ctx, cfg, N, H):
     z, mom = ctx.vae_encode(img.cuda(), eps=eps.cuda(), return_moments=True)
     x = 2 * ((img / 255.0).float().permute(0, 3, 1, 2) - 0.5)
     mom_ref = SO.vae_encode_moments(sd, x, cfg)
-    assert rel_l2(mom.cpu(), mom_ref) < NET_TOL
-    assert rel_l2(z.cpu(), SO.encode_img(sd, img, eps, cfg)) < NET_TOL
+    margin("test_vae_encode: mom.cpu()", rel_l2(mom.cpu(), mom_ref), NET_TOL)
+    margin("test_vae_encode: z.cpu()", rel_l2(z.cpu(), SO.encode_img(sd, img, eps, cfg)), NET_TOL)
     # eps=None -> distribution mean
     z0 = ctx.vae_encode(img.cuda())
-    assert rel_l2(z0.cpu(), SO.vae_sample(mom_ref) * SO.SCALE) < NET_TOL
+    margin("test_vae_encode: z0.cpu()", rel_l2(z0.cpu(), SO.vae_sample(mom_ref) * SO.SCALE), NET_TOL)
 
 
 @pytest.mark.parametrize("cfg,N,h", [(TINY_VAE, 2, 16), (MID_VAE, 1, 8), (MID_VAE, 2, 16)])
@@ -79,7 +79,7 @@ def test_vae_decode(ctx, cfg, N, h):
     z = torch.randn(N, 4, h, h, generator=g) * 0.18215 * 3
     img, fl = ctx.vae_decode(z.cuda(), return_float=True)
     ref_img, ref_fl = SO.decode_img_latents(sd, z, cfg, return_float=True)
-    assert rel_l2(fl.cpu(), ref_fl) < NET_TOL
+    margin("test_vae_decode: fl.cpu()", rel_l2(fl.cpu(), ref_fl), NET_TOL)
     mean, within2, mx = img_close(img.cpu(), ref_img)
     assert mean <= 1.0 and within2 >= 0.97, (mean, within2, mx)
 
@@ -103,7 +103,7 @@ def test_vae_batch_chunking(ctx):
     # the chunks may pick other tile shapes than the whole batch (accumulation order): equal up to bf16 rounding
     assert rel_l2(fl1, fl0) < 1.5e-2 and rel_l2(z1, z0) < 1.5e-2   # other tile shapes per chunk: bf16 roundings differ layer by layer
     ref_img, ref_fl = SO.decode_img_latents(sd, z, cfg, return_float=True)
-    assert rel_l2(fl1.cpu(), ref_fl) < NET_TOL
+    margin("test_vae_batch_chunking: fl1.cpu()", rel_l2(fl1.cpu(), ref_fl), NET_TOL)
     mean, within2, mx = img_close(img1.cpu(), ref_img)
     assert mean <= 1.0 and within2 >= 0.97, (mean, within2, mx)
 
@@ -134,7 +134,7 @@ def test_unet_forward(ctx, cfg, N, h, L):
     e = ctx.unet_forward(x.cuda(), t.cuda(), c.cuda())
     ref = SO.unet_forward(sd, x, t, c, cfg)
     assert torch.isfinite(e).all()
-    assert rel_l2(e.cpu(), ref) < NET_TOL
+    margin("test_unet_forward: e.cpu()", rel_l2(e.cpu(), ref), NET_TOL)
 
 
 def test_ddim_step_matches_scheduler(ctx):
@@ -163,7 +163,7 @@ def test_ddim_loop(ctx, guidance, start):
                          noise=noise.cuda(), return_hist=True).cpu()
     assert hist.shape == ref.shape
     assert rel_l2(hist[:N], ref[:N]) < 1e-6                       # add_noise / start latents: f32 exact-ish
-    assert rel_l2(hist[-N:], ref[-N:]) < NET_TOL
+    margin("test_ddim_loop: hist[-N:]", rel_l2(hist[-N:], ref[-N:]), NET_TOL)
     out = ctx.ddim_loop(lat.cuda(), emb.cuda(), num_steps=steps, start_step=start, guidance=guidance, noise=noise.cuda())
     assert torch.equal(out.cpu(), hist[-N:])
 

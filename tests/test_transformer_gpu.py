@@ -52,7 +52,7 @@ def test_tiny_against_reference_golden(ctx):
     assert rel_l2(batched.cpu(), rows.cpu()) < 1e-6
 
 
-@pytest.mark.parametrize("cfg", ["config_test", "1_16_kitti_L1_64"])
+@pytest.mark.parametrize("cfg", ["config_test", "1_16_kitti_L1_64", "11_27_ucf_final"])
 def test_full_size_against_reference_golden(ctx, cfg):
     spot = gold("transformer_spot.pt")[cfg]
     m = build(cfg, spot["kw"], seed=spot["seed"])
