@@ -59,9 +59,21 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("SVG_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(cfg_name, start_step):
-    """The CPU restatement (oracle/, kind "port") timed on this host's cores on a bounded sample of the same
-    per-frame work; linear extrapolation to (50 - start_step) UNet steps and to 512x512 VAE passes is stated."""
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg_name, start_step, denoise=True):
+    """The CPU restatement (oracle/, kind "port": the reference's own Python cannot travel to the GPU box) timed on this
+    host's cores on a bounded sample of the same per-frame work: the latent Transformer forward, ONE batch-1 UNet step
+    (the DDIM loop repeats it 50 - start_step times: linear extrapolation, stated), and the VAE passes at 512x512 and at
+    F x F timed directly."""
     import torch
     from oracle import sd_oracle as SO, transformer_oracle as TO
     from sd_video_gen_amd import sd_layout
@@ -87,29 +99,33 @@ def cpu_baseline(cfg_name, start_step):
         sd = m.state_dict()
         D = m.d_lat
         X = torch.randn(1, 6, D)
-        timed("transformer", lambda: TO.predict(sd, X, cfg.NUM_HEADS[0]), reps=3)
+        timed("transformer", lambda: TO.predict(sd, X, cfg.NUM_HEADS[0]), reps=5 if denoise else 40)
         del m, sd
+        if not denoise:
+            return {"value": 1.0 / t["transformer"], "unit": "frames/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+                    "sample": "oracle (plain torch fp32) latent Transformer forward, one clip (6 tokens), %.4f s per frame on %d threads (40 forwards timed)"
+                              % (t["transformer"], cores)}
         usd = sd_layout.seeded_weights(sd_layout.unet_shapes(), 2)
         x = torch.randn(1, 4, 64, 64)
         c = torch.randn(1, 77, 768)
-        timed("unet_step_b1", lambda: SO.unet_forward(usd, x, 500, c))
+        timed("unet_step_b1", lambda: SO.unet_forward(usd, x, 500, c), reps=2)
         del usd
         vsd = sd_layout.seeded_weights(sd_layout.vae_shapes(), 1)
         F = cfg.FRAME_SIZE
-        img = torch.randint(0, 256, (1, 256, 256, 3), dtype=torch.uint8)
-        timed("vae_enc_256", lambda: SO.encode_img(vsd, img))
-        z = torch.randn(1, 4, 32, 32) * 0.2
-        timed("vae_dec_256", lambda: SO.decode_img_latents(vsd, z))
+        img = torch.randint(0, 256, (1, 512, 512, 3), dtype=torch.uint8)
+        timed("vae_enc_512", lambda: SO.encode_img(vsd, img))
+        z = torch.randn(1, 4, 64, 64) * 0.2
+        timed("vae_dec_512", lambda: SO.decode_img_latents(vsd, z))
         imgF = torch.randint(0, 256, (1, F, F, 3), dtype=torch.uint8)
         timed("vae_enc_F", lambda: SO.encode_img(vsd, imgF))
         zF = torch.randn(1, 4, F // 8, F // 8) * 0.2
         timed("vae_dec_F", lambda: SO.decode_img_latents(vsd, zF))
     n_unet = 50 - start_step
-    per_frame = t["transformer"] + n_unet * t["unet_step_b1"] + 4.0 * (t["vae_enc_256"] + t["vae_dec_256"]) + t["vae_enc_F"] + t["vae_dec_F"]
-    return {"value": 1.0 / per_frame, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "oracle (plain torch fp32) on host cores: 1 Transformer fwd %.3fs, 1 batch-1 UNet step %.2fs (x%d extrapolated), "
-                      "VAE enc+dec at 256x256 %.2fs+%.2fs (x4 extrapolated to 512x512, conv work is linear in pixels), VAE enc+dec at F %.2fs+%.2fs"
-                      % (t["transformer"], t["unet_step_b1"], n_unet, t["vae_enc_256"], t["vae_dec_256"], t["vae_enc_F"], t["vae_dec_F"])}
+    per_frame = t["transformer"] + n_unet * t["unet_step_b1"] + t["vae_enc_512"] + t["vae_dec_512"] + t["vae_enc_F"] + t["vae_dec_F"]
+    return {"value": 1.0 / per_frame, "unit": "frames/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "sample": "oracle (plain torch fp32) on %d host threads: 1 Transformer fwd %.3fs, 1 batch-1 UNet step %.2fs (mean of 2; x%d DDIM steps extrapolated: "
+                      "every step is the same call), VAE enc + dec at 512x512 %.2fs + %.2fs and at %dx%d %.2fs + %.2fs timed directly"
+                      % (cores, t["transformer"], t["unet_step_b1"], n_unet, t["vae_enc_512"], t["vae_dec_512"], F, F, t["vae_enc_F"], t["vae_dec_F"])}
 
 
 def self_launch(args):
@@ -126,6 +142,87 @@ def self_launch(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL / cross-process device memory on this driver
     env.setdefault("OMP_NUM_THREADS", "4")
     return subprocess.run(cmd, env=env).returncode
+
+
+MFMA_FAMILIES = {"conv3x3": "3x3 convolutions: conv_halo_kernel<BN,PP> + igemm_kernel<BN, conv modes> (UNet resnets / samplers, every VAE conv)",
+                 "gemm": "dense GEMMs: igemm_kernel<BN,dense> + gemm_pp_kernel<BN> (+ split-K reduce): attention projections, GEGLU feed-forward, 1x1 convs, time MLP",
+                 "attention": "attn_kernel<D,QB,NST,BC>: fused softmax(QK^T)V, self (4096/1024/256/64 keys) and cross (77 keys)"}
+HBM_FAMILIES = {"groupnorm": "gn_stats / gn_apply / gn_small", "layernorm": "ln_stats (LayerNorm itself is folded into the consuming GEMM)",
+                "eltwise": "layout / DDIM step / image pre-post kernels", "softmax": "VAE mid-block row softmax"}
+
+
+def roofline_pass(args, sd_utils, step, denoise, C):
+    """Instrumented pass on rank 0: ONE stream group's clips alone, hipEvent brackets recorded by the library on the launch
+    stream around every launch of each kernel family (svg_prof_*).  `roofline` is the family that takes the most time;
+    `roofline.by_family` lists every family against its own bound."""
+    import torch
+    from sd_video_gen_amd import _lib
+    ctx = sd_utils.ctx
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    step(gather=False)          # rank-0-only pass: no collective
+    torch.cuda.synchronize()
+    rep = ctx.prof_report()
+    ctx.prof_enable(False)
+    n_grp = max(1, C // args.streams)
+    out = {}
+    outer = rep.pop("unet_step", None)          # outer bracket around whole UNet calls: not a family (its time is inside the others)
+    fam = {k: {"calls": v["calls"], "ms": round(v["ms"], 3), "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),
+               "alg_gb_per_s": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)} for k, v in rep.items()}
+    tot_ms = sum(v["ms"] for v in rep.values())
+    if not denoise:
+        dom = rep["xf_gemm"]
+        ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+        fwd_ms = rep["xf_gemm"]["ms"] + rep.get("xf_misc", {"ms": 0})["ms"]
+        out["roofline"] = {"bound": "hbm", "kernel": "xf_gemm_kernel<MT> (f32 weight stream of the latent Transformer, v_mfma_f32_16x16x4_f32)",
+                           "achieved": ach, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": ach / (PEAK_HBM / 1e9), "traffic": None,
+                           "launches": dom["calls"], "avg_launch_ms": dom["ms"] / dom["calls"],
+                           "algorithmic_bytes_per_launch": dom["bytes"] / dom["calls"],
+                           "whole_forward_gb_per_s": dom["bytes"] / (fwd_ms * 1e-3) / 1e9,
+                           "rows_per_forward": n_grp * 6,
+                           "f32_mfma_tflops": dom["flops"] / (dom["ms"] * 1e-3) / 1e12,
+                           "note": "f32 MFMA peaks at 157 TFLOP/s: above ~50 rows (2*M/4 FLOP/B against 157e12/6.3e12) the stream is MFMA-bound, not HBM-bound"}
+        out["families"] = fam
+        return out
+    pmc = None
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if name.endswith("pmc_summary.json"):
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                cand = json.load(f)
+            # HBM counters cannot be read from inside this process: they come from committed rocprofv3 --pmc passes of the same
+            # step (tools/pmc_step.sh) and are used only when they were taken from THIS build of the kernels
+            if cand.get("src_hash") == _lib.source_hash():
+                pmc = (name, cand)
+                break
+    by_family = {}
+    for k, v in rep.items():
+        if k in MFMA_FAMILIES:
+            ach = v["flops"] / (v["ms"] * 1e-3) / 1e12
+            e = {"bound": "mfma", "kernel": MFMA_FAMILIES[k], "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": ach / (PEAK_BF16 / 1e12),
+                 "algorithmic_flop_per_launch": v["flops"] / v["calls"]}
+        elif k in HBM_FAMILIES:
+            ach = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+            e = {"bound": "hbm", "kernel": HBM_FAMILIES[k], "achieved": ach, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": ach / (PEAK_HBM / 1e9)}
+        else:
+            continue
+        e.update(launches=v["calls"], ms=v["ms"], share_of_kernel_time=v["ms"] / tot_ms, avg_launch_ms=v["ms"] / v["calls"],
+                 algorithmic_bytes_per_launch=v["bytes"] / v["calls"], traffic=None)
+        if pmc and k in pmc[1]["families"] and pmc[1]["families"][k]["launches"] == v["calls"]:
+            e["traffic"] = pmc[1]["families"][k]["hbm_bytes_per_launch"]
+            e["traffic_source"] = "profiles/%s (%s)" % (pmc[0], pmc[1].get("note", ""))
+        by_family[k] = e
+    dom_name = max((k for k in by_family if by_family[k]["bound"] == "mfma"), key=lambda k: by_family[k]["ms"])
+    out["roofline"] = dict(by_family[dom_name], family=dom_name, by_family=by_family,
+                           instrumented_pass="one stream group (%d clips) run alone with hipEvent brackets around every launch" % n_grp,
+                           whole_frame_frac_of_mfma_peak=FRAME_FLOP * n_grp * args.pred_frames / (tot_ms * 1e-3) / PEAK_BF16)
+    if outer and outer["calls"]:
+        t_step = outer["ms"] / outer["calls"] * 1e-3
+        out["roofline"]["unet_step"] = {"calls": outer["calls"], "ms_per_call": t_step * 1e3, "samples": n_grp,
+                                        "achieved": UNET_FLOP * n_grp / t_step / 1e12, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                                        "frac": UNET_FLOP * n_grp / t_step / PEAK_BF16,
+                                        "definition": "803.27e9 FLOP x samples / time of one UNet call + scheduler step (SURVEY 8d)"}
+    out["families"] = fam
+    return out
 
 
 def main():
@@ -223,9 +320,11 @@ def main():
     frames = n_global * args.pred_frames * args.steps
     fps = frames / dt
 
-    line = {"metric": "generated frames/sec at 50 DDIM denoise steps, 512x512", "value": fps, "unit": "frames/s",
+    metric = "generated frames/sec at 50 DDIM denoise steps, 512x512" if denoise else \
+        "generated frames/sec, 64x64 no-denoise (latent Transformer only)"
+    line = {"metric": metric, "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if denoise else "f32", "data": "synthetic",
             "config": {"workload": "configs[2]: %s F=%d, --denoise --denoise_start_step %d (%d DDIM steps of the SD-v1.4 UNet at 64x64 latents, "
                                    "VAE enc/dec at 512x512), guidance_scale 0" % (args.config, F, args.start_step, 50 - args.start_step)
                        if denoise else "%s F=%d no --denoise (latent Transformer only)" % (args.config, F),
@@ -233,44 +332,9 @@ def main():
                        "weights": "seeded random init (SD v1.4 architecture, %s)" % args.config}}
 
     if rank == 0 and not args.no_roofline:
-        # instrumented pass: hipEvent brackets around every launch of each kernel family, on the launch stream
-        ctx = sd_utils.ctx
-        ctx.prof_reset()
-        ctx.prof_enable(True)
-        step(gather=False)          # rank-0-only pass: no collective
-        torch.cuda.synchronize()
-        rep = ctx.prof_report()
-        ctx.prof_enable(False)
-        fam = {k: {"calls": v["calls"], "ms": round(v["ms"], 3), "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1)} for k, v in rep.items()}
-        if denoise:
-            dom = rep["conv3x3"]
-            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            line["roofline"] = {"bound": "mfma", "kernel": "conv3x3 family: conv_halo_kernel<BN> + igemm_kernel<BN, conv modes> (every 3x3 conv of the UNet / VAE in one step)",
-                                "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": ach / (PEAK_BF16 / 1e12),
-                                "traffic": None, "launches": dom["calls"], "avg_launch_ms": dom["ms"] / dom["calls"],
-                                "algorithmic_flop_per_launch": dom["flops"] / dom["calls"]}
-            line["roofline"]["algorithmic_bytes_per_launch"] = dom["bytes"] / dom["calls"]
-            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_summary.json")
-            if os.path.exists(pmc):
-                # HBM bytes per launch of the same family from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, collected
-                # offline with rocprofv3 on one 28-clip group: counters cannot be read from inside this process)
-                with open(pmc) as f:
-                    fam_pmc = json.load(f)["families"].get("conv3x3")
-                if fam_pmc and fam_pmc["launches"] == dom["calls"]:
-                    line["roofline"]["traffic"] = fam_pmc["hbm_bytes_per_launch"] * (max(1, C // args.streams) / 28.0)
-                    line["roofline"]["traffic_source"] = "profiles/r01_pmc_summary.json (28-clip group, scaled by clips per group)"
-            tot_ms = sum(v["ms"] for v in rep.values())
-            line["roofline"]["whole_frame_frac_of_mfma_peak"] = FRAME_FLOP * max(1, C // args.streams) * args.pred_frames / (tot_ms * 1e-3) / PEAK_BF16
-            line["roofline"]["instrumented_pass"] = "one stream group (%d clips) run alone with hipEvent brackets around every launch" % max(1, C // args.streams)
-        else:
-            dom = rep["xf_gemm"]
-            ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-            line["roofline"] = {"bound": "hbm", "kernel": "xf_gemm_kernel (f32 weight stream)", "achieved": ach, "peak": PEAK_HBM / 1e9,
-                                "unit": "GB/s", "frac": ach / (PEAK_HBM / 1e9), "traffic": None, "launches": dom["calls"],
-                                "avg_launch_ms": dom["ms"] / dom["calls"]}
-        line["families"] = fam
+        line.update(roofline_pass(args, sd_utils, step, denoise, C))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(args.config, args.start_step) if denoise else None
+        line["cpu_baseline"] = cpu_baseline(args.config, args.start_step, denoise)
     if rank == 0:
         print(json.dumps(line))
     if world > 1:

@@ -150,8 +150,9 @@ int svg_op_xf_gemm(svg_ctx* ctx, const float* X, const float* W, const float* bi
                    int M, int N, int K, int relu_in, void* stream);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
-/* When enabled, every launch of each kernel family is bracketed by hipEvents on its stream;
- * svg_prof_report synchronises and writes "name calls total_ms flops bytes\n" lines into buf. */
+/* When enabled (on = 1), every launch of each kernel family is bracketed by hipEvents on its stream;
+ * svg_prof_report synchronises and writes "name calls total_ms flops bytes\n" lines into buf.
+ * on = 2 additionally keeps one entry per call-site signature, reported as "@family|shape ..." lines. */
 int svg_prof_enable(svg_ctx* ctx, int on);
 int svg_prof_reset(svg_ctx* ctx);
 int svg_prof_report(svg_ctx* ctx, char* buf, int buflen);

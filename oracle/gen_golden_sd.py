@@ -7,7 +7,8 @@ diffusers is not installable here), on seeded weights and CPU-generator noise; n
 
   sd_cfg2_frame.pt    configs[2]: 1_16_kitti_L1_64, F=64, one clip, ONE predicted frame, --denoise_start_step 0:
                       50 DDIM steps of the SD-v1.4 UNet at 64x64 latents between the 512x512 VAE passes; keeps the
-                      latent entering the loop and the loop's history at selected steps (per-step drift table)
+                      latent entering the loop and the loop's whole latent history (free-running drift table and
+                      per-step, teacher-forced errors)
   sd_cfg1_rollout.pt  configs[1]: same model, 8 predicted frames, --denoise_start_step 25 (25 steps per frame)
   sd_cfg3_rollout.pt  configs[3]: 11_27_ucf_final, F=128, 16 predicted frames, start step 48 (2 steps per frame: the
                       full 50 would be 800 UNet calls)
@@ -32,7 +33,7 @@ sys.path.insert(0, ROOT)
 from oracle import loop_oracle, sd_oracle as SO  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
-HIST_STEPS = [0, 1, 2, 3, 5, 10, 15, 20, 25, 30, 35, 40, 45, 50]
+HIST_STEPS = list(range(51))      # the whole history (3.3 MB f32): the per-step (teacher-forced) test needs consecutive pairs
 UNET_SEED, VAE_SEED, XF_SEED, CLIP_SEED, NOISE_SEED, EMB_SEED = 31, 32, 7, 4, 5, 123
 
 

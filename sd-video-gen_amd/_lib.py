@@ -70,6 +70,11 @@ def load():
     return lib
 
 
+def source_hash():
+    """hash of the kernel sources this library was built from (svg_version(): '... src <hash>')"""
+    return load().svg_version().decode().rsplit(" ", 1)[-1]
+
+
 def _ptr(t):
     if t is None:
         return None
@@ -239,14 +244,15 @@ class Context:
         return out
 
     # ---- profiling -----------------------------------------------------------------------------
-    def prof_enable(self, on=True):
-        self.lib.svg_prof_enable(self.h, 1 if on else 0)
+    def prof_enable(self, on=True, detail=False):
+        """on: hipEvent brackets per kernel family; detail: additionally per call-site signature (names starting with '@')"""
+        self.lib.svg_prof_enable(self.h, (2 if detail else 1) if on else 0)
 
     def prof_reset(self):
         self.check(self.lib.svg_prof_reset(self.h), "svg_prof_reset")
 
     def prof_report(self):
-        buf = C.create_string_buffer(1 << 16)
+        buf = C.create_string_buffer(1 << 20)
         self.check(self.lib.svg_prof_report(self.h, buf, len(buf)), "svg_prof_report")
         out = {}
         for line in buf.value.decode().strip().splitlines():

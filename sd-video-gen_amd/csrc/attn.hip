@@ -361,8 +361,10 @@ void attention(svg_ctx* ctx, const AttnArgs& a, hipStream_t s) {
     switch (a.d) { case 8: case 16: case 32: case 40: case 64: case 80: case 160: return; default: break; }
     SVG_CHECK(false, "attention: head dim %d unsupported (instantiated: 8, 16, 32, 40, 64, 80, 160)", a.d);
   }
+  char tag[96];
+  snprintf(tag, sizeof(tag), "B%d_h%d_Sq%d_Skv%d_d%d", a.B, a.heads, a.Sq, a.Skv, a.d);
   ProfScope ps(ctx, PK_ATTN, s, 4.0 * a.B * a.heads * (double)a.Sq * a.Skv * a.d,
-               2.0 * a.B * a.heads * ((double)a.Sq * a.d * 2 + (double)a.Skv * a.d * 2));
+               2.0 * a.B * a.heads * ((double)a.Sq * a.d * 2 + (double)a.Skv * a.d * 2), tag);
   switch (a.d) {
     case 8: launch<8>(a, s); break;
     case 16: launch<16>(a, s); break;

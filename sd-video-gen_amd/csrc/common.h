@@ -95,8 +95,10 @@ struct svg_ctx {
   Arena arena;
   DevBuf arena_buf;
   bool prof = false;
+  bool prof_detail = false;            // svg_prof_enable(ctx, 2): additionally one entry per call-site signature ("@kind|shape")
   bool graph_mode = false;
   std::vector<ProfEntry> prof_entries;
+  std::unordered_map<std::string, ProfEntry> prof_shapes;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
   // models (opaque here; defined in their own translation units)
@@ -111,13 +113,15 @@ struct svg_ctx {
 
 // Kernel families for the profiler (index into prof_entries)
 enum ProfKind {
-  PK_GEMM = 0, PK_CONV3, PK_ATTN, PK_GNORM, PK_LNORM, PK_ELT, PK_XF_GEMM, PK_XF_MISC, PK_SOFTMAX, PK_COUNT
+  PK_GEMM = 0, PK_CONV3, PK_ATTN, PK_GNORM, PK_LNORM, PK_ELT, PK_XF_GEMM, PK_XF_MISC, PK_SOFTMAX,
+  PK_UNET_STEP,   // outer bracket: one whole UNet call + scheduler step of the DDIM loop (contains the families above)
+  PK_COUNT
 };
 extern const char* kProfNames[PK_COUNT];
 
 struct ProfScope {
   svg_ctx* c; int kind; hipStream_t s; hipEvent_t e0 = nullptr, e1 = nullptr;
-  ProfScope(svg_ctx* c_, int kind_, hipStream_t s_, double flops, double bytes);
+  ProfScope(svg_ctx* c_, int kind_, hipStream_t s_, double flops, double bytes, const char* tag = nullptr);
   ~ProfScope();
 };
 

@@ -412,8 +412,16 @@ void launch_gemm(svg_ctx* ctx, const GemmArgs& g, hipStream_t s, int prof_kind) 
   }
   // algorithmic bytes: every operand once (a conv reads its image once, not once per tap)
   const double a_elems = g.amode == A_DENSE ? (double)g.M * g.K : (double)(g.M / (g.Ho * g.Wo)) * g.H * g.W * g.Cin;
+  char tag[160] = "";
+  if (ctx->prof_detail) {
+    const char* kern = conv_halo_supported(a) ? "halo" : (gemm_pp_supported(a) ? "pp" : "igemm");
+    if (g.amode == A_DENSE)
+      snprintf(tag, sizeof(tag), "M%d_N%d_K%d_b%d_act%d_res%d_ln%d_sk%d_%s", g.M, g.N, g.K, g.batch, g.act, g.residual ? 1 : 0, g.ln_rs ? 1 : 0, a.splitk, kern);
+    else
+      snprintf(tag, sizeof(tag), "conv%d_B%d_%dx%d_Cin%d_Cout%d_res%d_sk%d_%s", g.amode, g.M / (g.Ho * g.Wo), g.H, g.W, g.Cin, g.N, g.residual ? 1 : 0, a.splitk, kern);
+  }
   ProfScope ps(ctx, prof_kind, s, 2.0 * g.M * (double)g.N * g.K * g.batch,
-               2.0 * (a_elems + (double)g.N * g.K + (double)g.M * g.N) * g.batch);
+               2.0 * (a_elems + (double)g.N * g.K + (double)g.M * g.N) * g.batch, tag);
   if (conv_halo_supported(a)) {
     // 16 x 16 pixel blocks x channel tiles; splitk partitions the 64-channel chunks
     const int blocks = (a.M / 256) * cdiv(a.N, conv_halo_bn(a));

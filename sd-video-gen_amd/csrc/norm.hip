@@ -346,7 +346,9 @@ void groupnorm(svg_ctx* ctx, const bf16* x, int C1, const bf16* x2, int C2, cons
     static const int no_small = getenv("SVG_GN_NOSMALL") ? atoi(getenv("SVG_GN_NOSMALL")) : 0;
     if (!no_small && HW <= 256 && cpg % 4 == 0 && C1 % 4 == 0 && (int64_t)HW * (cpg / 4) <= 256 * 20) {
       if (!SVG_LAUNCHING(ctx)) return;
-      ProfScope ps(ctx, PK_GNORM, s, 0, 2.0 * B * HW * C * 2);
+      char tag[96];
+      snprintf(tag, sizeof(tag), "small_B%d_HW%d_C%d", B, HW, C);
+      ProfScope ps(ctx, PK_GNORM, s, 0, 2.0 * B * HW * C * 2, tag);
       if ((int64_t)HW * (cpg / 4) <= 256 * 5)
         hipLaunchKernelGGL(gn_small_kernel<5>, dim3(groups, B), dim3(256), 0, s, x, C1, x2, C2, gamma, beta, out, HW, groups, eps, silu);
       else
@@ -363,8 +365,10 @@ void groupnorm(svg_ctx* ctx, const bf16* x, int C1, const bf16* x2, int C2, cons
   float* partial = ctx->arena.get<float>((int64_t)B * nchunk * groups * 2);
   if (SVG_LAUNCHING(ctx)) {
     const double bytes = (double)B * HW * C * 2;
+    char tag[96];
+    snprintf(tag, sizeof(tag), "stats_B%d_HW%d_C%d", B, HW, C);
     {
-      ProfScope ps(ctx, PK_GNORM, s, 0, bytes);
+      ProfScope ps(ctx, PK_GNORM, s, 0, bytes, tag);
       const int threads = (CV * PL + 63) / 64 * 64;
       const size_t sh = (size_t)PL * C * 2 * sizeof(float);
       hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(std::max(threads, 64)), sh, s, x, C1, x2, C2, partial, HW,
@@ -372,7 +376,8 @@ void groupnorm(svg_ctx* ctx, const bf16* x, int C1, const bf16* x2, int C2, cons
       check_launch("gn_stats");
     }
     {
-      ProfScope ps(ctx, PK_GNORM, s, 0, 2 * bytes);
+      tag[0] = 'a'; tag[1] = 'p'; tag[2] = 'p'; tag[3] = 'l'; tag[4] = 'y';
+      ProfScope ps(ctx, PK_GNORM, s, 0, 2 * bytes, tag);
       const int threads = std::max((CV * PL + 63) / 64 * 64, 64);
       // ~16 pixels per thread, at least enough blocks to fill the chip
       int nblk = std::max(1, std::min(HW / PL, std::max(HW / (PL * 16), (2048 + B - 1) / B)));
@@ -396,7 +401,9 @@ void layernorm(svg_ctx* ctx, const bf16* x, const float* gamma, const float* bet
 void ln_stats(svg_ctx* ctx, const bf16* x, float* rs, float* rm, int M, int C, float eps, hipStream_t s) {
   SVG_CHECK(C % 8 == 0 && C <= 2048, "ln_stats: C=%d unsupported", C);
   if (!SVG_LAUNCHING(ctx)) return;
-  ProfScope ps(ctx, PK_LNORM, s, 0, 2.0 * M * C);
+  char tag[64];
+  snprintf(tag, sizeof(tag), "stats_M%d_C%d", M, C);
+  ProfScope ps(ctx, PK_LNORM, s, 0, 2.0 * M * C, tag);
   hipLaunchKernelGGL(ln_stats_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, x, rs, rm, M, C, eps);
   check_launch("ln_stats");
 }

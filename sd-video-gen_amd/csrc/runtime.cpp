@@ -3,9 +3,10 @@
 #include "../../include/svg_hip.h"
 #include <algorithm>
 #include <sstream>
+#include "build/srchash.h"
 
 const char* kProfNames[PK_COUNT] = {"gemm", "conv3x3", "attention", "groupnorm", "layernorm", "eltwise",
-                                    "xf_gemm", "xf_misc", "softmax"};
+                                    "xf_gemm", "xf_misc", "softmax", "unet_step"};
 
 static std::string g_err;   // errors without a context
 
@@ -35,7 +36,7 @@ void svg_ctx::ensure_arena(int64_t bytes) {
   arena.cap = bytes;
 }
 
-ProfScope::ProfScope(svg_ctx* c_, int kind_, hipStream_t s_, double flops, double bytes) : c(c_), kind(kind_), s(s_) {
+ProfScope::ProfScope(svg_ctx* c_, int kind_, hipStream_t s_, double flops, double bytes, const char* tag) : c(c_), kind(kind_), s(s_) {
   if (!c->prof) return;
   auto next_event = [&]() {
     if (c->ev_used == c->ev_pool.size()) {
@@ -52,6 +53,11 @@ ProfScope::ProfScope(svg_ctx* c_, int kind_, hipStream_t s_, double flops, doubl
   pe.flops += flops;
   pe.bytes += bytes;
   pe.ev.push_back({e0, e1});
+  if (c->prof_detail && tag) {
+    ProfEntry& d = c->prof_shapes[std::string("@") + kProfNames[kind] + "|" + tag];
+    d.calls++; d.flops += flops; d.bytes += bytes;
+    d.ev.push_back({e0, e1});
+  }
   hipEventRecord(e0, s);
 }
 ProfScope::~ProfScope() {
@@ -142,7 +148,7 @@ std::unordered_map<std::string, std::vector<int64_t>> parse_kv(const char* kv) {
 
 extern "C" {
 
-const char* svg_version(void) { return "svg_hip 0.1 (gfx950)"; }
+const char* svg_version(void) { return "svg_hip 0.2 (gfx950, bf16) src " SVG_SRC_HASH; }
 
 int svg_create(int device_id, svg_ctx** out) {
   svg_ctx* ctx = nullptr;
@@ -190,12 +196,14 @@ int svg_set_graph_mode(svg_ctx* ctx, int on) {
 int svg_prof_enable(svg_ctx* ctx, int on) {
   if (!ctx) return -1;
   ctx->prof = on != 0;
+  ctx->prof_detail = on == 2;
   return 0;
 }
 int svg_prof_reset(svg_ctx* ctx) {
   API_BEGIN
   HIP_OK(hipDeviceSynchronize());
   for (auto& e : ctx->prof_entries) { e.calls = 0; e.flops = 0; e.bytes = 0; e.ev.clear(); }
+  ctx->prof_shapes.clear();
   ctx->ev_used = 0;
   API_END(ctx)
 }
@@ -211,6 +219,14 @@ int svg_prof_report(svg_ctx* ctx, char* buf, int buflen) {
       if (hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) ms += t;
     }
     os << e.name << " " << e.calls << " " << ms << " " << e.flops << " " << e.bytes << "\n";
+  }
+  for (auto& kv : ctx->prof_shapes) {
+    double ms = 0;
+    for (auto& p : kv.second.ev) {
+      float t = 0;
+      if (hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) ms += t;
+    }
+    os << kv.first << " " << kv.second.calls << " " << ms << " " << kv.second.flops << " " << kv.second.bytes << "\n";
   }
   std::string s = os.str();
   SVG_CHECK((int)s.size() + 1 <= buflen, "svg_prof_report: buffer too small");
@@ -311,7 +327,7 @@ int svg_op_attention(svg_ctx* ctx, const uint16_t* q, const uint16_t* k, const u
 int svg_op_xf_gemm(svg_ctx* ctx, const float* X, const float* W, const float* bias, float* Y, int M, int N, int K, int relu_in,
                    void* stream) {
   API_BEGIN
-  xf_gemm(ctx, X, W, bias, Y, M, N, K, relu_in, (hipStream_t)stream);
+  run_planned(ctx, [&]() { xf_gemm(ctx, X, W, bias, Y, M, N, K, relu_in, (hipStream_t)stream); });
   API_END(ctx)
 }
 

@@ -2,6 +2,8 @@
 // (utils/sd_utils.py:222-267) on NHWC bf16 activations.
 #include "models.h"
 #include "../../include/svg_hip.h"
+#include <algorithm>
+#include <cstdlib>
 
 void UnetModel::configure(const char* kv) {
   auto m = parse_kv(kv);
@@ -74,6 +76,15 @@ PackedLinear load_stacked(svg_ctx* ctx, WeightStore& ws, const std::vector<std::
 bool ln_fold_enabled() {
   static const int on = getenv("SVG_LN_FOLD") ? atoi(getenv("SVG_LN_FOLD")) : 1;
   return on != 0;
+}
+
+// rows per ff1 -> ff2 chunk: SVG_FF_CHUNK_MB bounds the chunk's GEGLU intermediate (rows x 4C x 2 bytes); 0 = unchunked.
+// Rounded to a multiple of 4096 rows (whole 256-row tiles of gemm_pp, whole samples at 64 x 64).
+int ff_chunk_rows(int M, int C) {
+  static const int mb = getenv("SVG_FF_CHUNK_MB") ? atoi(getenv("SVG_FF_CHUNK_MB")) : 0;
+  if (mb <= 0) return M;
+  const int64_t rows = ((int64_t)mb << 20) / ((int64_t)8 * C);
+  return (int)std::max<int64_t>(4096, std::min<int64_t>(M, rows / 4096 * 4096));
 }
 
 XfBlockW load_xf(svg_ctx* ctx, WeightStore& ws, const std::string& p, int C, int ctx_dim, hipStream_t s) {
@@ -336,10 +347,17 @@ struct UnetRun {
     // ---- GEGLU feed-forward
     const bf16* a3 = norm(h2, b.ln3);
     {
+      // The GEGLU intermediate is M x 4C (293 MB at 28 clips x 64 x 64 x 1280): written by ff1 and read back by ff2.  Run
+      // the pair over row chunks whose intermediate fits the 256 MiB Infinity Cache (with the other stream group's share):
+      // the same chunk-sized buffer is rewritten per chunk, so ff2 reads it from the cache instead of HBM.
       ctx->arena.push();
-      bf16* g = ctx->arena.get<bf16>(P * 4 * C);
-      linear(ctx, a3, C, b.ff1, g, 4 * C, M, ACT_GEGLU, nullptr, 0, 0, s, rs, rm);
-      linear(ctx, g, 4 * C, b.ff2, h, C, M, ACT_NONE, h2, C, 0, s);   // h is free again: reuse as h3
+      const int rows = ff_chunk_rows(M, C);
+      bf16* g = ctx->arena.get<bf16>((int64_t)std::min(rows, M) * 4 * C);
+      for (int m0 = 0; m0 < M; m0 += rows) {
+        const int mc = std::min(rows, M - m0);
+        linear(ctx, a3 + (int64_t)m0 * C, C, b.ff1, g, 4 * C, mc, ACT_GEGLU, nullptr, 0, 0, s, rs ? rs + m0 : nullptr, rm ? rm + m0 : nullptr);
+        linear(ctx, g, 4 * C, b.ff2, h + (int64_t)m0 * C, C, mc, ACT_NONE, h2 + (int64_t)m0 * C, C, 0, s);   // h is free again: reuse as h3
+      }
       ctx->arena.pop();
     }
     linear(ctx, h, C, b.proj_out, out, C, M, ACT_NONE, x, C, 0, s);
@@ -463,6 +481,8 @@ void UnetModel::ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const flo
         }
       }
       // guidance == 0: noise_pred = uncond + 0*(text - uncond) == uncond — only the uncond half is needed
+      std::unique_ptr<ProfScope> step_scope;
+      if (SVG_LAUNCHING(ctx)) step_scope.reset(new ProfScope(ctx, PK_UNET_STEP, s, 0, 0));
       forward(ctx, cfg ? zin : z, NB, h, w, tvec, text_emb, ctx_len, eps, s, &kv);
       if (SVG_LAUNCHING(ctx)) {
         float sa, s1a, sap, s1ap;
@@ -471,6 +491,7 @@ void UnetModel::ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const flo
         ddim_step(z, eps, cfg ? eps + n : nullptr, guidance, z, n, sa, s1a, sap, s1ap, s);
         if (hist) HIP_OK(hipMemcpyAsync(hist + (int64_t)(i - start_step + 1) * n, z, n * sizeof(float), hipMemcpyDeviceToDevice, s));
       }
+      step_scope.reset();
       ctx->arena.pop();
       if (ctx->arena.dry && i > start_step) break;   // one step is enough to size the arena
     }

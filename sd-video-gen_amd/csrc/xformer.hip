@@ -1,81 +1,111 @@
 // Latent-sequence Transformer kernels (f32 end to end).
 //
-// The model is a weight stream: M = clips*T <= 64 rows against 0.44 G parameters, ~3 FLOP/B, HBM-bound.
-// xf_gemm streams W[N][K] once with 16-B loads and feeds v_mfma_f32_16x16x4_f32 (exact f32 fma chain):
+// The model is a weight stream: M = clips*T rows against 0.44 G parameters.  f32 MFMA runs at 157 TFLOP/s, so the
+// stream is HBM-bound up to M ~ 50 rows (2*M/4 FLOP/B against a ridge of 157e12 / 6.3e12 = 25) and MFMA-bound beyond.
+// xf_gemm streams W[N][K] ONCE for any M <= 336 (56 clips x 6 tokens) and feeds v_mfma_f32_16x16x4_f32 (exact f32 fma chain):
 //   A operand = W tile (16 output columns n), B operand = X^T (16 rows m), D[i=n][j=m].
-//   A lane loads W[n0 + (l&15)][k0 + 4(l>>4) .. +3] as one float4; MFMA j (0..3) consumes element j, so
-//   k-slot q = l>>4 of MFMA j is k = k0 + 4q + j — X is loaded with the identical pattern.
-// One workgroup = 8 waves = 16 output columns; the waves interleave over K in 16-wide steps and are
-// reduced through LDS; an optional 2-way K split across workgroups finishes with f32 atomics onto a
-// zeroed output (two addends: order-independent, so results stay bitwise reproducible).
+//   A K step is 32 floats: lane (l15, lq) loads W[n0 + l15][k0 + 8 lq .. +7] as two float4, so a wave-load covers whole
+//   128-byte lines of 16 rows; MFMA (h, j) consumes element j of half h, so k-slot lq of that MFMA is k = k0 + 8 lq + 4 h + j
+//   — X is loaded with the identical pattern (from L2: every workgroup reads all of X).
+// One workgroup = 8 waves = 16 output columns; the waves interleave over K and are reduced through LDS in a fixed order.
+// W loads run one step ahead of the MFMAs (two 2-KiB wave-loads in flight per wave, 32 KiB per workgroup: the bytes in
+// flight per CU are what sets a stream's rate).  Optional K split across workgroups (short N): partial sums go to f32
+// slabs that a finishing kernel adds in a fixed order (deterministic, unlike atomics with more than two addends).
 #include "kernels.h"
+#include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
 constexpr int XF_WAVES = 8;
-constexpr int XF_MAXMT = 4;   // M <= 64
+constexpr int XF_MAXMT = 21;   // M <= 336
 
 template <int MT>
 __global__ void __launch_bounds__(512) xf_gemm_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                        const float* __restrict__ bias, float* __restrict__ Y, int M,
                                                        int N, int K, int relu_in, int ksplit) {
-  __shared__ f32x4 red[XF_WAVES][MT][64];
+  constexpr int RB = MT < 4 ? MT : 4;            // m tiles reduced through LDS at a time
+  __shared__ f32x4 red[XF_WAVES][RB][64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int n0 = blockIdx.x * 16;
   const int kz = blockIdx.y;
   const int l15 = lane & 15, lq = lane >> 4;
   const int n = n0 + l15;
   const bool n_ok = n < N;
-  const float* wrow = W + (int64_t)(n_ok ? n : 0) * K + 4 * lq;
-  const float* xrow[MT];
-  bool m_ok[MT];
-#pragma unroll
-  for (int t = 0; t < MT; ++t) {
-    const int m = t * 16 + l15;
-    m_ok[t] = m < M;
-    xrow[t] = X + (int64_t)(m_ok[t] ? m : 0) * K + 4 * lq;
-  }
+  const float* wrow = W + (int64_t)(n_ok ? n : 0) * K + 8 * lq;
+  const float* xbase = X + (int64_t)l15 * K + 8 * lq;       // row of m tile t: + t * 16 * K
   f32x4 acc[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int steps = K / 16;
+  const int steps = (K + 31) / 32;
   const int stride = XF_WAVES * ksplit;
-  for (int st = kz * XF_WAVES + wid; st < steps; st += stride) {
-    const int k0 = st * 16;
-    f32x4 w = n_ok ? *(const f32x4*)(wrow + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 x[MT];
+  int st = kz * XF_WAVES + wid;
+  f32x4 w0 = zero, w1 = zero;
+  auto load_w = [&](int step, f32x4& a, f32x4& b) {
+    const int k = step * 32 + 8 * lq;
+    const bool ok = n_ok && step < steps && k < K;          // K % 8 == 0: both halves or none
+    a = ok ? *(const f32x4*)(wrow + step * 32) : zero;
+    b = ok ? *(const f32x4*)(wrow + step * 32 + 4) : zero;
+  };
+  load_w(st, w0, w1);
+  for (; st < steps; st += stride) {
+    f32x4 nw0, nw1;
+    load_w(st + stride, nw0, nw1);                           // next step's weights: in flight under this step's MFMAs
+    const int k0 = st * 32;
+    const bool k_ok = k0 + 8 * lq < K;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-      x[t] = m_ok[t] ? *(const f32x4*)(xrow[t] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const bool ok = k_ok && (t * 16 + l15 < M);
+      const float* xr = xbase + (int64_t)t * 16 * K + k0;
+      f32x4 x0 = ok ? *(const f32x4*)xr : zero;
+      f32x4 x1 = ok ? *(const f32x4*)(xr + 4) : zero;
       if (relu_in) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) x[t][j] = fmaxf(x[t][j], 0.f);
+        for (int j = 0; j < 4; ++j) { x0[j] = fmaxf(x0[j], 0.f); x1[j] = fmaxf(x1[j], 0.f); }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[j], x0[j], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[j], x1[j], acc[t], 0, 0, 0);
+    }
+    w0 = nw0; w1 = nw1;
+  }
+  // D layout: col j = lane&15 -> m, row i = (lane>>4)*4 + reg -> n.  Fixed summation order over the waves.
+  float* out = Y + (ksplit > 1 ? (int64_t)kz * M * N : 0);
+#pragma unroll
+  for (int t0 = 0; t0 < MT; t0 += RB) {
+    if (t0) __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < RB; ++tt)
+      if (t0 + tt < MT) red[wid][tt][lane] = acc[t0 + tt];
+    __syncthreads();
+    for (int idx = tid; idx < RB * 256; idx += 512) {
+      const int tt = idx >> 8, rem = idx & 255, ln = rem >> 2, rg = rem & 3;
+      if (t0 + tt >= MT) continue;
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < XF_WAVES; ++w) sum += red[w][tt][ln][rg];
+      const int m = (t0 + tt) * 16 + (ln & 15);
+      const int nn = n0 + 4 * (ln >> 4) + rg;
+      if (m < M && nn < N) {
+        if (ksplit == 1 && bias) sum += bias[nn];
+        out[(int64_t)m * N + nn] = sum;
       }
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j], x[t][j], acc[t], 0, 0, 0);
   }
-#pragma unroll
-  for (int t = 0; t < MT; ++t) red[wid][t][lane] = acc[t];
-  __syncthreads();
-  // D layout: col j = lane&15 -> m, row i = (lane>>4)*4 + reg -> n
-  for (int idx = tid; idx < MT * 256; idx += 512) {
-    const int t = idx >> 8, rem = idx & 255, ln = rem >> 2, rg = rem & 3;
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < XF_WAVES; ++w) s += red[w][t][ln][rg];
-    const int m = t * 16 + (ln & 15);
-    const int nn = n0 + 4 * (ln >> 4) + rg;
-    if (m < M && nn < N) {
-      if (kz == 0 && bias) s += bias[nn];
-      if (ksplit > 1) atomicAdd(Y + (int64_t)m * N + nn, s);
-      else Y[(int64_t)m * N + nn] = s;
-    }
+}
+
+// Y[m][n] = sum_z slabs[z][m][n] + bias[n], z ascending (deterministic)
+__global__ void __launch_bounds__(256) xf_splitk_finish_kernel(const float* __restrict__ slabs, const float* __restrict__ bias,
+                                                                float* __restrict__ Y, int64_t MN, int N, int ksplit) {
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < MN; i += (int64_t)gridDim.x * 1024) {
+    f32x4 v = *(const f32x4*)(slabs + i);
+    for (int z = 1; z < ksplit; ++z) v += *(const f32x4*)(slabs + (int64_t)z * MN + i);
+    if (bias) v += *(const f32x4*)(bias + (i % N));
+    *(f32x4*)(Y + i) = v;
   }
 }
 
@@ -177,24 +207,46 @@ __global__ void __launch_bounds__(256) xf_attention_kernel(const float* __restri
 
 }  // namespace
 
+template <int MT>
+static void xf_launch(dim3 grid, hipStream_t s, const float* X, const float* W, const float* bias, float* Y, int M, int N, int K,
+                      int relu_in, int ksplit) {
+  hipLaunchKernelGGL((xf_gemm_kernel<MT>), grid, dim3(512), 0, s, X, W, bias, Y, M, N, K, relu_in, ksplit);
+}
+
 void xf_gemm(svg_ctx* ctx, const float* X, const float* W, const float* bias, float* Y, int M, int N, int K, int relu_in,
              hipStream_t s) {
-  SVG_CHECK(K % 16 == 0, "xf_gemm: K=%d must be a multiple of 16", K);
+  SVG_CHECK(K % 8 == 0 && N % 4 == 0, "xf_gemm: K=%d must be a multiple of 8 and N=%d of 4", K, N);
   SVG_CHECK(M >= 1 && M <= 16 * XF_MAXMT, "xf_gemm: M=%d must be in 1..%d", M, 16 * XF_MAXMT);
-  if (!SVG_LAUNCHING(ctx)) return;
   const int nb = cdiv(N, 16);
-  int ksplit = (nb < 192 && K >= 16 * XF_WAVES * 2) ? 2 : 1;
+  // K split: enough workgroups to put >= 2 on every CU while every wave keeps >= 2 steps of 32 (its load pipeline)
+  const int steps = cdiv(K, 32);
+  int ksplit = 1;
+  while (nb * ksplit < 512 && steps / (XF_WAVES * ksplit * 2) >= 2 && ksplit < 8) ksplit *= 2;
+  static const int ks_env = getenv("SVG_XF_KSPLIT") ? atoi(getenv("SVG_XF_KSPLIT")) : 0;
+  if (ks_env > 0) ksplit = ks_env;
+  float* slabs = nullptr;
+  if (ksplit > 1) { ctx->arena.push(); slabs = ctx->arena.get<float>((int64_t)ksplit * M * N); ctx->arena.pop(); }   // stream order protects it
+  if (!SVG_LAUNCHING(ctx)) return;
   ProfScope ps(ctx, PK_XF_GEMM, s, 2.0 * M * (double)N * K, 4.0 * ((double)N * K + (double)M * K + (double)M * N));
-  if (ksplit > 1) HIP_OK(hipMemsetAsync(Y, 0, (size_t)M * N * sizeof(float), s));
   dim3 grid(nb, ksplit);
+  float* dst = ksplit > 1 ? slabs : Y;
   const int mt = cdiv(M, 16);
-  switch (mt) {
-    case 1: hipLaunchKernelGGL((xf_gemm_kernel<1>), grid, dim3(512), 0, s, X, W, bias, Y, M, N, K, relu_in, ksplit); break;
-    case 2: hipLaunchKernelGGL((xf_gemm_kernel<2>), grid, dim3(512), 0, s, X, W, bias, Y, M, N, K, relu_in, ksplit); break;
-    case 3: hipLaunchKernelGGL((xf_gemm_kernel<3>), grid, dim3(512), 0, s, X, W, bias, Y, M, N, K, relu_in, ksplit); break;
-    default: hipLaunchKernelGGL((xf_gemm_kernel<4>), grid, dim3(512), 0, s, X, W, bias, Y, M, N, K, relu_in, ksplit); break;
-  }
+  if (mt <= 1) xf_launch<1>(grid, s, X, W, bias, dst, M, N, K, relu_in, ksplit);
+  else if (mt <= 2) xf_launch<2>(grid, s, X, W, bias, dst, M, N, K, relu_in, ksplit);
+  else if (mt <= 3) xf_launch<3>(grid, s, X, W, bias, dst, M, N, K, relu_in, ksplit);
+  else if (mt <= 4) xf_launch<4>(grid, s, X, W, bias, dst, M, N, K, relu_in, ksplit);
+  else if (mt <= 6) xf_launch<6>(grid, s, X, W, bias, dst, M, N, K, relu_in, ksplit);
+  else if (mt <= 8) xf_launch<8>(grid, s, X, W, bias, dst, M, N, K, relu_in, ksplit);
+  else if (mt <= 11) xf_launch<11>(grid, s, X, W, bias, dst, M, N, K, relu_in, ksplit);
+  else if (mt <= 16) xf_launch<16>(grid, s, X, W, bias, dst, M, N, K, relu_in, ksplit);
+  else xf_launch<21>(grid, s, X, W, bias, dst, M, N, K, relu_in, ksplit);
   check_launch("xf_gemm");
+  if (ksplit > 1) {
+    const int64_t MN = (int64_t)M * N;
+    hipLaunchKernelGGL(xf_splitk_finish_kernel, dim3((unsigned)std::min<int64_t>((MN / 4 + 255) / 256, 1024)), dim3(256), 0, s, slabs, bias, Y,
+                       MN, N, ksplit);
+    check_launch("xf_splitk_finish");
+  }
 }
 
 void xf_add_ln(const float* x, const float* r, const float* g, const float* b, float* y, int M, int d, float eps, hipStream_t s) {

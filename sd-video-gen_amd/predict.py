@@ -46,7 +46,9 @@ def sample_clips(model, sd_utils, clips_u8, pred_frames, denoise=False, start_st
     oracle fixtures of tests/golden/sd_*.pt were drawn that way); default is the device generator, like the reference.
     Returns all_latents (C, 4+N, D_lat) f32 [and the decoded frames (C,4+N,F,F,3) uint8].
     """
-    ctx = sd_utils.ctx
+    ctx = sd_utils.vae.ctx                      # (checked: the context's slots still hold this SDUtils' networks)
+    if denoise:
+        assert sd_utils.unet is not None and sd_utils.unet.ctx is ctx, "sample_clips(denoise=True) needs SDUtils built with --denoise"
     dev = clips_u8.device
     C, T, F = clips_u8.shape[0], clips_u8.shape[1], clips_u8.shape[2]
     assert T == 5, "the reference conditions on 5 frames (predict.py:57, window hard-coded at :196)"
@@ -255,7 +257,7 @@ def main(argv=None):
     ckpt = "./checkpoints/" + str(args.config) + "_" + str(args.index) + "_" + str(args.mode) + ".pt"     # predict.py:51
     from .sd_utils import synthetic_allowed
     if os.path.exists(ckpt):
-        model.load_state_dict(torch.load(ckpt, map_location="cpu"))
+        model.load_state_dict(torch.load(ckpt, map_location="cpu", weights_only=True))
         weights_source = ckpt
     elif synthetic_allowed():
         weights_source = "initial (seeded) parameters — SVG_ALLOW_SYNTHETIC_WEIGHTS"

@@ -202,9 +202,9 @@ class SDUtils():
         prompt string ('' included), so equal prompts give equal embeddings as the real encoder would."""
         if self._text_embeddings is not None:
             return self._text_embeddings.to(self.device)
-        if self.unet_source not in (None, "synthetic"):
+        if str(self.unet_source).startswith("local:"):
             # real UNet weights conditioned on a random stand-in would silently diverge from the reference's CLIP('')
-            raise RuntimeError("encode_text: real UNet weights (%s) need real CLIP embeddings — pass text_embeddings= "
+            raise RuntimeError("encode_text: UNet weights from %s need real CLIP embeddings — pass text_embeddings= "
                                "to SDUtils (the CLIP text model's weights are not available)" % self.unet_source)
         import zlib
 
@@ -225,7 +225,7 @@ class SDUtils():
         N, H, W, _ = imgs.shape
         if eps is None:
             eps = torch.randn((N, 4, H // 8, W // 8), device=self.device)
-        return self.ctx.vae_encode(imgs, eps=eps)
+        return self.vae.ctx.vae_encode(imgs, eps=eps)
 
     def encode_batch(self, img_batch, use_sos=True, eps=None):
         img_batch = torch.as_tensor(img_batch)
@@ -239,11 +239,11 @@ class SDUtils():
     # ---- sd_utils.py:156-169 ---------------------------------------------------------------------------
     def decode_img_latents(self, latents):
         """-> numpy (N,8h,8w,3) uint8 on the HOST, like the reference (callers do np.array(img[0]))."""
-        return self.ctx.vae_decode(latents.to(self.device)).cpu().numpy()
+        return self.vae.ctx.vae_decode(latents.to(self.device)).cpu().numpy()
 
     def decode_img_latents_device(self, latents, out_hw=None):
         """same frames, kept on the device (no D2H sync), optionally nearest-resized (predict.py:158,178)."""
-        return self.ctx.vae_decode(latents.to(self.device), out_hw=out_hw)
+        return self.vae.ctx.vae_decode(latents.to(self.device), out_hw=out_hw)
 
     # ---- sd_utils.py:222-267 ---------------------------------------------------------------------------
     def gen_i2i_latents(self, text_embeddings, height=512, width=512, num_inference_steps=50, guidance_scale=7.5,
@@ -255,7 +255,7 @@ class SDUtils():
         latents = latents.to(self.device)
         if start_step > 0 and noise is None:
             noise = torch.randn_like(latents)
-        return self.ctx.ddim_loop(latents, text_embeddings.to(self.device), num_steps=num_inference_steps, start_step=start_step,
+        return self.unet.ctx.ddim_loop(latents, text_embeddings.to(self.device), num_steps=num_inference_steps, start_step=start_step,
                                   guidance=guidance_scale, noise=noise, return_hist=return_all_latents)
 
     def perturb_latents(self, latents, scale=0.1):

@@ -54,7 +54,7 @@ class Transformer(nn.Module):
         self._uploaded_version = None
 
     # ---- weight hand-over -------------------------------------------------------------------------
-    def _version(self):
+    def _weights_version(self):
         return tuple(int(p._version) for p in self.parameters()) + (id(self._ctx),)
 
     def use_context(self, ctx):
@@ -67,7 +67,7 @@ class Transformer(nn.Module):
         ctx = getattr(self, "_bound_ctx", None) or _lib.default_context()
         # the context's Transformer slot may have been taken by another module (another checkpoint, the text variant)
         # since the last call: upload again unless the slot still holds THIS module's current parameters
-        if self._ctx is ctx and ctx.owner(_lib.SVG_TRANSFORMER) is self and self._uploaded_version == self._version():
+        if self._ctx is ctx and ctx.owner(_lib.SVG_TRANSFORMER) is self and self._uploaded_version == self._weights_version():
             return ctx
         self._ctx = ctx
         ctx.configure(_lib.SVG_TRANSFORMER, d_lat=self.d_lat, d_model=self.dim_model, heads=self.num_heads,
@@ -76,7 +76,7 @@ class Transformer(nn.Module):
         ctx.load_state_dict(_lib.SVG_TRANSFORMER, self.state_dict())
         self.n_params = ctx.finalize(_lib.SVG_TRANSFORMER)
         ctx.claim(_lib.SVG_TRANSFORMER, self)
-        self._uploaded_version = self._version()
+        self._uploaded_version = self._weights_version()
         return ctx
 
     def load_state_dict(self, *a, **k):

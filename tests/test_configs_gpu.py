@@ -10,7 +10,8 @@ through conftest.margin (printed, and collected into gpurun_out/parity_margins.j
   configs[3]  11_27_ucf_final, F=128, 16 predicted frames (start step 48: 2 of the 50 steps per frame)  sd_cfg3_rollout.pt
   configs[4]  11_27_ucf_text_final: d = 2432 text-conditioned Transformer; guidance_scale 7.5 => the batch-2 UNet call of
               evaluation/predict_fvd2_denoise.py:227-229 is genuinely needed (in-test oracle, a few UNet calls)
-Tolerances are <= 3x what was measured on MI355X (bf16 storage with f32 accumulation against the fp32 oracle).
+Tolerances are <= 3x what was measured on MI355X (bf16 storage with f32 accumulation against the fp32 oracle); the
+free-running many-step comparisons are bounded by the saturation level of a chaotic map instead (see test_config2_*).
 """
 import os
 import sys
@@ -26,6 +27,8 @@ from oracle import gen_golden_sd as GG, sd_oracle as SO, transformer_oracle as T
 from sd_video_gen_amd import _lib  # noqa: E402
 
 pytestmark = pytest.mark.gpu
+FORCED_TOL = 4.5e-2  # one DDIM step from the oracle's latent: measured 1.5e-2 worst (bf16 UNet call 1e-2, amplified by 1/sqrt(alpha_t))
+SATURATION = 0.9     # two decorrelated latents of equal norm differ by ~sqrt(2) x correlation loss; measured 0.55 (both HIP-vs-HIP and HIP-vs-oracle)
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
@@ -72,28 +75,56 @@ def _rollout(cfg_name, g, nets):
 
 
 def test_config2_full_frame_50_steps(ctx, nets):
-    """configs[2] end to end for one generated frame, and the per-step drift of the 50-step DDIM loop."""
+    """configs[2] end to end for one generated frame, and the 50-step DDIM loop step by step.
+
+    What was measured on MI355X (profiles/r02_parity.md): the DDIM map of this seeded random-weight UNet is chaotic — a
+    1e-3 (rel-L2) perturbation of the starting latent grows 16x in the first step and saturates near 0.55 within ten steps,
+    HIP path against HIP path, exactly as the bf16-vs-fp32 difference does.  A free-running 50-step comparison therefore
+    measures the conditioning of the (untrained) network, not the arithmetic.  The arithmetic is checked per step with
+    teacher forcing: every one of the 50 steps starts from the ORACLE's latent z_k and must reproduce the oracle's z_{k+1};
+    the free-running table is reported, its first step asserted, and its tail bounded by the saturation level."""
     g = gold("sd_cfg2_frame.pt")
     lat, sdu = _rollout("1_16_kitti_L1_64", g, nets)
-    margin("cfg2 conditioning latents (VAE encode @64)", rel_l2(lat[:, :4], g["all_latents"][:, :4]), 1.5e-2)
-    margin("cfg2 generated frame latent after 50 DDIM steps + 3 uint8 round trips", rel_l2(lat[:, 4:], g["all_latents"][:, 4:]), 6e-2)
-    # drift: the SAME starting latent as the oracle's loop (isolates UNet + scheduler from what is upstream of them)
-    hist = sdu.ctx.ddim_loop(g["lat0"].cuda(), GG.text_emb().cuda(), num_steps=50, start_step=0, guidance=0.0, return_hist=True).cpu()
+    e_cond = rel_l2(lat[:, :4], g["all_latents"][:, :4])
+    e_frame = rel_l2(lat[:, 4:], g["all_latents"][:, 4:])
+    emb = GG.text_emb().cuda()
+    hist_ref = g["hist"]
+    assert g["hist_steps"] == list(range(51)) and hist_ref.shape == (51, 4, 64, 64)
+    # ---- teacher-forced: all 50 steps in ONE batch-50 UNet call (per-sample timesteps 980, 960, ..., 0), then the scheduler
+    c = sdu.unet.ctx
+    ts = torch.tensor([980.0 - 20.0 * k for k in range(50)])
+    eps = c.unet_forward(hist_ref[:50].cuda(), ts.cuda(), emb[:1].repeat(50, 1, 1))          # guidance 0: the uncond half
+    forced = []
+    for k in range(50):
+        t = int(ts[k])
+        z1 = c.ddim_step(hist_ref[k:k + 1].cuda(), eps[k:k + 1], t, t - 20).cpu()
+        forced.append(rel_l2(z1, hist_ref[k + 1:k + 2]))
+    print("[parity] teacher-forced DDIM step k -> k+1 (oracle z_k in), rel-L2 of z_{k+1}: " + "  ".join("%d:%.1e" % (k, e) for k, e in enumerate(forced)))
+    # ---- free-running from the oracle's starting latent, and the growth of a 1e-3 perturbation through the same HIP loop
+    hist = c.ddim_loop(g["lat0"].cuda(), emb, num_steps=50, start_step=0, guidance=0.0, return_hist=True).cpu()
     assert hist.shape[0] == 51
-    table = []
-    for s, ref in zip(g["hist_steps"], g["hist"]):
-        table.append((s, rel_l2(hist[s], ref)))
-    print("[parity] DDIM drift vs the fp32 oracle, rel-L2 of the latent after k steps: " + "  ".join("k=%d: %.2e" % t for t in table))
-    worst = max(e for _, e in table)
-    margin("cfg2 DDIM latent drift, worst over 50 steps", worst, 4e-2)
-    margin("cfg2 DDIM latent after 50 steps", table[-1][1], 4e-2)
+    ks = [0, 1, 2, 3, 5, 10, 15, 20, 30, 40, 50]
+    table = [(k, rel_l2(hist[k], hist_ref[k])) for k in ks]
+    print("[parity] free-running DDIM drift vs the fp32 oracle after k steps: " + "  ".join("k=%d: %.2e" % t for t in table))
+    gp = torch.Generator().manual_seed(99)
+    d = torch.randn(g["lat0"].shape, generator=gp)
+    pert = g["lat0"] + 1e-3 * d * (g["lat0"].norm() / d.norm())
+    hist_p = c.ddim_loop(pert.cuda(), emb, num_steps=50, start_step=0, guidance=0.0, return_hist=True).cpu()
+    sens = [(k, rel_l2(hist_p[k], hist[k])) for k in ks]
+    print("[parity] growth of a 1e-3 input perturbation through the same loop (HIP vs HIP): " + "  ".join("k=%d: %.2e" % t for t in sens))
     import json
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "ddim_drift.json"), "w") as f:
-            json.dump({"steps": [t[0] for t in table], "rel_l2": [t[1] for t in table]}, f)
+            json.dump({"teacher_forced_rel_l2_per_step": forced, "steps": ks, "free_running_rel_l2_vs_oracle": [t[1] for t in table],
+                       "growth_of_1e-3_perturbation_hip_vs_hip": [t[1] for t in sens]}, f)
     except OSError:
         pass
+    margin("cfg2 conditioning latents (VAE encode @64)", e_cond, 1.2e-2)
+    margin("cfg2 DDIM step, teacher-forced, worst of the 50 steps", max(forced), FORCED_TOL)
+    margin("cfg2 DDIM free-running, after the first step", table[1][1], FORCED_TOL)
+    margin("cfg2 DDIM free-running after 50 steps (chaotic map: saturation level)", table[-1][1], SATURATION)
+    margin("cfg2 generated frame latent after 50 DDIM steps + 3 uint8 round trips (same)", e_frame, SATURATION)
 
 
 def test_config1_rollout_8_frames_start25(ctx, nets):
@@ -102,8 +133,10 @@ def test_config1_rollout_8_frames_start25(ctx, nets):
     lat, _ = _rollout("1_19_ball_complex_L1_64", g, nets)
     for k in range(g["pred_frames"]):
         print("[parity] cfg1 frame %d rel-L2 %.3e" % (k, rel_l2(lat[:, 4 + k], g["all_latents"][:, 4 + k])))
-    margin("cfg1 8-frame rollout, all generated latents", rel_l2(lat[:, 4:], g["all_latents"][:, 4:]), 1e-1)
-    margin("cfg1 8-frame rollout, last frame", rel_l2(lat[:, -1], g["all_latents"][:, -1]), 1.5e-1)
+    # 25 free-running DDIM steps per frame: the chaotic regime of test_config2_full_frame_50_steps (saturation), then three
+    # uint8 round trips and the next frame's Transformer step on top
+    margin("cfg1 8-frame rollout (25 steps / frame), all generated latents", rel_l2(lat[:, 4:], g["all_latents"][:, 4:]), SATURATION)
+    margin("cfg1 8-frame rollout, first generated frame", rel_l2(lat[:, 4], g["all_latents"][:, 4]), SATURATION)
 
 
 def test_config3_rollout_16_frames_f128(ctx, nets):
@@ -112,8 +145,9 @@ def test_config3_rollout_16_frames_f128(ctx, nets):
     lat, _ = _rollout("11_27_ucf_final", g, nets)
     for k in (0, 7, 15):
         print("[parity] cfg3 frame %d rel-L2 %.3e" % (k, rel_l2(lat[:, 4 + k], g["all_latents"][:, 4 + k])))
-    margin("cfg3 16-frame rollout, all generated latents", rel_l2(lat[:, 4:], g["all_latents"][:, 4:]), 1e-1)
-    margin("cfg3 16-frame rollout, last frame", rel_l2(lat[:, -1], g["all_latents"][:, -1]), 1.5e-1)
+    margin("cfg3 16-frame rollout, first generated frame", rel_l2(lat[:, 4], g["all_latents"][:, 4]), 7e-2)       # measured 2.6e-2
+    margin("cfg3 16-frame rollout, all generated latents", rel_l2(lat[:, 4:], g["all_latents"][:, 4:]), 2.2e-1)   # measured 7.8e-2
+    margin("cfg3 16-frame rollout, last frame (16 autoregressive steps)", rel_l2(lat[:, -1], g["all_latents"][:, -1]), 3e-1)   # 1.1e-1
 
 
 def test_config4_guidance_7p5_full_size(ctx, nets):
@@ -131,12 +165,12 @@ def test_config4_guidance_7p5_full_size(ctx, nets):
     x2 = torch.cat([z, z])
     e = ctx.unet_forward(x2.cuda(), torch.tensor([500.0, 500.0]).cuda(), emb.cuda()).cpu()
     ref = SO.unet_forward(usd, x2, 500, emb)
-    margin("cfg4 batch-2 UNet call (uncond/cond rows), full size", rel_l2(e, ref), 1.5e-2)
-    margin("cfg4 guided noise u + 7.5 (c - u)", rel_l2(e[:1] + 7.5 * (e[1:] - e[:1]), ref[:1] + 7.5 * (ref[1:] - ref[:1])), 6e-2)
+    margin("cfg4 batch-2 UNet call (uncond/cond rows), full size", rel_l2(e, ref), 2.5e-2)      # measured 1.05e-2
+    margin("cfg4 guided noise u + 7.5 (c - u)", rel_l2(e[:1] + 7.5 * (e[1:] - e[:1]), ref[:1] + 7.5 * (ref[1:] - ref[:1])), 2e-1)
     S = 47
     got = ctx.ddim_loop(z.cuda(), emb.cuda(), num_steps=50, start_step=S, guidance=7.5, noise=noise.cuda()).cpu()
     want = SO.gen_i2i_latents(usd, emb, z, 50, 7.5, S, noise=noise)
-    margin("cfg4 3 DDIM steps at guidance 7.5", rel_l2(got, want), 3e-2)
+    margin("cfg4 3 DDIM steps at guidance 7.5", rel_l2(got, want), 1.5e-2)                       # measured 5.5e-3
 
 
 def test_config4_text_transformer_full_size(ctx):
@@ -156,6 +190,6 @@ def test_config4_text_transformer_full_size(ctx):
     out = m(X.cuda(), names, X.cuda(), m.get_tgt_mask(6).cuda(), pe_row=torch.zeros(2, dtype=torch.int32)).cpu()
     for b in range(2):
         ref = TO.forward(sd, X[b:b + 1], X[b:b + 1], 8, TO.get_tgt_mask(6), txt=txt[b:b + 1])
-        margin("cfg4 text Transformer d=2432 forward, clip %d" % b, rel_l2(out[:, b:b + 1], ref), 2e-5)
+        margin("cfg4 text Transformer d=2432 forward, clip %d" % b, rel_l2(out[:, b:b + 1], ref), 8e-6)
     p = predict_text(m, X[:1].cuda(), names[:1]).cpu()
-    margin("cfg4 predict_text (D_lat,)", rel_l2(p, TO.predict(sd, X[:1], 8, txt=txt[:1])), 2e-5)
+    margin("cfg4 predict_text (D_lat,)", rel_l2(p, TO.predict(sd, X[:1], 8, txt=txt[:1])), 8e-6)

@@ -15,7 +15,7 @@ from oracle import loop_oracle, sd_oracle as SO  # noqa: E402
 from sd_video_gen_amd import _lib  # noqa: E402
 
 pytestmark = pytest.mark.gpu
-NET_TOL = 3e-2
+NET_TOL = 3e-2      # per-network bound; each check below states its own <= 3x-measured tolerance
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -54,12 +54,12 @@ def test_unet_step_full_size(ctx, full_unet):
     e = ctx.unet_forward(x.cuda(), torch.tensor([500.0]).cuda(), c.cuda())
     ref = SO.unet_forward(full_unet, x, 500, c)
     assert torch.isfinite(e).all()
-    margin("full-size UNet call, batch 1 (803 GFLOP)", rel_l2(e.cpu(), ref), NET_TOL)
+    margin("full-size UNet call, batch 1 (803 GFLOP)", rel_l2(e.cpu(), ref), 2.5e-2)      # measured 9.7e-3
     # batch rows are independent and the duplicated-batch form of sd_utils.py:249 gives the same rows
     e2 = ctx.unet_forward(torch.cat([x, x]).cuda(), torch.tensor([500.0, 500.0]).cuda(), torch.cat([c, c]).cuda())
     # (a different batch changes tile widths / split-K, hence bf16 rounding along the 60+ layers: same tolerance class)
-    margin("full-size UNet: same sample at batch 2 vs batch 1 (tile / split-K selection)", rel_l2(e2[:1].cpu(), e.cpu()), 2e-2)
-    margin("full-size UNet batch 2 vs oracle", rel_l2(e2[:1].cpu(), ref), NET_TOL)
+    margin("full-size UNet: same sample at batch 2 vs batch 1 (tile / split-K selection)", rel_l2(e2[:1].cpu(), e.cpu()), 2.5e-2)   # measured 9.2e-3: as large as the distance to the oracle
+    margin("full-size UNet batch 2 vs oracle", rel_l2(e2[:1].cpu(), ref), 2.5e-2)
     assert torch.equal(e2[:1], e2[1:])                                   # identical rows inside one launch are bit-identical
 
 
@@ -69,11 +69,11 @@ def test_vae_full_size_128(ctx, full_vae):
     eps = torch.randn(2, 4, 16, 16, generator=g)
     z, mom = ctx.vae_encode(img.cuda(), eps=eps.cuda(), return_moments=True)
     x = 2 * ((img / 255.0).float().permute(0, 3, 1, 2) - 0.5)
-    margin("full-size VAE encoder moments @128", rel_l2(mom.cpu(), SO.vae_encode_moments(full_vae, x)), NET_TOL)
+    margin("full-size VAE encoder moments @128", rel_l2(mom.cpu(), SO.vae_encode_moments(full_vae, x)), NET_TOL)   # measured 1.3e-2
     zz = torch.randn(2, 4, 16, 16, generator=g) * 0.4
     out, fl = ctx.vae_decode(zz.cuda(), return_float=True)
     ref_img, ref_fl = SO.decode_img_latents(full_vae, zz, return_float=True)
-    margin("full-size VAE decoder float output @128", rel_l2(fl.cpu(), ref_fl), NET_TOL)
+    margin("full-size VAE decoder float output @128", rel_l2(fl.cpu(), ref_fl), 4.5e-2)   # measured 2.1e-2 (31 convs, 26 GroupNorms at bf16)
     d = (out.cpu().int() - ref_img.int()).abs().float()
     margin("full-size VAE decoder uint8 frame mean |diff|", d.mean(), 1.0, unit="LSB")
     margin("full-size VAE decoder share of pixels off by > 2 LSB", 1.0 - (d <= 2).float().mean(), 0.03, unit="fraction")
@@ -116,8 +116,8 @@ def test_config2_one_denoised_frame_full_size(ctx, full_unet, full_vae):
     xsd = {k: v.cpu() for k, v in m.state_dict().items()}
     ref = loop_oracle.sample_clip(xsd, 8, full_vae, clips[0], 1, noise, denoise=True, start_step=S, unet_sd=full_unet,
                                   text_emb=emb.cpu())
-    margin("cfg2 (2 DDIM steps) conditioning latents", rel_l2(lat[:, :4].cpu(), ref[:, :4]), NET_TOL)   # VAE encode @64
-    margin("cfg2 (2 DDIM steps) predicted frame", rel_l2(lat[:, 4:].cpu(), ref[:, 4:]), 6e-2)          # three uint8 round trips in between
+    margin("cfg2 (2 DDIM steps) conditioning latents", rel_l2(lat[:, :4].cpu(), ref[:, :4]), 1.1e-2)   # VAE encode @64
+    margin("cfg2 (2 DDIM steps) predicted frame", rel_l2(lat[:, 4:].cpu(), ref[:, 4:]), 7e-2)       # measured 2.6e-2          # three uint8 round trips in between
 
 
 def test_config1_plumbing_full_size(ctx, full_vae):
@@ -138,4 +138,4 @@ def test_config1_plumbing_full_size(ctx, full_vae):
         gen = torch.Generator(device="cuda").manual_seed(9 + c)
         noise = {"cond": torch.randn((5, 4, 16, 16), generator=gen, device="cuda").cpu()}
         ref = loop_oracle.sample_clip(xsd, 8, full_vae, clips[c], 4, noise)
-        margin("cfg0 config_test 4+4 frames, clip %d" % c, rel_l2(lat[c:c + 1].cpu(), ref), NET_TOL)
+        margin("cfg0 config_test 4+4 frames, clip %d" % c, rel_l2(lat[c:c + 1].cpu(), ref), 1e-2)      # measured 3.5e-3

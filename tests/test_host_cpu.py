@@ -184,6 +184,25 @@ def test_text_model_loads_reference_checkpoint_layout():
         m.load_state_dict({k: v for k, v in sd.items() if k != "out.bias"})
 
 
+def test_checkpoint_format_roundtrip(tmp_path):
+    """checkpoints are plain `torch.save(model.state_dict())` files (trainer.py:469-480): tensors only, loadable with
+    weights_only=True, keys as SURVEY appendix B — in both directions."""
+    from sd_video_gen_amd import config as svg_config
+    from sd_video_gen_amd.transformer import Transformer
+    svg_config.set_args(["--dataset", "ball", "--config", "model_10_26"])
+    torch.manual_seed(0)
+    m = Transformer(dim_model=32, num_heads=4, num_encoder_layers=1, num_decoder_layers=2)
+    p = str(tmp_path / "model_10_26_0_train.pt")
+    torch.save(m.state_dict(), p)
+    assert os.path.getsize(p) < 2 * sum(t.numel() * 4 for t in m.state_dict().values())     # no module pickled along
+    sd = torch.load(p, map_location="cpu", weights_only=True)
+    ref_keys = set(torch.load(os.path.join(ROOT, "tests", "golden", "transformer_tiny.pt"), weights_only=False)["state_dict"])
+    assert set(sd) == ref_keys                                         # the reference module's own key set (G1)
+    m2 = Transformer(dim_model=32, num_heads=4, num_encoder_layers=1, num_decoder_layers=2)
+    m2.load_state_dict(sd)
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+
+
 def test_bench_refuses_mismatched_world_size():
     """bench.py --gpus N under a launcher that started another number of ranks stops with a clear message (and never
     initialises the GPU in the parent when it spawns the ranks itself)."""

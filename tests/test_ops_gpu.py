@@ -269,7 +269,8 @@ def test_attention_large_logits_and_shift_precision(ctx):
 
 
 @pytest.mark.parametrize("M,N,K,relu", [(6, 2048, 256, 0), (5, 6144, 2048, 0), (48, 2048, 2048, 1), (1, 256, 2048, 0),
-                                        (64, 96, 32, 0), (17, 1024, 2048, 1), (6, 32, 256, 0)])
+                                        (64, 96, 32, 0), (17, 1024, 2048, 1), (6, 32, 256, 0), (168, 2048, 2048, 0), (336, 256, 2048, 1),
+                                        (100, 2432, 2432, 0), (336, 2048, 48, 0), (65, 36, 40, 0)])
 def test_xf_gemm(ctx, M, N, K, relu):
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     X = torch.randn(M, K, device="cuda", generator=g)

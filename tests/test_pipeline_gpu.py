@@ -56,7 +56,7 @@ def test_loop_no_denoise_matches_oracle(ctx):
     for c in range(3):
         noise = clip_noise_cpu(seeds[c], 512, 64, 0, 0)
         ref = loop_oracle.sample_clip(xsd, 4, vsd, clips[c], 4, noise, vae_cfg=VCFG)
-        margin("test_loop_no_denoise_matches_oracle: lat[c:c + 1].cpu()", rel_l2(lat[c:c + 1].cpu(), ref), 3e-2)
+        margin("test_loop_no_denoise_matches_oracle: lat[c:c + 1].cpu()", rel_l2(lat[c:c + 1].cpu(), ref), 9e-3)      # measured 2.9e-3
     # batch invariance: a clip sampled alone equals the same clip inside the batch
     alone = sample_clips(m, sdu, clips[1:2].cuda(), 4, seeds=seeds[1:2])
     assert rel_l2(alone.cpu(), lat[1:2].cpu()) < 2e-3
@@ -79,7 +79,7 @@ def test_text_conditioned_loop_matches_oracle(ctx):
     for c in range(2):
         noise = clip_noise_cpu(seeds[c], 512, 64, 0, 0)
         ref = loop_oracle.sample_clip(xsd, 8, vsd, clips[c], 3, noise, vae_cfg=VCFG, txt=txt[c:c + 1])
-        margin("test_text_conditioned_loop_matches_oracle: lat[c:c + 1].cpu()", rel_l2(lat[c:c + 1].cpu(), ref), 3e-2)
+        margin("test_text_conditioned_loop_matches_oracle: lat[c:c + 1].cpu()", rel_l2(lat[c:c + 1].cpu(), ref), 6e-3)   # measured 1.9e-3
     # the class changes the prediction
     other = sample_clips(m, sdu, clips.cuda(), 3, seeds=seeds, cls_list=names[::-1])
     assert rel_l2(other[:, 4:].cpu(), lat[:, 4:].cpu()) > 1e-3
@@ -102,7 +102,7 @@ def test_loop_denoise_matches_oracle(ctx):
         ref = loop_oracle.sample_clip(xsd, 4, vsd, clips[c], 2, noise, denoise=True, start_step=S, unet_sd=usd,
                                       text_emb=emb.cpu(), vae_cfg=VCFG, unet_cfg=UCFG, res=128)
         # three uint8 round trips per frame sit between the networks: a 1-LSB pixel difference re-enters the encoder
-        margin("test_loop_denoise_matches_oracle: lat[c:c + 1].cpu()", rel_l2(lat[c:c + 1].cpu(), ref), 6e-2)
+        margin("test_loop_denoise_matches_oracle: lat[c:c + 1].cpu()", rel_l2(lat[c:c + 1].cpu(), ref), 2e-2)       # measured 6.6e-3
 
 
 def test_sdutils_reference_surface(ctx):

@@ -98,13 +98,14 @@ def main():
             print("b=%d %7d %5d  %8.3f ms  %7.1f GB/s" % (b, HW, C, ms, 3 * x.numel() * 2 / ms / 1e6))
     if "xf" in a.what:
         print("== xf_gemm: M N K  ms  GB/s")
-        for (M, N, K) in ((6, 2048, 2048), (6, 6144, 2048), (48, 6144, 2048), (48, 2048, 2048), (6, 2048, 256), (6, 256, 2048), (48, 4096, 2048)):
+        for (M, N, K) in ((6, 2048, 2048), (6, 6144, 2048), (48, 6144, 2048), (48, 2048, 2048), (6, 2048, 256), (6, 256, 2048), (48, 4096, 2048),
+                          (64, 2048, 2048), (64, 6144, 2048), (168, 2048, 2048), (168, 6144, 2048), (336, 2048, 2048), (336, 6144, 2048)):
             X = torch.randn(M, K, device="cuda")
             W = torch.randn(N, K, device="cuda")
             Y = torch.empty(M, N, device="cuda")
             ms, _, by = timeit(ctx, "xf_gemm", lambda: ctx.check(ctx.lib.svg_op_xf_gemm(
                 ctx.h, X.data_ptr(), W.data_ptr(), None, Y.data_ptr(), M, N, K, 0, stream()), "xf"))
-            print("%3d %5d %5d  %8.4f ms  %7.1f GB/s" % (M, N, K, ms, N * K * 4 / ms / 1e6))
+            print("%3d %5d %5d  %8.4f ms  %7.1f GB/s  %6.1f TFLOP/s (f32 MFMA peak 157)" % (M, N, K, ms, N * K * 4 / ms / 1e6, 2.0 * M * N * K / ms / 1e9))
 
 
 if __name__ == "__main__":
