@@ -19,6 +19,8 @@
  *   svg_ddim_loop             utils/sd_utils.py:222-267 (gen_i2i_latents: DDIMScheduler(0.00085,
  *                             0.012,'scaled_linear',1000), set_timesteps, add_noise, CFG combine,
  *                             scheduler.step) — the hot loop
+ *   svg_clip_text_forward     utils/sd_utils.py:84,91 (self.text_encoder(input_ids)[0]: transformers CLIPTextModel of
+ *                             'openai/clip-vit-large-patch14', last_hidden_state) — tokenisation stays on the host
  *   svg_resize_nearest_u8     prediction/predict.py:158,178 (F.interpolate on uint8, mode nearest)
  *   svg_load_weight/finalize  utils/sd_utils.py:52-66 + prediction/predict.py:50-51 (from_pretrained /
  *                             load_state_dict: tensors are handed over by their state_dict names)
@@ -48,7 +50,7 @@ extern "C" {
 
 typedef struct svg_ctx svg_ctx;
 
-enum svg_model { SVG_TRANSFORMER = 0, SVG_VAE = 1, SVG_UNET = 2 };
+enum svg_model { SVG_TRANSFORMER = 0, SVG_VAE = 1, SVG_UNET = 2, SVG_CLIP_TEXT = 3 };
 enum svg_status { SVG_OK = 0, SVG_ERR_RUNTIME = -1, SVG_ERR_INVALID = -2 };
 
 /* ---- context ------------------------------------------------------------------------------ */
@@ -63,7 +65,9 @@ const char* svg_version(void);
  *   text-conditioned variant, whose first layer is named project_image_embedding instead of embedding).
  * VAE keys: block_out (128,256,512,512), layers (2), groups (32), latent (4).
  * UNet keys: block_out (320,640,1280,1280), layers (2), heads (8), ctx_dim (768), groups (32),
- *            in_ch (4), out_ch (4), attn (1,1,1,0: cross-attention per down block). */
+ *            in_ch (4), out_ch (4), attn (1,1,1,0: cross-attention per down block).
+ * CLIP text keys: vocab (49408), d_model (768), heads (12), layers (12), ffn (3072), max_pos (77); tensors by their
+ *   transformers names without the "text_model." prefix (embeddings.token_embedding.weight, encoder.layers.N.*, ...). */
 int svg_model_configure(svg_ctx* ctx, int model, const char* kv);
 /* data: f32, host or device memory (hipMemcpyDefault); shape/ndim as in the state_dict. */
 int svg_load_weight(svg_ctx* ctx, int model, const char* name, const float* data,
@@ -85,6 +89,11 @@ int svg_transformer_forward(svg_ctx* ctx, const float* src, const float* tgt, in
  * token = cat(project_image_embedding(x), text[b]) * sqrt(d_model) + PE, d_model = DIM_MODEL + text_dim. */
 int svg_transformer_forward_text(svg_ctx* ctx, const float* src, const float* tgt, const float* text, int B, int Ts,
                                  int Tt, const float* mask, const int32_t* pe_row, float* out, void* stream);
+
+/* ---- CLIP text encoder ---------------------------------------------------------------------- */
+/* input_ids (B,T) int32 token ids (T <= max_pos; the reference pads to 77); out (B,T,d_model) f32 = last_hidden_state.
+ * Causal mask only (the reference passes no attention mask); f32 arithmetic like the reference. */
+int svg_clip_text_forward(svg_ctx* ctx, const int32_t* input_ids, int B, int T, float* out, void* stream);
 
 /* ---- VAE ------------------------------------------------------------------------------------ */
 /* img: u8 NHWC (N,srcH,srcW,3); nearest-resized to (H,W) on the fly when they differ.

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVG_LIB") or os.path.join(_HERE, "libsvg_hip.so")   # $SVG_LIB: A/B another build of the same ABI
 
-SVG_TRANSFORMER, SVG_VAE, SVG_UNET = 0, 1, 2
+SVG_TRANSFORMER, SVG_VAE, SVG_UNET, SVG_CLIP_TEXT = 0, 1, 2, 3
 SVG_ERR_RUNTIME, SVG_ERR_INVALID = -1, -2        # enum svg_status
 
 _lib = None
@@ -30,6 +30,7 @@ SIGNATURES = {
     "svg_finalize": [_vp, _i, C.POINTER(_i64)],
     "svg_transformer_forward": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "svg_transformer_forward_text": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "svg_clip_text_forward": [_vp, _vp, _i, _i, _vp, _vp],
     "svg_vae_encode": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "svg_vae_decode": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp],
     "svg_unet_forward": [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp],
@@ -176,6 +177,14 @@ class Context:
             return out
         self.check(self.lib.svg_transformer_forward(self.h, _ptr(src), _ptr(tgt_c), B, Ts, Tt, _ptr(mask), _ptr(pe_row),
                                                     _ptr(out), _stream()), "svg_transformer_forward")
+        return out
+
+    def clip_text_forward(self, input_ids, d_model=768):
+        """input_ids (B,T) integer tensor -> (B,T,d_model) f32 last_hidden_state"""
+        ids = input_ids.to(device=self.device, dtype=torch.int32).contiguous()
+        B, T = ids.shape
+        out = torch.empty((B, T, d_model), device=self.device, dtype=torch.float32)
+        self.check(self.lib.svg_clip_text_forward(self.h, _ptr(ids), B, T, _ptr(out), _stream()), "svg_clip_text_forward")
         return out
 
     def vae_encode(self, img_u8, H=None, W=None, eps=None, return_moments=False):

@@ -105,8 +105,10 @@ struct svg_ctx {
   struct XfModel* xf = nullptr;
   struct VaeModel* vae = nullptr;
   struct UnetModel* unet = nullptr;
-  std::vector<void*> owned[4];   // device allocations per model id (3 = context) freed at reconfigure / destroy
-  int cur_model = 3;
+  struct ClipTextModel* clip = nullptr;
+  static constexpr int kCtxSlot = 4;                 // owned[] index of allocations that belong to the context itself
+  std::vector<void*> owned[5];   // device allocations per model id (kCtxSlot = context) freed at reconfigure / destroy
+  int cur_model = kCtxSlot;
   void* dalloc(int64_t bytes);
   void ensure_arena(int64_t bytes);
 };

@@ -137,8 +137,12 @@ void fill_f32(float* p, int64_t n, float v, hipStream_t s);
 // ------------------------------------------------------------------------------------------------
 // latent Transformer (f32, f32-input MFMA)
 // ------------------------------------------------------------------------------------------------
+// act_in on X: 0 none, 1 ReLU, 2 quick-GELU; Y = act_in(X) W^T + bias (+ residual[M][N]); M <= 336
 void xf_gemm(svg_ctx* ctx, const float* X, const float* W, const float* bias, float* Y, int M, int N,
-             int K, int relu_in, hipStream_t s);
+             int K, int act_in, hipStream_t s, const float* residual = nullptr);
+// CLIP text tower pieces (f32): token + position embedding lookup; causal self-attention on packed [q|k|v] rows
+void xf_embed_tokens(const int32_t* ids, const float* tok, const float* pos, float* y, int rows, int T, int d, int vocab, hipStream_t s);
+void xf_attention_causal(const float* qkv, float* o, int B, int T, int heads, int hd, hipStream_t s);
 // y = LayerNorm(x + r) rows of d
 void xf_add_ln(const float* x, const float* r, const float* g, const float* b, float* y, int M, int d,
                float eps, hipStream_t s);

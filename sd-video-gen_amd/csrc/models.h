@@ -118,6 +118,19 @@ struct UnetModel {
   void ddim_coefs(int t, int t_prev, float* sa, float* s1a, float* sap, float* s1ap) const;
 };
 
+// ---- CLIP text tower (transformers CLIPTextModel; reference call site utils/sd_utils.py:60,84,91) ---------------------
+// f32 like the reference (the text encoder runs outside autocast), on the latent Transformer's weight-streaming kernels.
+struct ClipTextModel {
+  WeightStore ws;
+  int vocab = 49408, d_model = 768, heads = 12, layers = 12, ffn = 3072, max_pos = 77;
+  bool ready = false;
+  std::vector<float*> qkv_w, qkv_b;        // per layer: [Wq; Wk; Wv] stacked (3d x d) so the three projections are one stream
+  void configure(const char* kv);
+  void finalize(svg_ctx* ctx, int64_t* n_params);
+  // ids (B,T) int32 -> out (B,T,d_model) f32 = last_hidden_state (after final_layer_norm)
+  void forward(svg_ctx* ctx, const int32_t* ids, int B, int T, float* out, hipStream_t s);
+};
+
 void destroy_models(svg_ctx* ctx);
 
 // shared graph pieces (sdnet.cpp)

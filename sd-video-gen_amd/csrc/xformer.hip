@@ -23,8 +23,8 @@ constexpr int XF_MAXMT = 21;   // M <= 336
 
 template <int MT>
 __global__ void __launch_bounds__(512) xf_gemm_kernel(const float* __restrict__ X, const float* __restrict__ W,
-                                                       const float* __restrict__ bias, float* __restrict__ Y, int M,
-                                                       int N, int K, int relu_in, int ksplit) {
+                                                       const float* __restrict__ bias, const float* __restrict__ residual,
+                                                       float* __restrict__ Y, int M, int N, int K, int act_in, int ksplit) {
   constexpr int RB = MT < 4 ? MT : 4;            // m tiles reduced through LDS at a time
   __shared__ f32x4 red[XF_WAVES][RB][64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -62,9 +62,12 @@ __global__ void __launch_bounds__(512) xf_gemm_kernel(const float* __restrict__ 
       const float* xr = xbase + (int64_t)t * 16 * K + k0;
       f32x4 x0 = ok ? *(const f32x4*)xr : zero;
       f32x4 x1 = ok ? *(const f32x4*)(xr + 4) : zero;
-      if (relu_in) {
+      if (act_in == 1) {          // ReLU on the input (nn.Transformer's feed-forward)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { x0[j] = fmaxf(x0[j], 0.f); x1[j] = fmaxf(x1[j], 0.f); }
+      } else if (act_in == 2) {   // quick-GELU x * sigmoid(1.702 x) on the input (CLIP's MLP)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x0[j] = x0[j] / (1.f + __expf(-1.702f * x0[j])); x1[j] = x1[j] / (1.f + __expf(-1.702f * x1[j])); }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[j], x0[j], acc[t], 0, 0, 0);
@@ -91,7 +94,10 @@ __global__ void __launch_bounds__(512) xf_gemm_kernel(const float* __restrict__ 
       const int m = (t0 + tt) * 16 + (ln & 15);
       const int nn = n0 + 4 * (ln >> 4) + rg;
       if (m < M && nn < N) {
-        if (ksplit == 1 && bias) sum += bias[nn];
+        if (ksplit == 1) {
+          if (bias) sum += bias[nn];
+          if (residual) sum += residual[(int64_t)m * N + nn];
+        }
         out[(int64_t)m * N + nn] = sum;
       }
     }
@@ -100,11 +106,13 @@ __global__ void __launch_bounds__(512) xf_gemm_kernel(const float* __restrict__ 
 
 // Y[m][n] = sum_z slabs[z][m][n] + bias[n], z ascending (deterministic)
 __global__ void __launch_bounds__(256) xf_splitk_finish_kernel(const float* __restrict__ slabs, const float* __restrict__ bias,
-                                                                float* __restrict__ Y, int64_t MN, int N, int ksplit) {
+                                                                const float* __restrict__ residual, float* __restrict__ Y, int64_t MN,
+                                                                int N, int ksplit) {
   for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < MN; i += (int64_t)gridDim.x * 1024) {
     f32x4 v = *(const f32x4*)(slabs + i);
     for (int z = 1; z < ksplit; ++z) v += *(const f32x4*)(slabs + (int64_t)z * MN + i);
     if (bias) v += *(const f32x4*)(bias + (i % N));
+    if (residual) v += *(const f32x4*)(residual + i);
     *(f32x4*)(Y + i) = v;
   }
 }
@@ -205,16 +213,77 @@ __global__ void __launch_bounds__(256) xf_attention_kernel(const float* __restri
   }
 }
 
+// CLIP text embeddings: y[b][t] = token_embedding[ids[b][t]] + position_embedding[t]
+__global__ void xf_embed_tokens_kernel(const int32_t* __restrict__ ids, const float* __restrict__ tok, const float* __restrict__ pos,
+                                       float* __restrict__ y, int T, int d, int vocab) {
+  const int row = blockIdx.x;                       // b * T + t
+  int id = ids[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const float* tr = tok + (int64_t)id * d;
+  const float* pr = pos + (int64_t)(row % T) * d;
+  for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4)
+    *(f32x4*)(y + (int64_t)row * d + c) = *(const f32x4*)(tr + c) + *(const f32x4*)(pr + c);
+}
+
+// batch-first causal self-attention for the CLIP text tower: qkv rows (b*T + t) hold [q | k | v] (ld = 3d), head dim <= 64,
+// T <= 128.  One workgroup per (b, head): K and V of the head in LDS; a wave owns query rows i = wid, wid+4, ...; lane j
+// scores key j (and j + 64), wave-shuffle max / sum, then lane c accumulates channel c.  q is scaled by hd^-1/2 (CLIPAttention).
+__global__ void __launch_bounds__(256) xf_attention_causal_kernel(const float* __restrict__ qkv, float* __restrict__ o, int T, int heads, int hd) {
+  __shared__ float sk[128][65];
+  __shared__ float sv[128][64];
+  __shared__ float sp[4][128];
+  const int b = blockIdx.x, hh = blockIdx.y;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int d = heads * hd, ld = 3 * d;
+  const float* base = qkv + (int64_t)b * T * ld + hh * hd;
+  for (int idx = threadIdx.x; idx < T * hd; idx += 256) {
+    const int j = idx / hd, c = idx - j * hd;
+    sk[j][c] = base[(int64_t)j * ld + d + c];
+    sv[j][c] = base[(int64_t)j * ld + 2 * d + c];
+  }
+  __syncthreads();
+  const float scale = rsqrtf((float)hd);
+  for (int i = wid; i < T; i += 4) {
+    const float* qr = base + (int64_t)i * ld;
+    float s0 = -INFINITY, s1 = -INFINITY;
+    if (lane <= i) {
+      float a = 0.f;
+      for (int c = 0; c < hd; ++c) a += qr[c] * scale * sk[lane][c];
+      s0 = a;
+    }
+    if (lane + 64 <= i) {
+      float a = 0.f;
+      for (int c = 0; c < hd; ++c) a += qr[c] * scale * sk[lane + 64][c];
+      s1 = a;
+    }
+    float mx = fmaxf(s0, s1);
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    const float e0 = (lane <= i) ? __expf(s0 - mx) : 0.f, e1 = (lane + 64 <= i) ? __expf(s1 - mx) : 0.f;
+    float sum = e0 + e1;
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    const float inv = 1.f / sum;
+    sp[wid][lane] = e0 * inv;
+    sp[wid][lane + 64] = e1 * inv;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < hd) {
+      float acc = 0.f;
+      for (int j = 0; j <= i; ++j) acc += sp[wid][j] * sv[j][lane];
+      o[((int64_t)b * T + i) * d + hh * hd + lane] = acc;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 }  // namespace
 
 template <int MT>
-static void xf_launch(dim3 grid, hipStream_t s, const float* X, const float* W, const float* bias, float* Y, int M, int N, int K,
-                      int relu_in, int ksplit) {
-  hipLaunchKernelGGL((xf_gemm_kernel<MT>), grid, dim3(512), 0, s, X, W, bias, Y, M, N, K, relu_in, ksplit);
+static void xf_launch(dim3 grid, hipStream_t s, const float* X, const float* W, const float* bias, const float* residual, float* Y,
+                      int M, int N, int K, int act_in, int ksplit) {
+  hipLaunchKernelGGL((xf_gemm_kernel<MT>), grid, dim3(512), 0, s, X, W, bias, residual, Y, M, N, K, act_in, ksplit);
 }
 
-void xf_gemm(svg_ctx* ctx, const float* X, const float* W, const float* bias, float* Y, int M, int N, int K, int relu_in,
-             hipStream_t s) {
+void xf_gemm(svg_ctx* ctx, const float* X, const float* W, const float* bias, float* Y, int M, int N, int K, int act_in,
+             hipStream_t s, const float* residual) {
   SVG_CHECK(K % 8 == 0 && N % 4 == 0, "xf_gemm: K=%d must be a multiple of 8 and N=%d of 4", K, N);
   SVG_CHECK(M >= 1 && M <= 16 * XF_MAXMT, "xf_gemm: M=%d must be in 1..%d", M, 16 * XF_MAXMT);
   const int nb = cdiv(N, 16);
@@ -231,20 +300,20 @@ void xf_gemm(svg_ctx* ctx, const float* X, const float* W, const float* bias, fl
   dim3 grid(nb, ksplit);
   float* dst = ksplit > 1 ? slabs : Y;
   const int mt = cdiv(M, 16);
-  if (mt <= 1) xf_launch<1>(grid, s, X, W, bias, dst, M, N, K, relu_in, ksplit);
-  else if (mt <= 2) xf_launch<2>(grid, s, X, W, bias, dst, M, N, K, relu_in, ksplit);
-  else if (mt <= 3) xf_launch<3>(grid, s, X, W, bias, dst, M, N, K, relu_in, ksplit);
-  else if (mt <= 4) xf_launch<4>(grid, s, X, W, bias, dst, M, N, K, relu_in, ksplit);
-  else if (mt <= 6) xf_launch<6>(grid, s, X, W, bias, dst, M, N, K, relu_in, ksplit);
-  else if (mt <= 8) xf_launch<8>(grid, s, X, W, bias, dst, M, N, K, relu_in, ksplit);
-  else if (mt <= 11) xf_launch<11>(grid, s, X, W, bias, dst, M, N, K, relu_in, ksplit);
-  else if (mt <= 16) xf_launch<16>(grid, s, X, W, bias, dst, M, N, K, relu_in, ksplit);
-  else xf_launch<21>(grid, s, X, W, bias, dst, M, N, K, relu_in, ksplit);
+  if (mt <= 1) xf_launch<1>(grid, s, X, W, bias, residual, dst, M, N, K, act_in, ksplit);
+  else if (mt <= 2) xf_launch<2>(grid, s, X, W, bias, residual, dst, M, N, K, act_in, ksplit);
+  else if (mt <= 3) xf_launch<3>(grid, s, X, W, bias, residual, dst, M, N, K, act_in, ksplit);
+  else if (mt <= 4) xf_launch<4>(grid, s, X, W, bias, residual, dst, M, N, K, act_in, ksplit);
+  else if (mt <= 6) xf_launch<6>(grid, s, X, W, bias, residual, dst, M, N, K, act_in, ksplit);
+  else if (mt <= 8) xf_launch<8>(grid, s, X, W, bias, residual, dst, M, N, K, act_in, ksplit);
+  else if (mt <= 11) xf_launch<11>(grid, s, X, W, bias, residual, dst, M, N, K, act_in, ksplit);
+  else if (mt <= 16) xf_launch<16>(grid, s, X, W, bias, residual, dst, M, N, K, act_in, ksplit);
+  else xf_launch<21>(grid, s, X, W, bias, residual, dst, M, N, K, act_in, ksplit);
   check_launch("xf_gemm");
   if (ksplit > 1) {
     const int64_t MN = (int64_t)M * N;
-    hipLaunchKernelGGL(xf_splitk_finish_kernel, dim3((unsigned)std::min<int64_t>((MN / 4 + 255) / 256, 1024)), dim3(256), 0, s, slabs, bias, Y,
-                       MN, N, ksplit);
+    hipLaunchKernelGGL(xf_splitk_finish_kernel, dim3((unsigned)std::min<int64_t>((MN / 4 + 255) / 256, 1024)), dim3(256), 0, s, slabs, bias, residual,
+                       Y, MN, N, ksplit);
     check_launch("xf_splitk_finish");
   }
 }
@@ -268,4 +337,15 @@ void xf_attention(const float* q, int ldq, const float* k, const float* v, int l
   SVG_CHECK(Tq <= 16 && Tk <= 16, "xf_attention: sequence length %d/%d > 16", Tq, Tk);
   hipLaunchKernelGGL(xf_attention_kernel, dim3(B, heads), dim3(256), 0, s, q, ldq, k, v, ldk, mask, o, Tq, Tk, B, heads, hd);
   check_launch("xf_attention");
+}
+
+void xf_embed_tokens(const int32_t* ids, const float* tok, const float* pos, float* y, int rows, int T, int d, int vocab, hipStream_t s) {
+  hipLaunchKernelGGL(xf_embed_tokens_kernel, dim3(rows), dim3(192), 0, s, ids, tok, pos, y, T, d, vocab);
+  check_launch("xf_embed_tokens");
+}
+
+void xf_attention_causal(const float* qkv, float* o, int B, int T, int heads, int hd, hipStream_t s) {
+  SVG_CHECK(T >= 1 && T <= 128 && hd >= 1 && hd <= 64, "xf_attention_causal: T=%d (<= 128) / head dim %d (<= 64) unsupported", T, hd);
+  hipLaunchKernelGGL(xf_attention_causal_kernel, dim3(B, heads), dim3(256), 0, s, qkv, o, T, heads, hd);
+  check_launch("xf_attention_causal");
 }

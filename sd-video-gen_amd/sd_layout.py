@@ -11,6 +11,7 @@ import torch
 SD_UNET = dict(block_out=(320, 640, 1280, 1280), layers=2, heads=8, ctx_dim=768, groups=32, in_ch=4, out_ch=4,
                attn=(1, 1, 1, 0))
 SD_VAE = dict(block_out=(128, 256, 512, 512), layers=2, groups=32, latent=4)
+SD_CLIP = dict(vocab=49408, d_model=768, heads=12, layers=12, ffn=3072, max_pos=77)      # openai/clip-vit-large-patch14, text tower
 SCALE = 0.18215
 
 
@@ -158,3 +159,23 @@ def seeded_weights(shapes, seed, gain=0.6, device="cpu"):
             t = 0.05 * torch.randn(shape, generator=g)
         sd[name] = t.to(device)
     return sd
+
+
+def clip_text_shapes(cfg=SD_CLIP):
+    """transformers CLIPTextModel state_dict names (without the 'text_model.' prefix) -> shapes"""
+    d, f = cfg["d_model"], cfg["ffn"]
+    s = {"embeddings.token_embedding.weight": (cfg["vocab"], d), "embeddings.position_embedding.weight": (cfg["max_pos"], d),
+         "final_layer_norm.weight": (d,), "final_layer_norm.bias": (d,)}
+    for i in range(cfg["layers"]):
+        p = "encoder.layers.%d." % i
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            s[p + "self_attn." + n + ".weight"] = (d, d)
+            s[p + "self_attn." + n + ".bias"] = (d,)
+        s[p + "mlp.fc1.weight"] = (f, d)
+        s[p + "mlp.fc1.bias"] = (f,)
+        s[p + "mlp.fc2.weight"] = (d, f)
+        s[p + "mlp.fc2.bias"] = (d,)
+        for n in ("layer_norm1", "layer_norm2"):
+            s[p + n + ".weight"] = (d,)
+            s[p + n + ".bias"] = (d,)
+    return s

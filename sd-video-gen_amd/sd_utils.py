@@ -7,7 +7,9 @@ diffusers-named state_dicts, a local directory in ``$SVG_SD_WEIGHTS`` (``vae/`` 
 ``diffusion_pytorch_model.bin|.safetensors``).  When neither provides a network the constructor RAISES like the
 reference's failed ``from_pretrained`` — seeded synthetic weights of the exact SD v1.4 architecture are an explicit
 opt-in (``weights='synthetic'``, a ``'synthetic'`` entry in the dict, or ``SVG_ALLOW_SYNTHETIC_WEIGHTS=1``) used by the
-bench, the smoke test and the parity tests; ``vae_source`` / ``unet_source`` record where each network came from.
+bench, the smoke test and the parity tests; ``vae_source`` / ``unet_source`` / ``clip_source`` record where each network
+came from.  The CLIP text encoder ('openai/clip-vit-large-patch14', sd_utils.py:59-60) is loaded the same way from
+``text_encoder/`` (+ ``tokenizer/``) and runs in the library (f32); ``text_embeddings=`` bypasses it.
 """
 import os
 
@@ -117,6 +119,70 @@ class _UNet(_Slot):
         return {"sample": self.ctx.unet_forward(sample, timestep, encoder_hidden_states)}
 
 
+class _CLIPText(_Slot):
+    """Stands where ``SDUtils.text_encoder`` (transformers CLIPTextModel) stands: ``text_encoder(input_ids)[0]`` is the
+    last hidden state (sd_utils.py:84,91).  f32, like the reference (the text encoder runs outside autocast)."""
+    slot = _lib.SVG_CLIP_TEXT
+
+    def __init__(self, ctx, n_params, d_model):
+        super().__init__(ctx, n_params)
+        self.d_model = d_model
+
+    def __call__(self, input_ids):
+        return (self.ctx.clip_text_forward(input_ids, self.d_model),)
+
+
+class _TokenBatch:
+    def __init__(self, ids):
+        self.input_ids = ids
+
+
+class StandInTokenizer:
+    """CLIPTokenizer's call surface (sd_utils.py:80-82,87-89) without the hub-only vocab.json / merges.txt: BOS, one
+    hashed id per whitespace-separated word, EOS, EOS padding to ``model_max_length``.  For the prompt '' — the only prompt
+    of prediction/predict.py:148 — these are exactly the ids the real tokenizer returns (49406, 49407, 49407, ...).  Used
+    with synthetic CLIP weights only; a local ``tokenizer/`` directory gets the real byte-pair encoder."""
+    model_max_length = 77
+    bos_token_id, eos_token_id = 49406, 49407
+
+    def __init__(self, vocab=49408):
+        self.vocab = vocab
+
+    def __call__(self, prompt, padding="max_length", max_length=None, truncation=True, return_tensors="pt"):
+        import zlib
+        L = max_length or self.model_max_length
+        prompts = [prompt] if isinstance(prompt, str) else list(prompt)
+        rows = []
+        for p in prompts:
+            ids = [self.bos_token_id] + [zlib.crc32(w.lower().encode()) % (self.vocab - 2) for w in p.split()][: L - 2] + [self.eos_token_id]
+            rows.append(ids + [self.eos_token_id] * (L - len(ids)))
+        return _TokenBatch(torch.tensor(rows, dtype=torch.long))
+
+
+def _load_local_clip(dirname):
+    for fn in ("model.safetensors", "pytorch_model.bin"):
+        p = os.path.join(dirname, "text_encoder", fn)
+        if os.path.exists(p):
+            if fn.endswith(".safetensors"):
+                from safetensors.torch import load_file
+                return load_file(p)
+            return torch.load(p, map_location="cpu", weights_only=True)
+    return None
+
+
+def _local_clip_arch(dirname):
+    import json
+    p = os.path.join(dirname, "text_encoder", "config.json")
+    if not os.path.exists(p):
+        return {}
+    with open(p) as f:
+        c = json.load(f)
+    c = c.get("text_config", c)
+    m = {"vocab_size": "vocab", "hidden_size": "d_model", "num_attention_heads": "heads", "num_hidden_layers": "layers",
+         "intermediate_size": "ffn", "max_position_embeddings": "max_pos"}
+    return {v: int(c[k]) for k, v in m.items() if k in c}
+
+
 class SDUtils():
     def __init__(self, weights=None, text_embeddings=None, seed=0, verbose=True, arch=None, ctx=None):
         self.config, self.args = parse_config_args()             # sd_utils.py:22
@@ -138,8 +204,10 @@ class SDUtils():
         local = os.environ.get("SVG_SD_WEIGHTS")
         self.vae_arch = dict(sd_layout.SD_VAE, **(_local_arch(local, "vae") if local else {}))
         self.unet_arch = dict(sd_layout.SD_UNET, **(_local_arch(local, "unet") if local else {}))
+        self.clip_arch = dict(sd_layout.SD_CLIP, **(_local_clip_arch(local) if local else {}))
         self.vae_arch.update((arch or {}).get('vae', {}))
         self.unet_arch.update((arch or {}).get('unet', {}))
+        self.clip_arch.update((arch or {}).get('clip', {}))
         vae, tokenizer, text_encoder, unet, scheduler = self.load_models(weights)
         self.vae = vae
         # sd_utils.py:30 builds a default-size Transformer and throws it away; it consumes CPU RNG, which matters
@@ -184,9 +252,13 @@ class SDUtils():
         ctx.load_state_dict(_lib.SVG_VAE, sd)
         vae = _VAE(ctx, ctx.finalize(_lib.SVG_VAE))
         del sd
-        self.unet_source = None
+        self.unet_source = self.clip_source = None
         if not self.args.denoise:
             return vae, None, None, None, None
+        # sd_utils.py:59-60: tokenizer + CLIP text encoder (skipped when the caller supplies the embeddings)
+        tokenizer = text_encoder = None
+        if self._text_embeddings is None:
+            tokenizer, text_encoder = self._load_clip(weights)
         c = self.unet_arch
         sd, self.unet_source = self._weights_for("unet", weights, lambda: sd_layout.unet_shapes(c), self._seed + 2)
         ctx.configure(_lib.SVG_UNET, block_out=list(c["block_out"]), layers=c["layers"], heads=c["heads"], ctx_dim=c["ctx_dim"],
@@ -194,26 +266,65 @@ class SDUtils():
         ctx.load_state_dict(_lib.SVG_UNET, sd)
         unet = _UNet(ctx, ctx.finalize(_lib.SVG_UNET))
         del sd
-        return vae, None, None, unet, None
+        # (the reference also builds an LMSDiscreteScheduler here, sd_utils.py:70-72; gen_i2i_latents never uses it — the DDIM
+        # schedule of sd_utils.py:233-237 lives in the library)
+        return vae, tokenizer, text_encoder, unet, None
+
+    def _load_clip(self, weights):
+        ctx, c = self.ctx, self.clip_arch
+        d = os.environ.get("SVG_SD_WEIGHTS")
+        sd = None
+        if isinstance(weights, dict) and "text_encoder" in weights and not isinstance(weights["text_encoder"], str):
+            sd, self.clip_source = weights["text_encoder"], "given"
+        elif d:
+            sd = _load_local_clip(d)
+            if sd is not None:
+                self.clip_source = "local:" + d
+        if sd is None:
+            # with any other UNet than the synthetic one a random text encoder would silently condition every
+            # cross-attention on noise: refuse like a failed from_pretrained
+            allowed = weights == "synthetic" or synthetic_allowed() or (isinstance(weights, dict) and weights.get("text_encoder") == "synthetic")
+            if not allowed:
+                raise FileNotFoundError("no CLIP text-encoder weights: put text_encoder/model.safetensors (+ tokenizer/) under "
+                                        "$SVG_SD_WEIGHTS, pass weights={'text_encoder': state_dict}, or text_embeddings=")
+            if self._verbose:
+                print("[sd-video-gen] text_encoder: seeded SYNTHETIC weights (seed %d)" % (self._seed + 3))
+            sd, self.clip_source = sd_layout.seeded_weights(sd_layout.clip_text_shapes(c), self._seed + 3, device=self.device), "synthetic"
+        sd = {(k[len("text_model."):] if k.startswith("text_model.") else k): v for k, v in sd.items() if "position_ids" not in k}
+        ctx.configure(_lib.SVG_CLIP_TEXT, vocab=c["vocab"], d_model=c["d_model"], heads=c["heads"], layers=c["layers"], ffn=c["ffn"],
+                      max_pos=c["max_pos"])
+        ctx.load_state_dict(_lib.SVG_CLIP_TEXT, sd)
+        text_encoder = _CLIPText(ctx, ctx.finalize(_lib.SVG_CLIP_TEXT), c["d_model"])
+        tokenizer = None
+        if d and os.path.exists(os.path.join(d, "tokenizer", "vocab.json")):
+            from transformers import CLIPTokenizer              # host-side string processing, as in the reference (sd_utils.py:59)
+            tokenizer = CLIPTokenizer.from_pretrained(os.path.join(d, "tokenizer"))
+        elif self.clip_source == "synthetic" or synthetic_allowed():
+            tokenizer = StandInTokenizer(c["vocab"])
+            tokenizer.model_max_length = c["max_pos"]
+        else:
+            raise FileNotFoundError("CLIP tokenizer files (tokenizer/vocab.json, merges.txt) not found under $SVG_SD_WEIGHTS")
+        return tokenizer, text_encoder
 
     # ---- sd_utils.py:78-95 -----------------------------------------------------------------------------
     def encode_text(self, prompt):
-        """-> (2*len(prompt), 77, 768) = [uncond ; text].  Without CLIP weights: seeded stand-ins, one per distinct
-        prompt string ('' included), so equal prompts give equal embeddings as the real encoder would."""
+        """-> (2*len(prompt), 77, 768) = [uncond ; text] (sd_utils.py:78-95): tokenizer (pad to model_max_length, truncate),
+        CLIP text model's last hidden state for the prompts and for '' * len(prompt)."""
         if self._text_embeddings is not None:
             return self._text_embeddings.to(self.device)
-        if str(self.unet_source).startswith("local:"):
-            # real UNet weights conditioned on a random stand-in would silently diverge from the reference's CLIP('')
-            raise RuntimeError("encode_text: UNet weights from %s need real CLIP embeddings — pass text_embeddings= "
-                               "to SDUtils (the CLIP text model's weights are not available)" % self.unet_source)
-        import zlib
-
-        def emb(p):
-            g = torch.Generator().manual_seed((self._seed * 7919 + zlib.crc32(p.encode())) % (2 ** 31))
-            return torch.randn((1, 77, 768), generator=g)
-        text = torch.cat([emb(p) for p in prompt])
-        uncond = torch.cat([emb("") for _ in prompt])
-        return torch.cat([uncond, text]).to(self.device)
+        if self.text_encoder is None:
+            raise RuntimeError("encode_text needs the text encoder: construct SDUtils with --denoise")
+        if isinstance(prompt, str):
+            prompt = [prompt]
+        text_input = self.tokenizer(prompt, padding="max_length", max_length=self.tokenizer.model_max_length, truncation=True,
+                                    return_tensors="pt")
+        with torch.no_grad():
+            text_embeddings = self.text_encoder(text_input.input_ids.to(self.device))[0]
+        uncond_input = self.tokenizer([""] * len(prompt), padding="max_length", max_length=self.tokenizer.model_max_length,
+                                      return_tensors="pt")
+        with torch.no_grad():
+            uncond_embeddings = self.text_encoder(uncond_input.input_ids.to(self.device))[0]
+        return torch.cat([uncond_embeddings, text_embeddings])
 
     # ---- sd_utils.py:128-154 ---------------------------------------------------------------------------
     def encode_img(self, imgs, eps=None):

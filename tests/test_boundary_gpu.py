@@ -83,7 +83,7 @@ def test_local_diffusers_directory(tmp_path, monkeypatch, tiny_nets, bin_format)
     write_diffusers_dir(str(tmp_path), vsd, usd, bin_format)
     _args()
     monkeypatch.delenv("SVG_SD_WEIGHTS", raising=False)
-    a = SDUtils(weights={"vae": vsd, "unet": usd}, arch={"vae": VCFG, "unet": UCFG}, verbose=False)
+    a = SDUtils(weights={"vae": vsd, "unet": usd}, arch={"vae": VCFG, "unet": UCFG}, verbose=False, text_embeddings=torch.zeros(2, 77, 768))
     g = torch.Generator().manual_seed(0)
     img = torch.randint(0, 256, (2, 64, 64, 3), dtype=torch.uint8, generator=g)
     eps = torch.randn(2, 4, 8, 8, generator=g)
@@ -94,7 +94,9 @@ def test_local_diffusers_directory(tmp_path, monkeypatch, tiny_nets, bin_format)
     fa = a.decode_img_latents(za)
     del a
     monkeypatch.setenv("SVG_SD_WEIGHTS", str(tmp_path))
-    b = SDUtils(verbose=False)                                    # no arch=, no weights=: everything from the directory
+    with pytest.raises(FileNotFoundError, match="CLIP"):          # a directory with real-looking UNet weights but no text encoder
+        SDUtils(verbose=False)
+    b = SDUtils(verbose=False, text_embeddings=torch.zeros(2, 77, 768))   # no arch=, no weights=: everything from the directory
     assert b.vae_source.startswith("local:") and b.unet_source.startswith("local:")
     assert tuple(b.unet_arch["block_out"]) == UCFG["block_out"] and b.unet_arch["heads"] == 4 and tuple(b.unet_arch["attn"]) == (1, 0)
     assert b.vae.n_params == SO.count(SO.vae_shapes(VCFG)) and b.unet.n_params == SO.count(SO.unet_shapes(UCFG))
@@ -108,7 +110,7 @@ def test_local_diffusers_directory(tmp_path, monkeypatch, tiny_nets, bin_format)
     write_diffusers_dir(str(tmp_path), vsd, bad, bin_format)
     del b
     with pytest.raises(ValueError, match="attn2.to_k"):
-        SDUtils(verbose=False)
+        SDUtils(verbose=False, text_embeddings=torch.zeros(2, 77, 768))
 
 
 def test_main_checkpoint_and_png_output(tmp_path, monkeypatch, tiny_nets):

@@ -60,7 +60,7 @@ def _sdu(cfg_name, nets):
     from sd_video_gen_amd.sd_utils import SDUtils
     svg_config.set_args(["--dataset", "synthetic-ball", "--config", cfg_name, "--denoise", "1"])
     usd, vsd = nets
-    return SDUtils(weights={"vae": vsd, "unet": usd}, verbose=False)
+    return SDUtils(weights={"vae": vsd, "unet": usd, "text_encoder": "synthetic"}, verbose=False)
 
 
 def _rollout(cfg_name, g, nets):

@@ -100,7 +100,7 @@ def test_config2_one_denoised_frame_full_size(ctx, full_unet, full_vae):
     from sd_video_gen_amd.sd_utils import SDUtils
     from sd_video_gen_amd.transformer import Transformer
     svg_config.set_args(["--dataset", "synthetic-ball", "--config", "1_16_kitti_L1_64", "--denoise", "1"])
-    sdu = SDUtils(weights={"vae": full_vae, "unet": full_unet}, verbose=False)
+    sdu = SDUtils(weights={"vae": full_vae, "unet": full_unet, "text_encoder": "synthetic"}, verbose=False)
     torch.manual_seed(7)
     m = Transformer(dim_model=2048, num_heads=8, num_encoder_layers=4, num_decoder_layers=8).eval()
     clips = bouncing_ball_clips(1, 64, 5, seed=4)

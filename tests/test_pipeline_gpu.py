@@ -26,7 +26,7 @@ def build(denoise, seed=3):
     svg_config.set_args(["--dataset", "synthetic-ball", "--config", "model_10_26"] + (["--denoise", "1"] if denoise else []))
     vsd = SO.seeded_weights(SO.vae_shapes(VCFG), seed)
     usd = SO.seeded_weights(SO.unet_shapes(UCFG), seed + 1)
-    sdu = SDUtils(weights={"vae": vsd, "unet": usd}, arch={"vae": VCFG, "unet": UCFG}, verbose=False)
+    sdu = SDUtils(weights={"vae": vsd, "unet": usd, "text_encoder": "synthetic"}, arch={"vae": VCFG, "unet": UCFG}, verbose=False)
     torch.manual_seed(seed)
     m = Transformer(dim_model=64, num_heads=4, num_encoder_layers=1, num_decoder_layers=2).eval()
     return sdu, m, vsd, usd
