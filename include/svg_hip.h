@@ -140,6 +140,16 @@ int svg_op_gemm(svg_ctx* ctx, const uint16_t* A, const uint16_t* W, const float*
  * 2 stride2 pad (0,1,0,1), 3 nearest-2x upsample then stride1 pad1.  out (B,Ho,Wo,Cout) bf16. */
 int svg_op_conv3x3(svg_ctx* ctx, const uint16_t* x, const float* w_oihw, const float* bias,
                    uint16_t* out, int B, int H, int W, int Cin, int Cout, int mode, void* stream);
+/* stride-1 3x3 conv whose tile epilogue leaves the GroupNorm column sums of its output, then the GroupNorm (+SiLU) that
+ * consumes them (no statistics pass over the tensor).  *used_epilogue_stats: 1 when that path ran (images >= 32 x 32 without
+ * split-K), 0 when the GroupNorm fell back to its own statistics pass.  Cin % 64 == 0, Cout % 4 == 0. */
+int svg_op_conv3x3_gn(svg_ctx* ctx, const uint16_t* x, const float* w_oihw, const float* bias, const float* gamma,
+                      const float* beta, uint16_t* conv_out, uint16_t* gn_out, int B, int H, int W, int Cin, int Cout,
+                      int groups, float eps, int silu, int* used_epilogue_stats, void* stream);
+/* C[M,N] = [A | A2] * W[N,K]^T + bias with the A operand given as two tensors (A: M x k_split, A2: M x (K - k_split)): the
+ * torch.cat([hidden, skip], dim=1) in front of a resnet's 1x1 shortcut, never materialised.  k_split % 64 == 0. */
+int svg_op_gemm_cat(svg_ctx* ctx, const uint16_t* A, const uint16_t* A2, const uint16_t* W, const float* bias, uint16_t* C,
+                    int M, int N, int K, int k_split, void* stream);
 /* GroupNorm (+SiLU) on NHWC bf16. */
 int svg_op_groupnorm(svg_ctx* ctx, const uint16_t* x, const float* gamma, const float* beta,
                      uint16_t* out, int B, int HW, int C, int groups, float eps, int silu,

@@ -79,8 +79,9 @@ def stand_in_ids(prompts, max_length=77, vocab=49408):
     for '' exactly what CLIPTokenizer(padding='max_length') returns."""
     out = []
     for p in prompts:
-        ids = [BOS] + [zlib.crc32(w.lower().encode()) % (vocab - 2) for w in p.split()][: max_length - 2] + [EOS]
-        out.append(ids + [EOS] * (max_length - len(ids)))
+        bos, eos = vocab - 2, vocab - 1            # 49406 / 49407 at CLIP's vocabulary size
+        ids = [bos] + [zlib.crc32(w.lower().encode()) % (vocab - 2) for w in p.split()][: max_length - 2] + [eos]
+        out.append(ids + [eos] * (max_length - len(ids)))
     return torch.tensor(out, dtype=torch.long)
 
 

@@ -66,6 +66,7 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
   } else {
     tn = tile % tiles_n; pb = tile / tiles_n;
   }
+  const int tile_m = pb;                 // linear index of the 16 x 16 pixel block: (b * by_n + by) * bx_n + bx
   const int bx = pb % bx_n; pb /= bx_n;
   const int by = pb % by_n;
   const int b = pb / by_n;
@@ -364,7 +365,7 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
         if (n < g.N) *(f32x4*)(g.slabs + ((int64_t)ks * g.M + mr + i * g.W) * g.N + n) = acc[i][j];
       }
   } else {
-    epi_tile<MT, NT>(g, 0, mr, g.W, nc, acc);
+    epi_tile<MT, NT>(g, 0, mr, g.W, nc, acc, smem, 4, wm, wn, tile_m, n0);
   }
 }
 

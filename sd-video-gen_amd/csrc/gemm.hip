@@ -82,21 +82,28 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const GemmArgs g) {
   const int c = (tid & 7) ^ ((r0 >> 1) & 7);   // logical 16-B chunk of the 64-wide K slab this lane fetches
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned a_bytes, b_bytes;
-  if (AMODE == A_DENSE) a_bytes = (unsigned)(((int64_t)(g.M - 1) * g.lda + g.K) * 2);
+  if (AMODE == A_DENSE) a_bytes = (unsigned)(((int64_t)(g.M - 1) * g.lda + (g.A2 ? g.k_split : g.K)) * 2);
   else a_bytes = (unsigned)((int64_t)(g.M / (g.Ho * g.Wo)) * g.H * g.W * g.Cin * 2);
   b_bytes = (unsigned)(((int64_t)(g.n_valid - 1) * g.ldb + g.K) * 2);
   const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc((void*)Ap, 0, a_bytes, 0x00020000);
+  // second source of a two-source dense A (channel concat [A | A2]): K slabs from k_split on
+  const bool two_src = AMODE == A_DENSE && g.A2 != nullptr;
+  const unsigned a2_bytes = two_src ? (unsigned)(((int64_t)(g.M - 1) * g.lda2 + (g.K - g.k_split)) * 2) : 0u;
+  const __amdgpu_buffer_rsrc_t srdA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(two_src ? g.A2 : Ap), 0, two_src ? a2_bytes : a_bytes, 0x00020000);
+  const int kt_split = two_src ? g.k_split / BK : 0x7fffffff;
   const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, b_bytes, 0x00020000);
 
   // A rows
   int a_base[4];                 // conv: element offset of (b,0,0,0)
   int a_yx[4];                   // conv: (y<<16)|x of the output pixel, -1 = row out of range
   unsigned a_voff[4];            // byte offset of this lane's chunk (dense: row; conv: current tap's pixel) or INVALID
+  unsigned a2_voff[4];           // the same in the second source of a two-source dense A
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int m = m0 + r0 + 32 * i;
     if (AMODE == A_DENSE) {
       a_voff[i] = (m < g.M) ? (unsigned)(m * g.lda + c * 8) * 2u : INVALID;
+      a2_voff[i] = (two_src && m < g.M) ? (unsigned)(m * g.lda2 + c * 8) * 2u : INVALID;
       a_base[i] = 0; a_yx[i] = 0;
     } else {
       if (m < g.M) {
@@ -167,9 +174,16 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const GemmArgs g) {
     const int ksoff = kt * (BK * 2);                        // bytes, wave-uniform
     const bool k_ok = !k_tail || (kt * BK + c * 8 < g.K);   // only the last slab of a ragged K can fail
     if (AMODE == A_DENSE) {
+      if (kt >= kt_split) {      // wave-uniform: this slab lies in the second source
+        const int ksoff2 = (kt - kt_split) * (BK * 2);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_ptr_t)(sa + i * 4096), 16, k_ok ? a_voff[i] : INVALID, ksoff, 0, 0);
+        for (int i = 0; i < 4; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA2, (lds_ptr_t)(sa + i * 4096), 16, k_ok ? a2_voff[i] : INVALID, ksoff2, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_ptr_t)(sa + i * 4096), 16, k_ok ? a_voff[i] : INVALID, ksoff, 0, 0);
+      }
     } else if (AMODE == A_CONV_SMALLC) {
       const int tap = kt * 8 + c;                           // Cin == 8: one 16-B chunk per tap
 #pragma unroll
@@ -258,7 +272,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const GemmArgs g) {
     return;
   }
   // (an LDS-staged, 16-byte coalesced store variant measured no faster: L2 merges the 8-byte pieces)
-  epi_tile<MT, NT>(g, z, m0 + wm * 64 + l15, 16, n0 + wn * (BN / 2) + lq * 4, acc);
+  epi_tile<MT, NT>(g, z, m0 + wm * 64 + l15, 16, n0 + wn * (BN / 2) + lq * 4, acc, smem, 2, wm, wn, tm, n0);
 }
 
 // sums the split-K slabs and applies the epilogue
@@ -379,6 +393,19 @@ int pick_bn(const GemmArgs& g) {
 
 }  // namespace
 
+static int plan_splitk(const GemmArgs& g);
+
+int gemm_emits_gn(const GemmArgs& g0) {
+  GemmArgs g = g0;
+  if (g.n_valid <= 0) g.n_valid = g.N;
+  if (g.batch != 1 || g.out_f32 || g.act == ACT_GEGLU || g.N > g.ldc) return 0;
+  if (plan_splitk(g) > 1) return 0;
+  g.splitk = 1;
+  if (conv_halo_supported(g)) return 256;
+  if (gemm_pp_supported(g)) return 256;
+  return pick_bn(g) >= 32 ? BM : 0;
+}
+
 void gemm_init_device() { attr_bn<32>(); attr_bn<64>(); attr_bn<128>(); attr_bn<160>(); }
 
 void launch_gemm(svg_ctx* ctx, const GemmArgs& g, hipStream_t s, int prof_kind) {
@@ -392,6 +419,8 @@ void launch_gemm(svg_ctx* ctx, const GemmArgs& g, hipStream_t s, int prof_kind) 
     SVG_CHECK(g.batch == 1, "conv: batch must be folded into M");
   } else {
     SVG_CHECK((int64_t)g.M * g.lda < (1LL << 31) && g.lda % 8 == 0, "gemm: lda %d / M %d unsupported", g.lda, g.M);
+    if (g.A2) SVG_CHECK(g.k_split > 0 && g.k_split % BK == 0 && g.k_split < g.K && g.lda2 % 8 == 0 && (int64_t)g.M * g.lda2 < (1LL << 31) && g.batch == 1,
+                        "gemm: two-source A needs k_split %d to be a multiple of %d inside K %d", g.k_split, BK, g.K);
   }
   SVG_CHECK((int64_t)g.N * g.ldb < (1LL << 31) && g.ldb % 8 == 0, "gemm: ldb %d unsupported", g.ldb);
   if (g.act == ACT_GEGLU) SVG_CHECK(g.N % 128 == 0, "geglu: packed N must be a multiple of 128");
@@ -448,41 +477,36 @@ void launch_gemm(svg_ctx* ctx, const GemmArgs& g, hipStream_t s, int prof_kind) 
   }
 }
 
-void gemm_auto(svg_ctx* ctx, GemmArgs g, hipStream_t s, int prof_kind) {
-  if (g.n_valid <= 0) g.n_valid = g.N;
-  g.splitk = 1;
+// split-K factor gemm_auto() uses for g (1 = none)
+static int plan_splitk(const GemmArgs& g) {
   if (conv_halo_supported(g)) {
     const int64_t blocks = (int64_t)(g.M / 256) * cdiv(g.N, conv_halo_bn(g));
     const int CC = g.Cin / 64;
-    int sk = 1;
     static const int tgt = getenv("SVG_HALO_SPLIT_TGT") ? atoi(getenv("SVG_HALO_SPLIT_TGT")) : 320;
-    if (blocks < 192 && CC >= 4) sk = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((tgt + blocks - 1) / blocks, CC / 2), 8));
-    g.splitk = sk;
-    if (sk > 1) {
-      ctx->arena.push();
-      g.slabs = ctx->arena.get<float>((int64_t)sk * g.M * g.N);
-      launch_gemm(ctx, g, s, prof_kind);
-      ctx->arena.pop();
-    } else {
-      launch_gemm(ctx, g, s, prof_kind);
-    }
-    return;
+    if (blocks < 192 && CC >= 4) return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((tgt + blocks - 1) / blocks, CC / 2), 8));
+    return 1;
   }
-  if (gemm_pp_supported(g)) { launch_gemm(ctx, g, s, prof_kind); return; }
+  if (gemm_pp_supported(g)) return 1;
   const int bn = pick_bn(g);
   const int64_t blocks = (int64_t)cdiv(g.M, BM) * cdiv(g.N, bn) * g.batch;
   const int KT = cdiv(g.K, BK);
-  int sk = 1;
   if (blocks < 192 && KT >= 8) {
-    sk = (int)std::min<int64_t>((384 + blocks - 1) / blocks, KT / 4);
-    sk = std::max(1, std::min(sk, 16));
-  } else if (blocks < 300 && KT >= 64) {
-    // about one workgroup (4 waves) per CU and a long K: a single wave per SIMD cannot hide its own load phases, so
-    // split in two for two co-resident workgroups (same-box A/B at 16 x 16 x 1280 convs: 0.149 -> 0.122 ms)
-    sk = 2;
+    const int sk = (int)std::min<int64_t>((384 + blocks - 1) / blocks, KT / 4);
+    return std::max(1, std::min(sk, 16));
   }
+  // about one workgroup (4 waves) per CU and a long K: a single wave per SIMD cannot hide its own load phases, so
+  // split in two for two co-resident workgroups (same-box A/B at 16 x 16 x 1280 convs: 0.149 -> 0.122 ms)
+  if (blocks < 300 && KT >= 64) return 2;
+  return 1;
+}
+
+void gemm_auto(svg_ctx* ctx, GemmArgs g, hipStream_t s, int prof_kind) {
+  if (g.n_valid <= 0) g.n_valid = g.N;
+  g.splitk = 1;
+  const int sk = plan_splitk(g);
   g.splitk = sk;
   if (sk > 1) {
+    SVG_CHECK(!g.gn_part, "gemm: GroupNorm statistics cannot be emitted by a split-K launch (ask gemm_emits_gn first)");
     ctx->arena.push();
     g.slabs = ctx->arena.get<float>((int64_t)sk * g.batch * g.M * g.N);
     launch_gemm(ctx, g, s, prof_kind);

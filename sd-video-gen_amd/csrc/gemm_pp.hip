@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs g) {
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------------------
-  epi_tile<MT, NT>(g, 0, m0 + wm * 64 + l15, 16, n0 + wn * (BN / 2) + lq * 4, acc);
+  epi_tile<MT, NT>(g, 0, m0 + wm * 64 + l15, 16, n0 + wn * (BN / 2) + lq * 4, acc, smem, 4, wm, wn, tm, n0);
 }
 
 template <int BN>
@@ -184,7 +184,7 @@ int gemm_pp_bn(const GemmArgs& g) {
 bool gemm_pp_supported(const GemmArgs& g) {
   static const int on = getenv("SVG_GEMM_PP") ? atoi(getenv("SVG_GEMM_PP")) : 1;
   static const int min_kt = getenv("SVG_GEMM_PP_MINKT") ? atoi(getenv("SVG_GEMM_PP_MINKT")) : 16;
-  if (!on || g.amode != A_DENSE || g.batch != 1 || g.splitk > 1 || g.out_f32 || (g.K & 63) != 0 || (g.K >> 6) < min_kt) return false;
+  if (!on || g.amode != A_DENSE || g.batch != 1 || g.splitk > 1 || g.out_f32 || (g.K & 63) != 0 || (g.K >> 6) < min_kt || g.A2) return false;
   if (g.lda % 8 != 0 || g.ldb % 8 != 0 || g.bias_row) return false;
   return (int64_t)cdiv(g.M, 256) * cdiv(g.N, gemm_pp_bn(g)) >= 192;
 }

@@ -140,14 +140,28 @@ __device__ __forceinline__ f32x4 geglu_value(const GemmArgs& g, int m, int nh, f
   return v;
 }
 
+// raw barrier that the compiler may not move LDS accesses across
+__device__ __forceinline__ void bar() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // The epilogue of a wave's whole accumulator tile: rows mr + mstep * i (i < MT_), columns nc + 16 j .. +3 (j < NT_).
 // Every load (bias, per-sample bias, residual, LayerNorm statistics) is issued BEFORE the first store: written as a
 // per-fragment loop of load -> use -> store, each load has to wait behind the previous store (the compiler cannot prove
 // that C does not alias them), i.e. one exposed L2 round trip per fragment and operand — 40-60 of them per tile, more
 // than the whole K loop of a short-K GEMM.
+// GN_: additionally emit the GroupNorm column sums of the stored values (GemmArgs::gn_part): each lane sums its rows, a
+// 16-lane butterfly finishes the wave's rows, the waves of the tile meet in LDS (`lds`: the tile's staging memory, free after
+// the K loop) and the first BN_ threads add them in a fixed order.  WM_ = waves along M, wm / wn = this wave's position,
+// BNH_ = columns per wave, tile_m = row-tile index, n0 = first column of the tile.
 template <int MT_, int NT_>
-__device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int mstep, int nc, f32x4 (&acc)[MT_][NT_]) {
+__device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int mstep, int nc, f32x4 (&acc)[MT_][NT_],
+                                         char* lds = nullptr, int WM_ = 0, int wm = 0, int wn = 0, int tile_m = 0, int n0 = 0) {
   const bool geglu = g.act == ACT_GEGLU;
+  const bool emit_gn = g.gn_part != nullptr && lds != nullptr;
+  const float* const bias_z = g.bias ? g.bias + (int64_t)z * g.bias_zs : nullptr;
   float alpha = g.alpha;
   if (g.ln_rs) { ln_fold_tile<MT_, NT_>(g, z, mr, mstep, nc, alpha, acc); alpha = 1.f; }
   // ---- loads
@@ -156,12 +170,12 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int m
 #pragma unroll
   for (int j = 0; j < NT_; ++j) {
     const int n = nc + 16 * j;
-    bj[j] = (g.bias && !g.bias_row && n < g.N) ? *(const f32x4*)(g.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    bj[j] = (bias_z && !g.bias_row && n < g.N) ? *(const f32x4*)(bias_z + n) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
 #pragma unroll
   for (int i = 0; i < MT_; ++i) {
     const int m = mr + mstep * i;
-    bi[i] = (g.bias && g.bias_row && m < g.M) ? g.bias[m] : 0.f;
+    bi[i] = (bias_z && g.bias_row && m < g.M) ? bias_z[m] : 0.f;
   }
   const bool has_bbn = g.bias_bn != nullptr, has_res = g.residual != nullptr && !geglu;
   const int ldbn = g.bias_bn_ld ? g.bias_bn_ld : g.N;
@@ -237,9 +251,53 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int m
           }
           const int64_t o = (int64_t)z * g.sC + (int64_t)m * g.ldc + n;
           if (g.out_f32) *(f32x4*)((float*)g.C + o) = v;
-          else *(bf16x4*)((bf16*)g.C + o) = to_bf16x4(v);
+          else {
+            const bf16x4 w = to_bf16x4(v);
+            *(bf16x4*)((bf16*)g.C + o) = w;
+            // the accumulator is dead from here: keep what the consumer will read (the rounded values) in it for the
+            // GroupNorm column sums below — no extra registers live across the stores
+            if (emit_gn) { acc[i][j][0] = (float)w[0]; acc[i][j][1] = (float)w[1]; acc[i][j][2] = (float)w[2]; acc[i][j][3] = (float)w[3]; }
+          }
         }
       }
+    }
+  }
+  if (emit_gn) {
+    // acc[i][j] now holds the stored values (rows past M were skipped above: zero them).  One column tile at a time: sum the
+    // wave's rows in the lane, then a butterfly over the 16 lanes that share lane >> 4 (lane bits 0-3).
+    const int lane = threadIdx.x & 63;
+    const int BNH = NT_ * 16;                               // columns of a wave tile
+    float* sc = (float*)lds;                                // [WM_][waves_n * BNH][2]
+    const int ncols = (blockDim.x >> 6) / WM_ * BNH;
+    bar();
+#pragma unroll
+    for (int j = 0; j < NT_; ++j) {
+      f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < MT_; ++i) {
+        const bool ok = (mr + mstep * i < g.M) && (nc + 16 * j < g.N);
+        const f32x4 v = ok ? acc[i][j] : f32x4{0.f, 0.f, 0.f, 0.f};
+        a += v; b += v * v;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = a[e], y = b[e];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { x += __shfl_xor(x, o); y += __shfl_xor(y, o); }
+        if ((lane & 15) == 0) {
+          const int col = wn * BNH + j * 16 + (lane >> 4) * 4 + e;
+          sc[(wm * ncols + col) * 2] = x;
+          sc[(wm * ncols + col) * 2 + 1] = y;
+        }
+      }
+    }
+    bar();
+    for (int col = threadIdx.x; col < ncols; col += blockDim.x) {
+      const int n = n0 + col;
+      if (n >= g.N) continue;
+      float a = 0.f, b = 0.f;
+      for (int w = 0; w < WM_; ++w) { a += sc[(w * ncols + col) * 2]; b += sc[(w * ncols + col) * 2 + 1]; }
+      *(float2*)(g.gn_part + ((int64_t)tile_m * g.N + n) * 2) = make_float2(a, b);
     }
   }
 }
@@ -277,12 +335,6 @@ __device__ __forceinline__ void wait_vm(int n) {
     case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
   }
-}
-// raw barrier that the compiler may not move LDS accesses across
-__device__ __forceinline__ void bar() {
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
 }
 
 }  // namespace

@@ -14,6 +14,10 @@ struct GemmArgs {
   const bf16* A = nullptr;
   int amode = A_DENSE;
   int lda = 0;                   // dense: row stride (elements)
+  // dense, two-source A = channel concat [A | A2] (torch.cat([hidden, skip], dim=1) feeding a 1x1 shortcut): K columns
+  // >= k_split (a multiple of 64) come from A2 (row stride lda2); igemm only
+  const bf16* A2 = nullptr;
+  int lda2 = 0, k_split = 0;
   int H = 0, W = 0, Cin = 0;     // conv: input dims (NHWC)
   int Ho = 0, Wo = 0;            // conv: output dims
   // B operand (weights [N][K], K contiguous)
@@ -49,11 +53,20 @@ struct GemmArgs {
   // split-K (0/1 = off). slabs: f32 [splitk][M][N] workspace
   int splitk = 1;
   float* slabs = nullptr;
+  // GroupNorm statistics of the OUTPUT emitted by the tile epilogue (the consumer is a GroupNorm): per row tile and column
+  // the sum and the sum of squares of the stored (bf16-rounded) values, gn_part[(tile_m * N + n) * 2 + {0,1}], written once per
+  // tile in a fixed order (deterministic).  Row tile = 128 rows (igemm), 256 rows (gemm_pp) or a 16 x 16 pixel block (halo conv);
+  // only without split-K.  gemm_emits_gn() says whether a problem qualifies and how many rows a tile has.
+  float* gn_part = nullptr;
+  int64_t bias_zs = 0;               // batched problems: element stride of `bias` per batch (0 = shared)
   int tn_major = 0;                  // tile order inside an XCD's run: 0 = tiles sharing the A rows adjacent, 1 = tiles sharing the weights adjacent
   int dbg = 0;                       // ablation switch (SVG_GEMM_DBG): 1 no stores, 2 no MFMA, 3 no DMA, 5 LDS-staged epilogue
 };
 
 void launch_gemm(svg_ctx* ctx, const GemmArgs& g, hipStream_t s, int prof_kind);
+// rows per row tile of the kernel gemm_auto() would launch for g, or 0 when that launch cannot emit GroupNorm statistics
+// (split-K, batched, f32 / GEGLU output)
+int gemm_emits_gn(const GemmArgs& g);
 // per-device kernel attributes (dynamic LDS limits) of every instantiation; called by svg_create after hipSetDevice
 void gemm_init_device();
 void gemm_pp_init_device();
@@ -75,10 +88,24 @@ void pack_geglu(const float* w, const float* b, bf16* wout, float* bout, int F, 
 // ------------------------------------------------------------------------------------------------
 // normalisation / softmax
 // ------------------------------------------------------------------------------------------------
-// x (B,HW,C) bf16 NHWC; optional second source for channel concat [x | x2] (C = C1 + C2)
+// per-row-tile column sums of a tensor, emitted by the epilogue that produced it (GemmArgs::gn_part)
+struct GnStats {
+  const float* part = nullptr;   // [B * tiles_per_sample][C][2]
+  int tiles_per_sample = 0;
+  bool valid() const { return part != nullptr && tiles_per_sample > 0; }
+};
+// x (B,HW,C) bf16 NHWC; optional second source for channel concat [x | x2] (C = C1 + C2).  With the producers' column sums
+// (st1 for x, st2 for x2) the statistics pass over the tensor is skipped: a small kernel finishes (mean, rstd) per (sample, group).
 void groupnorm(svg_ctx* ctx, const bf16* x, int C1, const bf16* x2, int C2, const float* gamma,
                const float* beta, bf16* out, int B, int HW, int groups, float eps, int silu,
+               hipStream_t s, const GnStats* st1 = nullptr, const GnStats* st2 = nullptr);
+// (mean, rstd) per (sample, group) from producer column sums -> stats[B][groups][2]
+void gn_finish(svg_ctx* ctx, const GnStats& st1, int C1, const GnStats* st2, int C2, float* stats, int B, int HW, int groups, float eps,
                hipStream_t s);
+// GroupNorm folded into a following 1x1 projection (no activation in between): per-sample weights
+// Wb[b][n][c] = bf16(W[n][c] gamma[c] rstd[b][g(c)]) and bias bb[b][n] = bias[n] + sum_c W[n][c] (beta[c] - mean rstd gamma[c])
+void gn_fold_weights(const float* W, const float* bias, const float* gamma, const float* beta, const float* stats, bf16* Wb,
+                     float* bb, int B, int N, int C, int groups, hipStream_t s);
 void layernorm(svg_ctx* ctx, const bf16* x, const float* gamma, const float* beta, bf16* out, int M,
                int C, float eps, hipStream_t s);
 // rows of f32 scores -> bf16 probabilities; cols valid < n_valid, row stride ld (elements)

@@ -131,7 +131,7 @@ struct XfRun {
 };
 }  // namespace
 
-// One chunk of batch rows (B*max(Ts,Tt) <= 64).  pe_row must be non-null here.
+// One chunk of batch rows (B*max(Ts,Tt) <= 336: the rows one pass of the weight stream serves).  pe_row must be non-null here.
 static void xf_forward_chunk(svg_ctx* ctx, XfModel* m, const float* src, const float* tgt, int B, int Ts, int Tt,
                              const float* mask, const int32_t* pe_row, float* out_tb, hipStream_t s, const float* text) {
   XfRun r{ctx, m, s, B};
@@ -162,7 +162,7 @@ void XfModel::forward(svg_ctx* ctx, const float* src, const float* tgt, int B, i
   SVG_CHECK(B >= 1 && Ts >= 1 && Tt >= 1 && Ts <= 16 && Tt <= 16, "transformer: B=%d Ts=%d Tt=%d unsupported", B, Ts, Tt);
   SVG_CHECK(pe_row || B <= 64, "transformer: batch %d > max_len 64 of the positional table", B);
   const int Tmax = std::max(Ts, Tt);
-  const int Bc = std::max(1, 64 / Tmax);
+  const int Bc = std::max(1, 336 / Tmax);       // xf_gemm streams W once for up to 336 rows (56 clips x 6 tokens)
   run_planned(ctx, [&]() {
     // PE rows: the reference indexes the table by batch row (positional_encoding.py:33-35)
     const int32_t* rows = iota;

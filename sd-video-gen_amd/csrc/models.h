@@ -85,6 +85,7 @@ struct VaeModel {
 struct XfBlockW {   // SpatialTransformer with one BasicTransformerBlock
   NormW gn, ln1, ln2, ln3;
   PackedLinear proj_in, proj_out, qk1, v1, o1, q2, k2, v2, o2, ff1, ff2;
+  float* proj_in_f32 = nullptr;   // [C][C] f32: source of the per-sample GroupNorm-folded weights
   int C = 0;
 };
 // cross-attention K / V^T of a constant context, computed on the first DDIM step and reused by the others
@@ -133,6 +134,15 @@ struct ClipTextModel {
 
 void destroy_models(svg_ctx* ctx);
 
+// Request for the GroupNorm column sums of an output (GemmArgs::gn_part): the caller provides `buf` (gn_part_floats() floats, at
+// the arena scope of the output tensor); the wrapper fills `st` when the launch it chose can emit them (else st stays invalid
+// and the consumer runs its own statistics pass).
+struct GnEmit {
+  float* buf = nullptr;
+  GnStats st;
+};
+static inline int64_t gn_part_floats(int64_t B, int64_t HW, int64_t N) { return B * (HW / 128 + 1) * N * 2; }
+
 // shared graph pieces (sdnet.cpp)
 ConvW load_conv3x3(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int Cin, int Cout, hipStream_t s);
 // fold != nullptr: the LayerNorm (gamma, beta) in front of this projection is folded into the packed weights (GemmArgs::ln_*)
@@ -142,7 +152,10 @@ NormW load_norm(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int C)
 float* keep_f32(svg_ctx* ctx, WeightStore& ws, const std::string& name, int64_t numel);
 // out (B,Ho,Wo,Cout) = conv3x3(x) + bias [+ per-sample bias] [+ residual]
 void conv3x3(svg_ctx* ctx, const bf16* x, const ConvW& cw, void* out, int B, int H, int W, int amode, const float* bias_bn,
-             int bias_bn_ld, const bf16* residual, int out_f32, hipStream_t s);
+             int bias_bn_ld, const bf16* residual, int out_f32, hipStream_t s, GnEmit* emit = nullptr);
 // C[M,N] = act(A[M,K] W^T + b) [+ residual]
+// emit / rows_per_sample: GroupNorm column sums of the output (M = samples x rows_per_sample).  A2 / k_split: the A operand is the
+// channel concat [A | A2] of two tensors (columns >= k_split come from A2, row stride lda2) without materialising it.
 void linear(svg_ctx* ctx, const bf16* A, int lda, const PackedLinear& pl, void* C, int ldc, int M, int act, const bf16* residual,
-            int ldr, int out_f32, hipStream_t s, const float* ln_rs = nullptr, const float* ln_rm = nullptr);
+            int ldr, int out_f32, hipStream_t s, const float* ln_rs = nullptr, const float* ln_rm = nullptr, GnEmit* emit = nullptr,
+            int rows_per_sample = 0, const bf16* A2 = nullptr, int lda2 = 0, int k_split = 0);

@@ -90,6 +90,11 @@ __global__ void gn_apply_kernel(const bf16* __restrict__ x, int C1, const bf16* 
   const int b = blockIdx.y;
   const int cpg = C / groups;
   for (int g = threadIdx.x; g < groups; g += blockDim.x) {
+    if (nchunk == 0) {   // finished statistics (gn_finish_kernel): (mean, rstd) per (sample, group)
+      mean_s[g] = partial[((int64_t)b * groups + g) * 2];
+      rstd_s[g] = partial[((int64_t)b * groups + g) * 2 + 1];
+      continue;
+    }
     float ss = 0.f, qq = 0.f;
     for (int ch = 0; ch < nchunk; ++ch) {
       const float* e = partial + (((int64_t)b * nchunk + ch) * groups + g) * 2;
@@ -146,6 +151,66 @@ __global__ void gn_apply_kernel(const bf16* __restrict__ x, int C1, const bf16* 
     *(bf16x8*)(dp + 3 * dstep) = apply(v3);
   }
   for (; p < p_end; p += PL, sp += sstep, dp += dstep) *(bf16x8*)dp = apply(*(const bf16x8*)sp);
+}
+
+// ---- GroupNorm statistics from the producers' column sums (GemmArgs::gn_part): one workgroup per (group, sample) adds the
+// tiles_per_sample x cpg (sum, sumsq) pairs of its channels in a fixed order; a group may straddle the two sources of a concat.
+__global__ void __launch_bounds__(256) gn_finish_kernel(const float* __restrict__ p1, int C1, int tps1, const float* __restrict__ p2, int C2,
+                                                         int tps2, float* __restrict__ stats, int HW, int groups, float eps) {
+  __shared__ float red[8];
+  const int C = C1 + C2, cpg = C / groups;
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  float s = 0.f, q = 0.f;
+  const int c_lo = g * cpg, c_hi = c_lo + cpg;
+  // source 1 channels [c_lo, min(c_hi, C1)), source 2 channels [max(c_lo, C1), c_hi) - C1
+  const int a1 = min(c_lo, C1), b1 = min(c_hi, C1), n1 = b1 - a1;
+  for (int idx = tid; idx < tps1 * n1; idx += 256) {
+    const int t = idx / n1, c = a1 + (idx - t * n1);
+    const float2 v = *(const float2*)(p1 + (((int64_t)b * tps1 + t) * C1 + c) * 2);
+    s += v.x; q += v.y;
+  }
+  const int a2 = max(c_lo, C1) - C1, b2 = max(c_hi, C1) - C1, n2 = b2 - a2;
+  for (int idx = tid; idx < tps2 * n2; idx += 256) {
+    const int t = idx / n2, c = a2 + (idx - t * n2);
+    const float2 v = *(const float2*)(p2 + (((int64_t)b * tps2 + t) * C2 + c) * 2);
+    s += v.x; q += v.y;
+  }
+  s = wave_sum(s); q = wave_sum(q);
+  if ((tid & 63) == 0) { red[(tid >> 6) * 2] = s; red[(tid >> 6) * 2 + 1] = q; }
+  __syncthreads();
+  if (tid == 0) {
+    s = (red[0] + red[2]) + (red[4] + red[6]);
+    q = (red[1] + red[3]) + (red[5] + red[7]);
+    const float n = (float)cpg * (float)HW;
+    const float mean = s / n;
+    stats[((int64_t)b * groups + g) * 2] = mean;
+    stats[((int64_t)b * groups + g) * 2 + 1] = rsqrtf(fmaxf(q / n - mean * mean, 0.f) + eps);
+  }
+}
+
+// ---- GroupNorm folded into the 1x1 projection that follows it (SpatialTransformer: norm -> proj_in, no activation between):
+// one workgroup per (output row n, sample b)
+__global__ void __launch_bounds__(256) gn_fold_weights_kernel(const float* __restrict__ W, const float* __restrict__ bias,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ stats, bf16* __restrict__ Wb, float* __restrict__ bb,
+                                                               int N, int C, int groups) {
+  __shared__ float red[4];
+  const int n = blockIdx.x, b = blockIdx.y, cpg = C / groups;
+  const float* wr = W + (int64_t)n * C;
+  bf16* o = Wb + ((int64_t)b * N + n) * C;
+  const float* st = stats + (int64_t)b * groups * 2;
+  float acc = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c / cpg;
+    const float mean = st[2 * g], rstd = st[2 * g + 1];
+    const float w = wr[c], a = gamma[c] * rstd;
+    o[c] = (bf16)(w * a);
+    acc += w * (beta[c] - mean * a);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) bb[(int64_t)b * N + n] = (bias ? bias[n] : 0.f) + ((red[0] + red[1]) + (red[2] + red[3]));
 }
 
 // ---- GroupNorm for small images (one launch, one read): a workgroup owns one (sample, group) — HW x cpg values that
@@ -335,8 +400,25 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const float* __restri
 
 }  // namespace
 
+void gn_finish(svg_ctx* ctx, const GnStats& st1, int C1, const GnStats* st2, int C2, float* stats, int B, int HW, int groups, float eps,
+               hipStream_t s) {
+  if (!SVG_LAUNCHING(ctx)) return;
+  char tag[96];
+  snprintf(tag, sizeof(tag), "finish_B%d_HW%d_C%d", B, HW, C1 + C2);
+  ProfScope ps(ctx, PK_GNORM, s, 0, 8.0 * B * ((double)st1.tiles_per_sample * C1 + (st2 ? (double)st2->tiles_per_sample * C2 : 0.0)), tag);
+  hipLaunchKernelGGL(gn_finish_kernel, dim3(groups, B), dim3(256), 0, s, st1.part, C1, st1.tiles_per_sample, st2 ? st2->part : nullptr, C2,
+                     st2 ? st2->tiles_per_sample : 0, stats, HW, groups, eps);
+  check_launch("gn_finish");
+}
+
+void gn_fold_weights(const float* W, const float* bias, const float* gamma, const float* beta, const float* stats, bf16* Wb, float* bb,
+                     int B, int N, int C, int groups, hipStream_t s) {
+  hipLaunchKernelGGL(gn_fold_weights_kernel, dim3(N, B), dim3(256), 0, s, W, bias, gamma, beta, stats, Wb, bb, N, C, groups);
+  check_launch("gn_fold_weights");
+}
+
 void groupnorm(svg_ctx* ctx, const bf16* x, int C1, const bf16* x2, int C2, const float* gamma, const float* beta,
-               bf16* out, int B, int HW, int groups, float eps, int silu, hipStream_t s) {
+               bf16* out, int B, int HW, int groups, float eps, int silu, hipStream_t s, const GnStats* st1, const GnStats* st2) {
   const int C = C1 + C2;
   SVG_CHECK(C % groups == 0 && C % 8 == 0 && C1 % 8 == 0 && groups <= 64, "groupnorm: C=%d groups=%d unsupported", C, groups);
   const int CV = C / 8;
@@ -358,6 +440,25 @@ void groupnorm(svg_ctx* ctx, const bf16* x, int C1, const bf16* x2, int C2, cons
     }
   }
   const int PL = std::max(1, 256 / CV);
+  static const int use_epi = getenv("SVG_GN_EPI") ? atoi(getenv("SVG_GN_EPI")) : 1;
+  if (use_epi && st1 && st1->valid() && (C2 == 0 || (st2 && st2->valid()))) {
+    // the producers' epilogues left per-tile column sums: no statistics pass over the tensor, one apply pass
+    ctx->arena.push();
+    float* stats = ctx->arena.get<float>((int64_t)B * groups * 2);
+    gn_finish(ctx, *st1, C1, C2 ? st2 : nullptr, C2, stats, B, HW, groups, eps, s);
+    if (SVG_LAUNCHING(ctx)) {
+      char tag[96];
+      snprintf(tag, sizeof(tag), "apply_B%d_HW%d_C%d", B, HW, C);
+      ProfScope ps(ctx, PK_GNORM, s, 0, 2.0 * B * HW * C * 2, tag);
+      const int threads = std::max((CV * PL + 63) / 64 * 64, 64);
+      int nblk = std::max(1, std::min(HW / PL, std::max(HW / (PL * 16), (2048 + B - 1) / B)));
+      hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, B), dim3(threads), 0, s, x, C1, x2, C2, stats, gamma, beta, out, HW, groups, 0, eps,
+                         silu, CV, PL);
+      check_launch("gn_apply");
+    }
+    ctx->arena.pop();
+    return;
+  }
   int nchunk = std::max(1, std::min(64, HW / (PL * 8)));
   // enough blocks to fill the chip at small batch
   while (nchunk * 2 <= 64 && (int64_t)nchunk * B < 512 && HW / (nchunk * 2) >= PL * 2) nchunk *= 2;

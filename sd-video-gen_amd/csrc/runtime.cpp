@@ -296,6 +296,53 @@ int svg_op_conv3x3(svg_ctx* ctx, const uint16_t* x, const float* w_oihw, const f
   API_END(ctx)
 }
 
+// conv3x3 (stride 1) whose epilogue leaves the GroupNorm column sums, followed by the GroupNorm that consumes them
+int svg_op_conv3x3_gn(svg_ctx* ctx, const uint16_t* x, const float* w_oihw, const float* bias, const float* gamma, const float* beta,
+                      uint16_t* conv_out, uint16_t* gn_out, int B, int H, int W, int Cin, int Cout, int groups, float eps, int silu,
+                      int* used_epilogue_stats, void* stream) {
+  API_BEGIN
+  hipStream_t s = (hipStream_t)stream;
+  SVG_CHECK(Cout % 4 == 0 && Cin % 64 == 0, "conv3x3_gn op: Cout %% 4 and Cin %% 64 must be 0");
+  int used = 0;
+  run_planned(ctx, [&]() {
+    ConvW cw;
+    cw.Cin = Cin; cw.Cout = Cout; cw.Opad = Cout;
+    cw.w = ctx->arena.get<bf16>((int64_t)Cout * 9 * Cin);
+    float* wdev = ctx->arena.get<float>((int64_t)Cout * Cin * 9);
+    cw.b = ctx->arena.get<float>(Cout);
+    float* gdev = ctx->arena.get<float>(Cout);
+    float* bdev = ctx->arena.get<float>(Cout);
+    if (SVG_LAUNCHING(ctx)) {
+      HIP_OK(hipMemcpyAsync(wdev, w_oihw, (size_t)Cout * Cin * 9 * sizeof(float), hipMemcpyDefault, s));
+      HIP_OK(hipMemsetAsync(cw.b, 0, Cout * sizeof(float), s));
+      if (bias) HIP_OK(hipMemcpyAsync(cw.b, bias, Cout * sizeof(float), hipMemcpyDefault, s));
+      HIP_OK(hipMemcpyAsync(gdev, gamma, Cout * sizeof(float), hipMemcpyDefault, s));
+      HIP_OK(hipMemcpyAsync(bdev, beta, Cout * sizeof(float), hipMemcpyDefault, s));
+      pack_conv3x3(wdev, cw.w, Cout, Cin, Cout, Cin, s);
+    }
+    GnEmit e;
+    e.buf = ctx->arena.get<float>(gn_part_floats(B, (int64_t)H * W, Cout));
+    conv3x3(ctx, (const bf16*)x, cw, conv_out, B, H, W, A_CONV_S1, nullptr, 0, nullptr, 0, s, &e);
+    used = e.st.valid() ? 1 : 0;
+    groupnorm(ctx, (const bf16*)conv_out, Cout, nullptr, 0, gdev, bdev, (bf16*)gn_out, B, H * W, groups, eps, silu, s, &e.st, nullptr);
+  });
+  if (used_epilogue_stats) *used_epilogue_stats = used;
+  API_END(ctx)
+}
+
+// C[M,N] = [A | A2][M, K] * W[N,K]^T + bias: dense GEMM whose A operand is the channel concat of two tensors (A: k_split columns)
+int svg_op_gemm_cat(svg_ctx* ctx, const uint16_t* A, const uint16_t* A2, const uint16_t* W, const float* bias, uint16_t* C, int M, int N,
+                    int K, int k_split, void* stream) {
+  API_BEGIN
+  run_planned(ctx, [&]() {
+    GemmArgs g;
+    g.A = (const bf16*)A; g.lda = k_split; g.A2 = (const bf16*)A2; g.lda2 = K - k_split; g.k_split = k_split;
+    g.Wt = (const bf16*)W; g.ldb = K; g.M = M; g.N = N; g.K = K; g.n_valid = N; g.bias = bias; g.C = C; g.ldc = N;
+    gemm_auto(ctx, g, (hipStream_t)stream, PK_GEMM);
+  });
+  API_END(ctx)
+}
+
 int svg_op_groupnorm(svg_ctx* ctx, const uint16_t* x, const float* gamma, const float* beta, uint16_t* out, int B, int HW, int C,
                      int groups, float eps, int silu, void* stream) {
   API_BEGIN

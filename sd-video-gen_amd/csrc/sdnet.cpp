@@ -71,8 +71,18 @@ NormW load_norm(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int C)
   return n;
 }
 
+// fills emit->st when the launch gemm_auto() picks for g can leave the output's GroupNorm column sums (whole row tiles per sample)
+static void plan_gn_emit(GemmArgs& g, GnEmit* emit, int rows_per_sample) {
+  if (!emit || !emit->buf || rows_per_sample < 1024) return;     // small images take the single-launch GroupNorm (one read)
+  const int rows = gemm_emits_gn(g);
+  if (rows <= 0 || rows_per_sample % rows != 0) return;
+  g.gn_part = emit->buf;
+  emit->st.part = emit->buf;
+  emit->st.tiles_per_sample = rows_per_sample / rows;
+}
+
 void conv3x3(svg_ctx* ctx, const bf16* x, const ConvW& cw, void* out, int B, int H, int W, int amode, const float* bias_bn,
-             int bias_bn_ld, const bf16* residual, int out_f32, hipStream_t s) {
+             int bias_bn_ld, const bf16* residual, int out_f32, hipStream_t s, GnEmit* emit) {
   // the kernels address an operand with 32-bit byte offsets: an input or output of 2^31 elements or more (the 512 x 512
   // VAE levels beyond ~30 images) is processed in batch chunks
   {
@@ -110,16 +120,19 @@ void conv3x3(svg_ctx* ctx, const bf16* x, const ConvW& cw, void* out, int B, int
   g.bias_bn = bias_bn; g.bias_bn_ld = bias_bn_ld; g.rows_per_batch = g.Ho * g.Wo;
   g.residual = residual; g.ldr = cw.Opad;
   g.C = out; g.ldc = cw.Opad; g.out_f32 = out_f32;
+  plan_gn_emit(g, emit, g.Ho * g.Wo);
   gemm_auto(ctx, g, s, PK_CONV3);
 }
 
 void linear(svg_ctx* ctx, const bf16* A, int lda, const PackedLinear& pl, void* C, int ldc, int M, int act, const bf16* residual,
-            int ldr, int out_f32, hipStream_t s, const float* ln_rs, const float* ln_rm) {
+            int ldr, int out_f32, hipStream_t s, const float* ln_rs, const float* ln_rm, GnEmit* emit, int rows_per_sample,
+            const bf16* A2, int lda2, int k_split) {
   SVG_CHECK((pl.ln_s != nullptr) == (ln_rs != nullptr), "linear: LayerNorm-folded weights need the row statistics (and only they)");
   {   // 32-bit operand offsets in the kernels: split very tall problems (1 x 1 convs on the 512 x 512 VAE levels) by rows
     const int64_t lim = chunk_limit();
     const int64_t per_row = std::max<int64_t>(lda, std::max(ldc, ldr));
     if ((int64_t)M * per_row > lim && M > 1) {
+      SVG_CHECK(!A2, "linear: a two-source A operand is not split by rows");
       const int chunk = (int)(lim / per_row) & ~255;
       SVG_CHECK(chunk >= 256, "linear: a %lld-element operand limit is below one 256-row slab of %lld-wide rows", (long long)lim, (long long)per_row);
       const int csz = out_f32 ? 4 : 2;
@@ -133,5 +146,7 @@ void linear(svg_ctx* ctx, const bf16* A, int lda, const PackedLinear& pl, void* 
   g.ln_rs = ln_rs; g.ln_rm = ln_rm; g.ln_s = pl.ln_s;
   g.A = A; g.lda = lda; g.Wt = pl.w; g.ldb = pl.K; g.M = M; g.N = pl.N; g.K = pl.K; g.n_valid = pl.N;
   g.bias = pl.b; g.act = act; g.residual = residual; g.ldr = ldr; g.C = C; g.ldc = ldc; g.out_f32 = out_f32;
+  g.A2 = A2; g.lda2 = lda2; g.k_split = k_split;
+  plan_gn_emit(g, emit, rows_per_sample);
   gemm_auto(ctx, g, s, PK_GEMM);
 }

@@ -92,6 +92,12 @@ XfBlockW load_xf(svg_ctx* ctx, WeightStore& ws, const std::string& p, int C, int
   b.C = C;
   const bool fold = ln_fold_enabled();
   b.gn = load_norm(ctx, ws, p + ".norm", C);
+  {   // f32 copy of proj_in (GroupNorm folding rounds W * gamma * rstd once, per sample, at run time)
+    const Weight& w = ws.get(p + ".proj_in.weight");
+    SVG_CHECK(w.numel == (int64_t)C * C, "weight %s.proj_in.weight: expected [%d,%d(,1,1)]", p.c_str(), C, C);
+    b.proj_in_f32 = (float*)ctx->dalloc((int64_t)C * C * sizeof(float));
+    HIP_OK(hipMemcpy(b.proj_in_f32, w.f32, (size_t)C * C * sizeof(float), hipMemcpyDeviceToDevice));
+  }
   b.proj_in = load_linear(ctx, ws, p + ".proj_in", C, C, true, s);
   b.proj_out = load_linear(ctx, ws, p + ".proj_out", C, C, true, s);
   const std::string t = p + ".transformer_blocks.0";
@@ -222,31 +228,55 @@ struct UnetRun {
   KvCache* cache = nullptr;        // cross-attention K / V^T reuse across DDIM steps (constant context)
   int xf_idx = 0;
 
-  bf16* resnet(const bf16* x, int Cx, const bf16* skip, int Cs, const ResW& r, int H, int W) {
+  // an activation tensor with, when its producer could leave them, the GroupNorm column sums of its row tiles
+  struct Act {
+    const bf16* p = nullptr;
+    int C = 0;
+    GnStats st;
+  };
+  GnEmit emit_for(int64_t hw, int Cout) {
+    GnEmit e;
+    if (hw >= 1024) e.buf = ctx->arena.get<float>(gn_part_floats(N, hw, Cout));
+    return e;
+  }
+
+  // ResnetBlock2D; `skip` (up path): the input is torch.cat([x, skip], dim=1) — never materialised when both tensors carry
+  // their column sums: GroupNorm reads the two sources, the 1x1 shortcut takes a two-source A operand
+  Act resnet(const Act& x, const Act* skip, const ResW& r, int H, int W) {
     const int64_t P = (int64_t)N * H * W;
-    bf16* out = ctx->arena.get<bf16>(P * r.c2.Opad);
+    const int HW = H * W;
+    const int Cx = x.C, Cs = skip ? skip->C : 0, Cin = Cx + Cs;
+    Act out;
+    out.C = r.c2.Cout;
+    bf16* outp = ctx->arena.get<bf16>(P * r.c2.Opad);
+    GnEmit eo = emit_for(HW, r.c2.Opad);
     ctx->arena.push();
-    const bf16* xin = x;
-    if (skip) {   // torch.cat([hidden, skip], dim=1)
-      bf16* cat = ctx->arena.get<bf16>(P * (Cx + Cs));
-      if (SVG_LAUNCHING(ctx)) { ProfScope ps(ctx, PK_ELT, s, 0, 4.0 * P * (Cx + Cs)); concat_channels(x, Cx, skip, Cs, cat, P, s); }
+    const bool virt = skip && x.st.valid() && skip->st.valid() && Cx % 64 == 0 && r.has_sc;   // virtual concat
+    const bf16* xin = x.p;
+    if (skip && !virt) {   // torch.cat([hidden, skip], dim=1)
+      bf16* cat = ctx->arena.get<bf16>(P * Cin);
+      if (SVG_LAUNCHING(ctx)) { ProfScope ps(ctx, PK_ELT, s, 0, 4.0 * P * Cin); concat_channels(x.p, Cx, skip->p, Cs, cat, P, s); }
       xin = cat;
     }
-    const int Cin = Cx + Cs;
     bf16* t0 = ctx->arena.get<bf16>(P * Cin);
-    groupnorm(ctx, xin, Cin, nullptr, 0, r.n1.g, r.n1.b, t0, N, H * W, m->groups, 1e-5f, 1, s);
+    if (virt) groupnorm(ctx, x.p, Cx, skip->p, Cs, r.n1.g, r.n1.b, t0, N, HW, m->groups, 1e-5f, 1, s, &x.st, &skip->st);
+    else groupnorm(ctx, xin, Cin, nullptr, 0, r.n1.g, r.n1.b, t0, N, HW, m->groups, 1e-5f, 1, s, skip ? nullptr : &x.st, nullptr);
     bf16* t1 = ctx->arena.get<bf16>(P * r.c1.Opad);
-    conv3x3(ctx, t0, r.c1, t1, N, H, W, A_CONV_S1, temb + r.temb_off, temb_ld, nullptr, 0, s);
+    GnEmit e1 = emit_for(HW, r.c1.Opad);
+    conv3x3(ctx, t0, r.c1, t1, N, H, W, A_CONV_S1, temb + r.temb_off, temb_ld, nullptr, 0, s, &e1);
     bf16* t2 = ctx->arena.get<bf16>(P * r.n2.C);
-    groupnorm(ctx, t1, r.n2.C, nullptr, 0, r.n2.g, r.n2.b, t2, N, H * W, m->groups, 1e-5f, 1, s);
+    groupnorm(ctx, t1, r.n2.C, nullptr, 0, r.n2.g, r.n2.b, t2, N, HW, m->groups, 1e-5f, 1, s, &e1.st, nullptr);
     const bf16* res = xin;
     if (r.has_sc) {
       bf16* sc = ctx->arena.get<bf16>(P * r.sc.N);
-      linear(ctx, xin, Cin, r.sc, sc, r.sc.N, (int)P, ACT_NONE, nullptr, 0, 0, s);
+      if (virt) linear(ctx, x.p, Cx, r.sc, sc, r.sc.N, (int)P, ACT_NONE, nullptr, 0, 0, s, nullptr, nullptr, nullptr, 0, skip->p, Cs, Cx);
+      else linear(ctx, xin, Cin, r.sc, sc, r.sc.N, (int)P, ACT_NONE, nullptr, 0, 0, s);
       res = sc;
     }
-    conv3x3(ctx, t2, r.c2, out, N, H, W, A_CONV_S1, nullptr, 0, res, 0, s);
+    conv3x3(ctx, t2, r.c2, outp, N, H, W, A_CONV_S1, nullptr, 0, res, 0, s, &eo);
     ctx->arena.pop();
+    out.p = outp;
+    out.st = eo.st;
     return out;
   }
 
@@ -283,16 +313,39 @@ struct UnetRun {
     return vt;
   }
 
-  bf16* spatial_transformer(const bf16* x, const XfBlockW& b, int H, int W) {
+  Act spatial_transformer(const Act& xa, const XfBlockW& b, int H, int W) {
+    const bf16* x = xa.p;
     const int HW = H * W, C = b.C;
     const int64_t P = (int64_t)N * HW;
     const int M = (int)P;
     bf16* out = ctx->arena.get<bf16>(P * C);
+    GnEmit eo = emit_for(HW, C);
     ctx->arena.push();
-    bf16* n0 = ctx->arena.get<bf16>(P * C);
-    groupnorm(ctx, x, C, nullptr, 0, b.gn.g, b.gn.b, n0, N, HW, m->groups, 1e-6f, 0, s);
     bf16* h = ctx->arena.get<bf16>(P * C);
-    linear(ctx, n0, C, b.proj_in, h, C, M, ACT_NONE, nullptr, 0, 0, s);
+    static const int gn_fold = getenv("SVG_GN_FOLD") ? atoi(getenv("SVG_GN_FOLD")) : 1;
+    if (gn_fold && xa.st.valid() && b.proj_in_f32) {
+      // GroupNorm (no activation) -> proj_in: the normalisation is folded into per-sample weights, so the normalised tensor
+      // is never written: h_b = x_b (W diag(gamma rstd_b))^T + (bias + W (beta - mean_b rstd_b gamma)), one batched GEMM
+      ctx->arena.push();
+      float* stats = ctx->arena.get<float>((int64_t)N * m->groups * 2);
+      bf16* wb = ctx->arena.get<bf16>((int64_t)N * C * C);
+      float* bb = ctx->arena.get<float>((int64_t)N * C);
+      gn_finish(ctx, xa.st, C, nullptr, 0, stats, N, HW, m->groups, 1e-6f, s);
+      if (SVG_LAUNCHING(ctx)) {
+        ProfScope ps(ctx, PK_GNORM, s, 0, (double)N * C * C * 2, "fold_weights");
+        gn_fold_weights(b.proj_in_f32, b.proj_in.b, b.gn.g, b.gn.b, stats, wb, bb, N, C, C, m->groups, s);
+      }
+      GemmArgs g;
+      g.A = x; g.lda = C; g.Wt = wb; g.ldb = C; g.M = HW; g.N = C; g.K = C; g.n_valid = C;
+      g.batch = N; g.sA = (int64_t)HW * C; g.sB = (int64_t)C * C; g.sC = (int64_t)HW * C;
+      g.bias = bb; g.bias_zs = C; g.C = h; g.ldc = C;
+      gemm_auto(ctx, g, s, PK_GEMM);
+      ctx->arena.pop();
+    } else {
+      bf16* n0 = ctx->arena.get<bf16>(P * C);
+      groupnorm(ctx, x, C, nullptr, 0, b.gn.g, b.gn.b, n0, N, HW, m->groups, 1e-6f, 0, s, &xa.st, nullptr);
+      linear(ctx, n0, C, b.proj_in, h, C, M, ACT_NONE, nullptr, 0, 0, s);
+    }
     // LayerNorms: folded into the consuming projections (row statistics only) unless SVG_LN_FOLD=0
     const bool fold = b.qk1.ln_s != nullptr;
     bf16* ln = fold ? nullptr : ctx->arena.get<bf16>(P * C);
@@ -360,9 +413,11 @@ struct UnetRun {
       }
       ctx->arena.pop();
     }
-    linear(ctx, h, C, b.proj_out, out, C, M, ACT_NONE, x, C, 0, s);
+    linear(ctx, h, C, b.proj_out, out, C, M, ACT_NONE, x, C, 0, s, nullptr, nullptr, &eo, HW);
     ctx->arena.pop();
-    return out;
+    Act o;
+    o.p = out; o.C = C; o.st = eo.st;
+    return o;
   }
 };
 }  // namespace
@@ -394,51 +449,55 @@ void UnetModel::forward(svg_ctx* ctx, const float* x, int N, int h, int w, const
   r.temb = tall; r.temb_ld = temb_all.N;
 
   // ---- conv_in
+  typedef UnetRun::Act Act;
   bf16* x0 = ctx->arena.get<bf16>((int64_t)N * h * w * 8);
   if (SVG_LAUNCHING(ctx)) { ProfScope ps(ctx, PK_ELT, s, 0, 0); nchw_to_act(x, x0, N, in_ch, h, w, 8, 1.f, s); }
   int H = h, W = w;
-  bf16* cur = ctx->arena.get<bf16>((int64_t)N * H * W * conv_in.Opad);
-  conv3x3(ctx, x0, conv_in, cur, N, H, W, A_CONV_S1, nullptr, 0, nullptr, 0, s);
-  struct Skip { const bf16* p; int C; };
-  std::vector<Skip> skips{{cur, c0}};
-  int C = c0;
+  Act cur;
+  {
+    bf16* y = ctx->arena.get<bf16>((int64_t)N * H * W * conv_in.Opad);
+    GnEmit e = r.emit_for((int64_t)H * W, conv_in.Opad);
+    conv3x3(ctx, x0, conv_in, y, N, H, W, A_CONV_S1, nullptr, 0, nullptr, 0, s, &e);
+    cur.p = y; cur.C = c0; cur.st = e.st;
+  }
+  std::vector<Act> skips{cur};
   // ---- down
   for (int i = 0; i < nb; ++i) {
     for (int j = 0; j < layers; ++j) {
-      cur = r.resnet(cur, C, nullptr, 0, down_res[i][j], H, W);
-      C = block_out[i];
+      cur = r.resnet(cur, nullptr, down_res[i][j], H, W);
       if (attn[i]) cur = r.spatial_transformer(cur, down_attn[i][j], H, W);
-      skips.push_back({cur, C});
+      skips.push_back(cur);
     }
     if (i < nb - 1) {
       bf16* y = ctx->arena.get<bf16>((int64_t)N * (H / 2) * (W / 2) * down_s[i].Opad);
-      conv3x3(ctx, cur, down_s[i], y, N, H, W, A_CONV_S2P1, nullptr, 0, nullptr, 0, s);
-      cur = y; H /= 2; W /= 2;
-      skips.push_back({cur, C});
+      GnEmit e = r.emit_for((int64_t)(H / 2) * (W / 2), down_s[i].Opad);
+      conv3x3(ctx, cur.p, down_s[i], y, N, H, W, A_CONV_S2P1, nullptr, 0, nullptr, 0, s, &e);
+      cur.p = y; cur.st = e.st; H /= 2; W /= 2;
+      skips.push_back(cur);
     }
   }
   // ---- mid
-  cur = r.resnet(cur, C, nullptr, 0, mid0, H, W);
+  cur = r.resnet(cur, nullptr, mid0, H, W);
   cur = r.spatial_transformer(cur, mid_attn, H, W);
-  cur = r.resnet(cur, C, nullptr, 0, mid1, H, W);
+  cur = r.resnet(cur, nullptr, mid1, H, W);
   // ---- up
   for (int i = 0; i < nb; ++i) {
     const int bi = nb - 1 - i;
     for (int j = 0; j < layers + 1; ++j) {
-      Skip sk = skips.back(); skips.pop_back();
-      cur = r.resnet(cur, C, sk.p, sk.C, up_res[i][j], H, W);
-      C = block_out[bi];
+      const Act sk = skips.back(); skips.pop_back();
+      cur = r.resnet(cur, &sk, up_res[i][j], H, W);
       if (attn[bi]) cur = r.spatial_transformer(cur, up_attn[i][j], H, W);
     }
     if (i < nb - 1) {
       bf16* y = ctx->arena.get<bf16>((int64_t)N * (2 * H) * (2 * W) * up_s[i].Opad);
-      conv3x3(ctx, cur, up_s[i], y, N, H, W, A_CONV_UP2, nullptr, 0, nullptr, 0, s);
-      cur = y; H *= 2; W *= 2;
+      GnEmit e = r.emit_for((int64_t)4 * H * W, up_s[i].Opad);
+      conv3x3(ctx, cur.p, up_s[i], y, N, H, W, A_CONV_UP2, nullptr, 0, nullptr, 0, s, &e);
+      cur.p = y; cur.st = e.st; H *= 2; W *= 2;
     }
   }
   // ---- out
   bf16* t = ctx->arena.get<bf16>((int64_t)N * H * W * c0);
-  groupnorm(ctx, cur, c0, nullptr, 0, norm_out.g, norm_out.b, t, N, H * W, groups, 1e-5f, 1, s);
+  groupnorm(ctx, cur.p, c0, nullptr, 0, norm_out.g, norm_out.b, t, N, H * W, groups, 1e-5f, 1, s, &cur.st, nullptr);
   float* o = ctx->arena.get<float>((int64_t)N * H * W * conv_out.Opad);
   conv3x3(ctx, t, conv_out, o, N, H, W, A_CONV_S1, nullptr, 0, nullptr, 1, s);
   if (SVG_LAUNCHING(ctx)) { ProfScope ps(ctx, PK_ELT, s, 0, 0); actf32_to_nchw(o, conv_out.Opad, eps_out, N, out_ch, H, W, s); }

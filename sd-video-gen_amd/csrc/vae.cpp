@@ -101,37 +101,63 @@ struct VaeRun {
   svg_ctx* ctx; VaeModel* m; hipStream_t s; int N;
   static constexpr float EPS = 1e-6f;
 
+  // an activation tensor with, when its producer's epilogue left them, the GroupNorm column sums of its row tiles
+  struct Act {
+    bf16* p = nullptr;
+    GnStats st;
+  };
+  GnEmit emit_for(int64_t hw, int Cout) {
+    GnEmit e;
+    if (hw >= 1024) e.buf = ctx->arena.get<float>(gn_part_floats(N, hw, Cout));
+    return e;
+  }
+  Act conv(const bf16* x, const ConvW& cw, int H, int W, int amode) {
+    const int Ho = amode == A_CONV_UP2 ? 2 * H : (amode == A_CONV_S2ASYM ? H / 2 : H), Wo = amode == A_CONV_UP2 ? 2 * W : (amode == A_CONV_S2ASYM ? W / 2 : W);
+    Act y;
+    y.p = ctx->arena.get<bf16>((int64_t)N * Ho * Wo * cw.Opad);
+    GnEmit e = emit_for((int64_t)Ho * Wo, cw.Opad);
+    conv3x3(ctx, x, cw, y.p, N, H, W, amode, nullptr, 0, nullptr, 0, s, &e);
+    y.st = e.st;
+    return y;
+  }
+
   // out = conv2(silu(gn2(conv1(silu(gn1(x)))))) + shortcut(x)
-  bf16* resnet(const bf16* x, const ResW& r, int H, int W) {
+  Act resnet(const Act& x, const ResW& r, int H, int W) {
     const int64_t P = (int64_t)N * H * W;
-    bf16* out = ctx->arena.get<bf16>(P * r.c2.Opad);
+    Act out;
+    out.p = ctx->arena.get<bf16>(P * r.c2.Opad);
+    GnEmit eo = emit_for((int64_t)H * W, r.c2.Opad);
     ctx->arena.push();
     bf16* t0 = ctx->arena.get<bf16>(P * r.n1.C);
-    groupnorm(ctx, x, r.n1.C, nullptr, 0, r.n1.g, r.n1.b, t0, N, H * W, m->groups, EPS, 1, s);
+    groupnorm(ctx, x.p, r.n1.C, nullptr, 0, r.n1.g, r.n1.b, t0, N, H * W, m->groups, EPS, 1, s, &x.st, nullptr);
     bf16* t1 = ctx->arena.get<bf16>(P * r.c1.Opad);
-    conv3x3(ctx, t0, r.c1, t1, N, H, W, A_CONV_S1, nullptr, 0, nullptr, 0, s);
+    GnEmit e1 = emit_for((int64_t)H * W, r.c1.Opad);
+    conv3x3(ctx, t0, r.c1, t1, N, H, W, A_CONV_S1, nullptr, 0, nullptr, 0, s, &e1);
     bf16* t2 = ctx->arena.get<bf16>(P * r.n2.C);
-    groupnorm(ctx, t1, r.n2.C, nullptr, 0, r.n2.g, r.n2.b, t2, N, H * W, m->groups, EPS, 1, s);
-    const bf16* res = x;
+    groupnorm(ctx, t1, r.n2.C, nullptr, 0, r.n2.g, r.n2.b, t2, N, H * W, m->groups, EPS, 1, s, &e1.st, nullptr);
+    const bf16* res = x.p;
     if (r.has_sc) {
       bf16* sc = ctx->arena.get<bf16>(P * r.sc.N);
-      linear(ctx, x, r.n1.C, r.sc, sc, r.sc.N, (int)P, ACT_NONE, nullptr, 0, 0, s);
+      linear(ctx, x.p, r.n1.C, r.sc, sc, r.sc.N, (int)P, ACT_NONE, nullptr, 0, 0, s);
       res = sc;
     }
-    conv3x3(ctx, t2, r.c2, out, N, H, W, A_CONV_S1, nullptr, 0, res, 0, s);
+    conv3x3(ctx, t2, r.c2, out.p, N, H, W, A_CONV_S1, nullptr, 0, res, 0, s, &eo);
     ctx->arena.pop();
+    out.st = eo.st;
     return out;
   }
 
   // single-head attention over HW tokens, unfused (d = C = 512): S and P go through HBM
-  bf16* attn(const bf16* x, const VaeAttnW& a, int H, int W) {
+  Act attn(const Act& xa, const VaeAttnW& a, int H, int W) {
+    const bf16* x = xa.p;
     const int HW = H * W, C = a.C;
     const int64_t P = (int64_t)N * HW;
     const int HWp = (int)align_up(HW, 8);
     bf16* out = ctx->arena.get<bf16>(P * C);
+    GnEmit eo = emit_for(HW, C);
     ctx->arena.push();
     bf16* n = ctx->arena.get<bf16>(P * C);
-    groupnorm(ctx, x, C, nullptr, 0, a.gn.g, a.gn.b, n, N, HW, m->groups, EPS, 0, s);
+    groupnorm(ctx, x, C, nullptr, 0, a.gn.g, a.gn.b, n, N, HW, m->groups, EPS, 0, s, &xa.st, nullptr);
     bf16* qk = ctx->arena.get<bf16>(P * 2 * C);
     linear(ctx, n, C, a.qk, qk, 2 * C, (int)P, ACT_NONE, nullptr, 0, 0, s);
     // V^T[b] = Wv * n_b^T + bv (per row)
@@ -161,14 +187,16 @@ struct VaeRun {
       g.C = o; g.ldc = C;
       gemm_auto(ctx, g, s, PK_GEMM);
     }
-    linear(ctx, o, C, a.proj, out, C, (int)P, ACT_NONE, x, C, 0, s);
+    linear(ctx, o, C, a.proj, out, C, (int)P, ACT_NONE, x, C, 0, s, nullptr, nullptr, &eo, HW);
     ctx->arena.pop();
-    return out;
+    Act y;
+    y.p = out; y.st = eo.st;
+    return y;
   }
 
-  bf16* norm_act(const bf16* x, const NormW& nw, int H, int W) {
+  bf16* norm_act(const Act& x, const NormW& nw, int H, int W) {
     bf16* t = ctx->arena.get<bf16>((int64_t)N * H * W * nw.C);
-    groupnorm(ctx, x, nw.C, nullptr, 0, nw.g, nw.b, t, N, H * W, m->groups, EPS, 1, s);
+    groupnorm(ctx, x.p, nw.C, nullptr, 0, nw.g, nw.b, t, N, H * W, m->groups, EPS, 1, s, &x.st, nullptr);
     return t;
   }
 };
@@ -185,14 +213,12 @@ void VaeModel::encode(svg_ctx* ctx, const uint8_t* img, int N, int srcH, int src
     bf16* x0 = ctx->arena.get<bf16>((int64_t)N * H * W * 8);
     if (SVG_LAUNCHING(ctx)) { ProfScope ps(ctx, PK_ELT, s, 0, 0); img_to_act(img, x0, N, srcH, srcW, H, W, s); }
     int h = H, w = W;
-    bf16* x = ctx->arena.get<bf16>((int64_t)N * h * w * e_conv_in.Opad);
-    conv3x3(ctx, x0, e_conv_in, x, N, h, w, A_CONV_S1, nullptr, 0, nullptr, 0, s);
+    VaeRun::Act x = r.conv(x0, e_conv_in, h, w, A_CONV_S1);
     for (int i = 0; i < nb; ++i) {
       for (auto& rw : e_down[i]) x = r.resnet(x, rw, h, w);
       if (i < nb - 1) {
-        bf16* y = ctx->arena.get<bf16>((int64_t)N * (h / 2) * (w / 2) * e_downs[i].Opad);
-        conv3x3(ctx, x, e_downs[i], y, N, h, w, A_CONV_S2ASYM, nullptr, 0, nullptr, 0, s);
-        x = y; h /= 2; w /= 2;
+        x = r.conv(x.p, e_downs[i], h, w, A_CONV_S2ASYM);
+        h /= 2; w /= 2;
       }
     }
     x = r.resnet(x, e_mid0, h, w);
@@ -230,17 +256,15 @@ void VaeModel::decode(svg_ctx* ctx, const float* z, int N, int h, int w, uint8_t
       actf32_pad_bf16(zq, 4, x0, 8, P0, s);
     }
     int H = h, W = w;
-    bf16* x = ctx->arena.get<bf16>(P0 * d_conv_in.Opad);
-    conv3x3(ctx, x0, d_conv_in, x, N, H, W, A_CONV_S1, nullptr, 0, nullptr, 0, s);
+    VaeRun::Act x = r.conv(x0, d_conv_in, H, W, A_CONV_S1);
     x = r.resnet(x, d_mid0, H, W);
     x = r.attn(x, d_attn, H, W);
     x = r.resnet(x, d_mid1, H, W);
     for (int i = 0; i < nb; ++i) {
       for (auto& rw : d_up[i]) x = r.resnet(x, rw, H, W);
       if (i < nb - 1) {
-        bf16* y = ctx->arena.get<bf16>((int64_t)N * (2 * H) * (2 * W) * d_ups[i].Opad);
-        conv3x3(ctx, x, d_ups[i], y, N, H, W, A_CONV_UP2, nullptr, 0, nullptr, 0, s);
-        x = y; H *= 2; W *= 2;
+        x = r.conv(x.p, d_ups[i], H, W, A_CONV_UP2);
+        H *= 2; W *= 2;
       }
     }
     bf16* t = r.norm_act(x, d_norm_out, H, W);

@@ -143,10 +143,10 @@ class StandInTokenizer:
     of prediction/predict.py:148 — these are exactly the ids the real tokenizer returns (49406, 49407, 49407, ...).  Used
     with synthetic CLIP weights only; a local ``tokenizer/`` directory gets the real byte-pair encoder."""
     model_max_length = 77
-    bos_token_id, eos_token_id = 49406, 49407
 
     def __init__(self, vocab=49408):
         self.vocab = vocab
+        self.bos_token_id, self.eos_token_id = vocab - 2, vocab - 1      # 49406 / 49407 at CLIP's vocabulary size
 
     def __call__(self, prompt, padding="max_length", max_length=None, truncation=True, return_tensors="pt"):
         import zlib

@@ -291,6 +291,80 @@ def test_xf_gemm_integer_exact(ctx):
     assert torch.equal(Y, X @ W.t())
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,silu,expect", [(2, 32, 32, 64, 320, 1, None), (28, 64, 64, 320, 320, 1, 1), (3, 32, 64, 128, 640, 0, 1),
+                                                        (16, 64, 64, 64, 128, 1, 1), (2, 16, 16, 64, 128, 1, 0), (12, 32, 32, 64, 640, 0, 1)])
+def test_conv_epilogue_groupnorm_stats(ctx, B, H, W, Cin, Cout, silu, expect):
+    """a conv whose tile epilogue leaves the GroupNorm column sums + the GroupNorm that consumes them == conv, then the
+    two-pass GroupNorm of the same bf16 tensor (halo kernel: 16 x 16 pixel tiles; implicit GEMM: 128-row tiles; images below
+    32 x 32 fall back to the statistics pass)."""
+    import ctypes
+    g = torch.Generator(device="cuda").manual_seed(B + H + Cin)
+    x = bf(torch.randn(B, H, W, Cin, device="cuda", generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, device="cuda", generator=g) * 0.5
+    gamma = 1 + 0.2 * torch.randn(Cout, device="cuda", generator=g)
+    beta = 0.3 * torch.randn(Cout, device="cuda", generator=g)
+    conv = torch.empty(B, H, W, Cout, device="cuda", dtype=torch.bfloat16)
+    out = torch.empty_like(conv)
+    used = ctypes.c_int(-1)
+    ctx.check(ctx.lib.svg_op_conv3x3_gn(ctx.h, u16(x), w.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), conv.data_ptr(), out.data_ptr(),
+                                        B, H, W, Cin, Cout, 32, 1e-5, silu, ctypes.byref(used), stream()), "conv_gn")
+    # (small problems take split-K, whose reduce kernel does not emit: the GroupNorm then runs its own statistics pass)
+    assert used.value in (0, 1) and (expect is None or used.value == expect)
+    ref_conv = conv_ref(x, w, b, 0)
+    assert rel_l2(conv.float(), ref_conv) < BF16_TOL
+    # GroupNorm of the SAME stored tensor: fp32 reference, and the library's own statistics-pass path
+    y = conv.float().permute(0, 3, 1, 2)
+    ref = F.group_norm(y, 32, gamma, beta, 1e-5)
+    ref = (F.silu(ref) if silu else ref).permute(0, 2, 3, 1)
+    assert rel_l2(out.float(), ref) < BF16_TOL
+    two_pass = torch.empty_like(conv)
+    ctx.check(ctx.lib.svg_op_groupnorm(ctx.h, u16(conv), gamma.data_ptr(), beta.data_ptr(), two_pass.data_ptr(), B, H * W, Cout, 32, 1e-5, silu, stream()), "gn")
+    assert (out.float() - two_pass.float()).abs().max() <= 2 * 2.0 ** -8 * two_pass.float().abs().max()      # one bf16 ulp at most
+
+
+def test_conv_epilogue_stats_integer_exact(ctx):
+    """integer data: every column sum is exact, so mean / variance — hence the normalised output — match the fp32 reference of
+    the stored tensor to f32 rounding; catches a tile or column mapped to the wrong slot of gn_part."""
+    import ctypes
+    g = torch.Generator(device="cuda").manual_seed(3)
+    B, H, W, Cin, Cout = 12, 32, 32, 64, 640
+    x = bf(torch.randint(-2, 3, (B, H, W, Cin), device="cuda", generator=g).float())
+    w = torch.randint(-1, 2, (Cout, Cin, 3, 3), device="cuda", generator=g).float()
+    b = torch.arange(Cout, device="cuda").float() % 5 - 2          # per-channel offsets: a swapped column shows
+    gamma = torch.ones(Cout, device="cuda")
+    beta = torch.zeros(Cout, device="cuda")
+    conv = torch.empty(B, H, W, Cout, device="cuda", dtype=torch.bfloat16)
+    out = torch.empty_like(conv)
+    used = ctypes.c_int(-1)
+    ctx.check(ctx.lib.svg_op_conv3x3_gn(ctx.h, u16(x), w.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), conv.data_ptr(), out.data_ptr(),
+                                        B, H, W, Cin, Cout, 32, 1e-5, 0, ctypes.byref(used), stream()), "conv_gn")
+    assert used.value == 1
+    assert torch.equal(conv.float(), conv_ref(x, w, b, 0).to(torch.bfloat16).float())
+    ref = F.group_norm(conv.float().permute(0, 3, 1, 2), 32, gamma, beta, 1e-5).permute(0, 2, 3, 1)
+    assert torch.equal(out, ref.to(torch.bfloat16)) or (out.float() - ref).abs().max() < 2e-2       # bf16 rounding of |values| <= 4
+
+
+@pytest.mark.parametrize("M,N,K,ks", [(4096, 320, 640, 320), (1024, 640, 1920, 1280), (300, 320, 960, 640), (2048, 1280, 2560, 1280)])
+def test_gemm_two_source_a(ctx, M, N, K, ks):
+    """1x1 shortcut of an up-path resnet on torch.cat([hidden, skip], dim=1) without materialising the concat"""
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    A = bf(torch.randn(M, ks, device="cuda", generator=g))
+    A2 = bf(torch.randn(M, K - ks, device="cuda", generator=g))
+    Wt = bf(torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K))
+    b = torch.randn(N, device="cuda", generator=g)
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ctx.check(ctx.lib.svg_op_gemm_cat(ctx.h, u16(A), u16(A2), u16(Wt), b.data_ptr(), out.data_ptr(), M, N, K, ks, stream()), "gemm_cat")
+    ref = torch.cat([A, A2], dim=1).float() @ Wt.float().t() + b
+    assert rel_l2(out.float(), ref) < BF16_TOL
+    # integer-exact
+    Ai = bf(torch.randint(-3, 4, (M, ks), device="cuda", generator=g).float())
+    A2i = bf(torch.randint(-3, 4, (M, K - ks), device="cuda", generator=g).float())
+    Wi = bf(torch.randint(-2, 3, (N, K), device="cuda", generator=g).float())
+    ctx.check(ctx.lib.svg_op_gemm_cat(ctx.h, u16(Ai), u16(A2i), u16(Wi), None, out.data_ptr(), M, N, K, ks, stream()), "gemm_cat")
+    assert torch.equal(out.float(), (torch.cat([Ai, A2i], dim=1).float() @ Wi.float().t()).to(torch.bfloat16).float())
+
+
 def test_conv3x3_halo_integer_exact(ctx):
     """halo kernel on integer data: patch gather, image borders, block seams and the tap shifts checked bit for bit."""
     g = torch.Generator(device="cuda").manual_seed(6)

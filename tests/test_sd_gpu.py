@@ -124,7 +124,7 @@ def test_vae_resize_fused(ctx):
     assert torch.equal(down.cpu(), SO.resize_nearest_u8(full.cpu(), 16, 16))
 
 
-@pytest.mark.parametrize("cfg,N,h,L", [(TINY_UNET, 2, 16, 7), (MID_UNET, 1, 16, 77), (MID_UNET, 3, 32, 77)])
+@pytest.mark.parametrize("cfg,N,h,L", [(TINY_UNET, 2, 16, 7), (MID_UNET, 1, 16, 77), (MID_UNET, 3, 32, 77), (MID_UNET, 2, 64, 77)])
 def test_unet_forward(ctx, cfg, N, h, L):
     sd = load_unet(ctx, cfg, 21)
     g = torch.Generator().manual_seed(h + L)
