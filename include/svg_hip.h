@@ -150,6 +150,12 @@ int svg_op_conv3x3_gn(svg_ctx* ctx, const uint16_t* x, const float* w_oihw, cons
  * torch.cat([hidden, skip], dim=1) in front of a resnet's 1x1 shortcut, never materialised.  k_split % 64 == 0. */
 int svg_op_gemm_cat(svg_ctx* ctx, const uint16_t* A, const uint16_t* A2, const uint16_t* W, const float* bias, uint16_t* C,
                     int M, int N, int K, int k_split, void* stream);
+/* Fused GEGLU feed-forward of a BasicTransformerBlock (C = 320): out = ff.net.2(GEGLU(ff.net.0(LayerNorm(x)))) + residual in ONE
+ * kernel (the M x 4C intermediate never reaches HBM).  x, residual, out: (M,C) bf16; w1 (8C,C) = [h; gate], b1 (8C), w2 (C,4C),
+ * b2 (C), LayerNorm gamma / beta (C): f32 in the state_dict layout (folded and packed inside: test hook). */
+int svg_op_ff_fused(svg_ctx* ctx, const uint16_t* x, const float* ln_gamma, const float* ln_beta, const float* w1,
+                    const float* b1, const float* w2, const float* b2, const uint16_t* residual, uint16_t* out, int M,
+                    int C, void* stream);
 /* GroupNorm (+SiLU) on NHWC bf16. */
 int svg_op_groupnorm(svg_ctx* ctx, const uint16_t* x, const float* gamma, const float* beta,
                      uint16_t* out, int B, int HW, int C, int groups, float eps, int silu,

@@ -1,0 +1,221 @@
+// Fused GEGLU feed-forward of a BasicTransformerBlock for gfx950 (C = 320, the 64 x 64 level of the SD UNet):
+//
+//     out = ff.net.2( GEGLU( LayerNorm3(x) W1^T + b1 ) ) + b2 + residual          (diffusers FeedForward)
+//
+// As two GEMMs the M x 4C intermediate (293 MB at 28 clips) is written by one kernel and read back by the next.  Here a
+// workgroup owns 128 rows and walks the 1280 hidden units in chunks of 64: GEMM1 (K = 320) produces the chunk's h | gate
+// tiles, GEGLU runs on the accumulator registers, and the bf16 result IS the B operand of GEMM2 (no LDS round trip: the k
+// order inside a 32-wide step is permuted, W2 is packed with the same permutation), which accumulates the 128 x 320 output.
+//   8 waves x 16 rows; the wave's 16 x 320 slice of x stays in registers for the whole kernel (40 VGPRs, MFMA B operand);
+//   W1 / W2 stream through an 8-slab LDS ring (16 KiB slabs = 128 rows x 64 k, asm LDS-DMA, counted vmcnt, 4 slabs in flight);
+//   LayerNorm is folded as in gemm.hip (W1' = W1 diag(gamma), row statistics applied to the accumulator);
+//   v_mfma_f32_16x16x32_bf16 with the weight fragment as the A operand (4 consecutive output columns per lane).
+// Per hidden chunk and wave: 80 + 40 MFMAs against 120 ds_read_b128 — LDS bandwidth and the matrix pipe saturate together.
+#include "igemm_epi.h"
+#include <cstdlib>
+
+namespace {
+
+constexpr int FC = 320;                 // channels
+constexpr int FH = 1280;                // hidden units (4C)
+constexpr int F_SLAB = 16384;           // 128 rows x 128 B
+constexpr int F_RING = 8;
+constexpr int F_DEPTH = 4;              // slabs in flight
+constexpr int F_KS = FC / 32;           // k-steps of GEMM1
+constexpr int F_NCH = FH / 64;          // hidden chunks
+constexpr int F_SPC = 5 + 3;            // slabs per chunk: 5 of W1 (k slabs), 3 of W2 (row blocks of 128 covering 320 rows)
+constexpr int F_OFF_S1 = F_RING * F_SLAB;              // s1 (2560 f32) then b1 (2560 f32)
+constexpr int F_LDS = F_OFF_S1 + 2 * 2 * FH * 4;
+
+struct FfArgs {
+  const bf16* X; int ldx;               // pre-LayerNorm input rows
+  const bf16* W1; const float* b1; const float* s1;   // packed GEGLU weights [2*FH][FC] (h / gate tiles of 16 rows alternate), folded bias, row sums
+  const float* rs; const float* rm;     // LayerNorm row statistics: rstd, rstd * mean
+  const bf16* W2p; const float* b2;     // [FC][FH], k permuted inside 32-blocks (pack_ff2_perm)
+  const bf16* residual; int ldr;
+  bf16* out; int ldo;
+  int M;
+};
+
+__global__ void __launch_bounds__(512, 2) ff_fused_kernel(const FfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wid);
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int m0 = blockIdx.x * 128;
+  const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+  constexpr unsigned INVALID = 0x80000000u;
+
+  const uint64_t p1 = (uint64_t)a.W1, p2 = (uint64_t)a.W2p;
+  const v4i srd1 = {(int)(unsigned)p1, (int)((p1 >> 32) & 0xffff), (int)(2u * FH * FC * 2u), 0x00020000};
+  const v4i srd2 = {(int)(unsigned)p2, (int)((p2 >> 32) & 0xffff), (int)((unsigned)FC * FH * 2u), 0x00020000};
+
+  // ---- ring DMA: slab q (global counter) = chunk c = q / 8, piece s = q % 8: s < 5 -> W1 rows [128c, +128) x k [64s, +64);
+  //      s >= 5 -> W2p rows [128(s-5), +128) (rows >= 320 read as zeros) x k [64c, +64).  Two 1-KiB pieces per wave and slab.
+  const int prow = lane >> 3;                              // row within an 8-row piece
+  auto dma_slab = [&](int q) {
+    const int c = q >> 3, s = q & 7;
+    const unsigned dst = lds0 + (q & (F_RING - 1)) * F_SLAB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int blk = i * 8 + wave_u;                      // 8-row block of the slab
+      const int row = blk * 8 + prow;
+      const int ch = (lane & 7) ^ (row & 7);               // swizzle on the source chunk
+      if (s < 5) {
+        const unsigned voff = (unsigned)((128 * c + row) * FC + ch * 8) * 2u;
+        dma16(srd1, voff, s * 128, dst + blk * 1024);
+      } else {
+        const int r = 128 * (s - 5) + row;
+        const unsigned voff = r < FC ? (unsigned)(r * FH + ch * 8) * 2u : INVALID;
+        dma16(srd2, voff, c * 128, dst + blk * 1024);
+      }
+    }
+  };
+  constexpr int NQ = F_NCH * F_SPC;
+#pragma unroll
+  for (int q = 0; q < F_DEPTH; ++q) dma_slab(q);
+
+  // ---- s1 / b1 to LDS, the wave's x rows and LayerNorm statistics to registers
+  {
+    float* ss = (float*)(smem + F_OFF_S1);
+    for (int i = tid; i < 2 * FH; i += 512) { ss[i] = a.s1[i]; ss[2 * FH + i] = a.b1[i]; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the ds_writes have left before this wave's first barrier
+  }
+  const int m = m0 + wave_u * 16 + l15;
+  const bool m_ok = m < a.M;
+  bf16x8 xf[F_KS];
+#pragma unroll
+  for (int ks = 0; ks < F_KS; ++ks) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (m_ok) v = *(const uint4*)(a.X + (int64_t)m * a.ldx + ks * 32 + lq * 8);
+    xf[ks] = *(bf16x8*)&v;
+  }
+  const float rs = m_ok ? a.rs[m] : 0.f, rm = m_ok ? a.rm[m] : 0.f;
+
+  f32x4 acc2[FC / 16];
+#pragma unroll
+  for (int t = 0; t < FC / 16; ++t) acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frag0 = l15 * 128;                             // row l15 of a 16-row tile; chunk (kk*4 + lq) ^ (l15 & 7)
+  int fsw[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) fsw[kk] = frag0 + (((kk * 4 + lq) ^ (l15 & 7)) << 4);
+  const float* const sS1 = (const float*)(smem + F_OFF_S1);
+  const float* const sB1 = sS1 + 2 * FH;
+
+  // ---- main loop.  All eight waves walk the slabs in lock step (one barrier per slab); the two waves of a SIMD alternate by
+  // themselves: while one issues its 8 MFMAs of a k half the other reads its 8 fragments.  (A finer software pipeline — the
+  // fragments of the next quarter step read before the MFMAs of the current one, pinned with sched_barrier — measured 10-19 %
+  // SLOWER: 0.495-0.533 ms against 0.448 ms for 114688 rows; LDS bandwidth, one fragment read per MFMA, is the co-limit.)
+  int q = 0;
+  auto step_begin = [&]() {                                // retire slab q, barrier, refill the slot F_DEPTH ahead
+    if (q + F_DEPTH - 1 < NQ) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // 2 * (F_DEPTH - 1): the steady state
+    else wait_vm((NQ - 1 - q) * 2);
+    bar();
+    if (q + F_DEPTH < NQ) dma_slab(q + F_DEPTH);
+  };
+
+  for (int c = 0; c < F_NCH; ++c) {
+    // ---- GEMM1: 16 rows x 128 packed columns (h0 g0 h1 g1 h2 g2 h3 g3), K = 320 in 5 slabs
+    f32x4 acc1[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      step_begin();
+      const char* sl = smem + (q & (F_RING - 1)) * F_SLAB;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 wf[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) wf[t] = *(const bf16x8*)(sl + t * 2048 + fsw[kk]);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf[s * 2 + kk], acc1[t], 0, 0, 0);
+      }
+      ++q;
+    }
+    // ---- folded LayerNorm + bias, GEGLU: p = h * gelu(gate) -> the B operand of GEMM2
+    bf16x8 pf[2];
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+      const int n = 128 * c + 32 * pr + 4 * lq;            // packed column of the h tile; the gate tile follows 16 later
+      const f32x4 sh = *(const f32x4*)(sS1 + n), sg = *(const f32x4*)(sS1 + n + 16);
+      const f32x4 bh = *(const f32x4*)(sB1 + n), bg = *(const f32x4*)(sB1 + n + 16);
+      const f32x4 h = acc1[2 * pr] * rs - sh * rm + bh;
+      const f32x4 gt = acc1[2 * pr + 1] * rs - sg * rm + bg;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pf[pr >> 1][(pr & 1) * 4 + e] = (bf16)(h[e] * gelu_erf(gt[e]));
+    }
+    // ---- GEMM2: acc2[320 columns] += P (16 x 64) W2p[:, chunk]^T, 3 slabs of 128 W2 rows
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      step_begin();
+      const char* sl = smem + (q & (F_RING - 1)) * F_SLAB;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          if (s * 8 + t < FC / 16) {
+            const bf16x8 wf = *(const bf16x8*)(sl + t * 2048 + fsw[kk]);
+            acc2[s * 8 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, pf[kk], acc2[s * 8 + t], 0, 0, 0);
+          }
+        }
+      }
+      ++q;
+    }
+  }
+
+  // ---- epilogue: + b2 + residual, bf16 store (4 consecutive columns per lane)
+  if (m_ok) {
+#pragma unroll
+    for (int t = 0; t < FC / 16; ++t) {
+      const int n = t * 16 + lq * 4;
+      f32x4 v = acc2[t] + *(const f32x4*)(a.b2 + n);
+      if (a.residual) {
+        const bf16x4 r = *(const bf16x4*)(a.residual + (int64_t)m * a.ldr + n);
+        v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+      }
+      *(bf16x4*)(a.out + (int64_t)m * a.ldo + n) = to_bf16x4(v);
+    }
+  }
+}
+
+// W2p[n][32 b + 8 lq + j] = W2[n][32 b + 16 (j >> 2) + 4 lq + (j & 3)]: the k order in which the GEGLU registers of a lane line up
+__global__ void pack_ff2_perm_kernel(const float* __restrict__ w, bf16* __restrict__ out, int N, int K) {
+  const int64_t total = (int64_t)N * K;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(idx / K), k = (int)(idx - (int64_t)n * K);
+    const int b = k >> 5, p = k & 31, lq = p >> 3, j = p & 7;
+    out[idx] = (bf16)w[(int64_t)n * K + 32 * b + 16 * (j >> 2) + 4 * lq + (j & 3)];
+  }
+}
+
+}  // namespace
+
+void ff_fused_init_device() {
+  HIP_OK(hipFuncSetAttribute((const void*)ff_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
+}
+
+bool ff_fused_supported(int C, int M) {
+  static const int on = getenv("SVG_FF_FUSED") ? atoi(getenv("SVG_FF_FUSED")) : 1;
+  return on && C == FC && M >= 128 * 192;     // enough 128-row tiles to give every CU a workgroup
+}
+
+void pack_ff2_perm(const float* w, bf16* out, int N, int K, hipStream_t s) {
+  const int64_t total = (int64_t)N * K;
+  hipLaunchKernelGGL(pack_ff2_perm_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, w, out, N, K);
+  check_launch("pack_ff2_perm");
+}
+
+void ff_fused(svg_ctx* ctx, const bf16* X, int ldx, const bf16* W1, const float* b1, const float* s1, const float* rs, const float* rm,
+              const bf16* W2p, const float* b2, const bf16* residual, int ldr, bf16* out, int ldo, int M, hipStream_t s) {
+  SVG_CHECK(ldx % 8 == 0 && ldr % 4 == 0 && ldo % 4 == 0 && (int64_t)M * ldx < (1LL << 31), "ff_fused: strides / size unsupported");
+  if (!SVG_LAUNCHING(ctx)) return;
+  char tag[64];
+  snprintf(tag, sizeof(tag), "ff_fused_M%d_C%d", M, FC);
+  ProfScope ps(ctx, PK_GEMM, s, 2.0 * M * (double)FC * (2 * FH) + 2.0 * M * (double)FH * FC,
+               2.0 * ((double)M * FC * 3 + 3.0 * FC * FH), tag);
+  FfArgs a{X, ldx, W1, b1, s1, rs, rm, W2p, b2, residual, ldr, out, ldo, M};
+  hipLaunchKernelGGL(ff_fused_kernel, dim3(cdiv(M, 128)), dim3(512), F_LDS, s, a);
+  check_launch("ff_fused");
+}

@@ -140,6 +140,16 @@ __device__ __forceinline__ f32x4 geglu_value(const GemmArgs& g, int m, int nh, f
   return v;
 }
 
+// sum over the 16 lanes of a DPP row (lanes sharing lane >> 4), result in every lane: four v_add_f32 with DPP operand
+// swizzles (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror) instead of four ds_bpermute round trips
+__device__ __forceinline__ float row16_sum(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));
+  return x;
+}
+
 // raw barrier that the compiler may not move LDS accesses across
 __device__ __forceinline__ void bar() {
   asm volatile("" ::: "memory");
@@ -281,9 +291,7 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int m
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float x = a[e], y = b[e];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { x += __shfl_xor(x, o); y += __shfl_xor(y, o); }
+        const float x = row16_sum(a[e]), y = row16_sum(b[e]);
         if ((lane & 15) == 0) {
           const int col = wn * BNH + j * 16 + (lane >> 4) * 4 + e;
           sc[(wm * ncols + col) * 2] = x;

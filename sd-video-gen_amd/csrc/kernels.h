@@ -71,6 +71,13 @@ int gemm_emits_gn(const GemmArgs& g);
 void gemm_init_device();
 void gemm_pp_init_device();
 void conv_halo_init_device();
+void ff_fused_init_device();
+
+// fused GEGLU feed-forward (C = 320): out = (GEGLU(LN(x) W1^T + b1)) W2^T + b2 + residual; the M x 4C intermediate stays on chip
+bool ff_fused_supported(int C, int M);
+void pack_ff2_perm(const float* w, bf16* out, int N, int K, hipStream_t s);
+void ff_fused(svg_ctx* ctx, const bf16* X, int ldx, const bf16* W1, const float* b1, const float* s1, const float* rs, const float* rm,
+              const bf16* W2p, const float* b2, const bf16* residual, int ldr, bf16* out, int ldo, int M, hipStream_t s);
 // picks split-K from the shape, allocates slabs from the arena, launches
 void gemm_auto(svg_ctx* ctx, GemmArgs g, hipStream_t s, int prof_kind);
 

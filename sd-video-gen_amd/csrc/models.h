@@ -86,6 +86,7 @@ struct XfBlockW {   // SpatialTransformer with one BasicTransformerBlock
   NormW gn, ln1, ln2, ln3;
   PackedLinear proj_in, proj_out, qk1, v1, o1, q2, k2, v2, o2, ff1, ff2;
   float* proj_in_f32 = nullptr;   // [C][C] f32: source of the per-sample GroupNorm-folded weights
+  bf16* ff2p = nullptr;           // ff.net.2 weights with the k order of the fused GEGLU feed-forward (ff_fused.hip), C = 320 only
   int C = 0;
 };
 // cross-attention K / V^T of a constant context, computed on the first DDIM step and reused by the others

@@ -165,6 +165,7 @@ int svg_create(int device_id, svg_ctx** out) {
   gemm_init_device();
   gemm_pp_init_device();
   conv_halo_init_device();
+  ff_fused_init_device();
   ctx = new svg_ctx();
   ctx->device = device_id;
   ctx->prof_entries.resize(PK_COUNT);
@@ -339,6 +340,46 @@ int svg_op_gemm_cat(svg_ctx* ctx, const uint16_t* A, const uint16_t* A2, const u
     g.A = (const bf16*)A; g.lda = k_split; g.A2 = (const bf16*)A2; g.lda2 = K - k_split; g.k_split = k_split;
     g.Wt = (const bf16*)W; g.ldb = K; g.M = M; g.N = N; g.K = K; g.n_valid = N; g.bias = bias; g.C = C; g.ldc = N;
     gemm_auto(ctx, g, (hipStream_t)stream, PK_GEMM);
+  });
+  API_END(ctx)
+}
+
+// fused GEGLU feed-forward of a transformer block at C = 320: out = ff2(GEGLU(ff1(LayerNorm(x)))) + residual.  Weights in the
+// state_dict layout (W1 [2*4C][C] = [h; gate], W2 [C][4C]); folding, packing and the row statistics happen here (test hook).
+int svg_op_ff_fused(svg_ctx* ctx, const uint16_t* x, const float* ln_gamma, const float* ln_beta, const float* w1, const float* b1,
+                    const float* w2, const float* b2, const uint16_t* residual, uint16_t* out, int M, int C, void* stream) {
+  API_BEGIN
+  hipStream_t s = (hipStream_t)stream;
+  SVG_CHECK(ff_fused_supported(C, 1 << 30), "ff_fused op: C = %d is not supported (320)", C);
+  run_planned(ctx, [&]() {
+    const int F = 4 * C;
+    float* w1d = ctx->arena.get<float>((int64_t)2 * F * C);
+    float* b1d = ctx->arena.get<float>(2 * F);
+    float* b1f = ctx->arena.get<float>(2 * F);
+    float* gd = ctx->arena.get<float>(C);
+    float* bd = ctx->arena.get<float>(C);
+    float* w2d = ctx->arena.get<float>((int64_t)C * F);
+    float* b2d = ctx->arena.get<float>(C);
+    bf16* w1p = ctx->arena.get<bf16>((int64_t)2 * F * C);
+    float* b1p = ctx->arena.get<float>(2 * F);
+    float* s1 = ctx->arena.get<float>(2 * F);
+    bf16* w2p = ctx->arena.get<bf16>((int64_t)C * F);
+    float* rs = ctx->arena.get<float>(M + 8);
+    float* rm = ctx->arena.get<float>(M + 8);
+    if (SVG_LAUNCHING(ctx)) {
+      HIP_OK(hipMemcpyAsync(w1d, w1, (size_t)2 * F * C * 4, hipMemcpyDefault, s));
+      HIP_OK(hipMemcpyAsync(b1d, b1, (size_t)2 * F * 4, hipMemcpyDefault, s));
+      HIP_OK(hipMemcpyAsync(gd, ln_gamma, (size_t)C * 4, hipMemcpyDefault, s));
+      HIP_OK(hipMemcpyAsync(bd, ln_beta, (size_t)C * 4, hipMemcpyDefault, s));
+      HIP_OK(hipMemcpyAsync(w2d, w2, (size_t)C * F * 4, hipMemcpyDefault, s));
+      HIP_OK(hipMemcpyAsync(b2d, b2, (size_t)C * 4, hipMemcpyDefault, s));
+      fold_ln_weights(w1d, b1d, gd, bd, b1f, 2 * F, C, s);
+      pack_geglu(w1d, b1f, w1p, b1p, F, C, s);
+      rowsum_bf16(w1p, s1, 2 * F, C, s);
+      pack_ff2_perm(w2d, w2p, C, F, s);
+    }
+    ln_stats(ctx, (const bf16*)x, rs, rm, M, C, 1e-5f, s);
+    ff_fused(ctx, (const bf16*)x, C, w1p, b1p, s1, rs, rm, w2p, b2d, (const bf16*)residual, C, (bf16*)out, C, M, s);
   });
   API_END(ctx)
 }

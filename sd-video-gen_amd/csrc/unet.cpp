@@ -134,6 +134,12 @@ XfBlockW load_xf(svg_ctx* ctx, WeightStore& ws, const std::string& p, int C, int
     if (btmp) HIP_OK(hipFree(btmp));
     ws.release(t + ".ff.net.0.proj.weight");
   }
+  if (ff_fused_supported(C, 1 << 30)) {   // k-permuted copy of ff.net.2 for the fused feed-forward
+    const Weight& w2 = ws.get(t + ".ff.net.2.weight", {C, 4 * C});
+    b.ff2p = (bf16*)ctx->dalloc((int64_t)C * 4 * C * sizeof(bf16));
+    pack_ff2_perm(w2.f32, b.ff2p, C, 4 * C, s);
+    HIP_OK(hipStreamSynchronize(s));
+  }
   b.ff2 = load_linear(ctx, ws, t + ".ff.net.2", C, 4 * C, true, s);
   return b;
 }
@@ -403,6 +409,10 @@ struct UnetRun {
       // The GEGLU intermediate is M x 4C (293 MB at 28 clips x 64 x 64 x 1280): written by ff1 and read back by ff2.  Run
       // the pair over row chunks whose intermediate fits the 256 MiB Infinity Cache (with the other stream group's share):
       // the same chunk-sized buffer is rewritten per chunk, so ff2 reads it from the cache instead of HBM.
+      if (fold && b.ff2p && ff_fused_supported(C, M)) {
+        // ff1 -> GEGLU -> ff2 in one kernel: the M x 4C intermediate never leaves the CU (h is free again: reused as h3)
+        ff_fused(ctx, h2, C, b.ff1.w, b.ff1.b, b.ff1.ln_s, rs, rm, b.ff2p, b.ff2.b, h2, C, h, C, M, s);
+      } else {
       ctx->arena.push();
       const int rows = ff_chunk_rows(M, C);
       bf16* g = ctx->arena.get<bf16>((int64_t)std::min(rows, M) * 4 * C);
@@ -412,6 +422,7 @@ struct UnetRun {
         linear(ctx, g, 4 * C, b.ff2, h + (int64_t)m0 * C, C, mc, ACT_NONE, h2 + (int64_t)m0 * C, C, 0, s);   // h is free again: reuse as h3
       }
       ctx->arena.pop();
+      }
     }
     linear(ctx, h, C, b.proj_out, out, C, M, ACT_NONE, x, C, 0, s, nullptr, nullptr, &eo, HW);
     ctx->arena.pop();

@@ -365,6 +365,34 @@ def test_gemm_two_source_a(ctx, M, N, K, ks):
     assert torch.equal(out.float(), (torch.cat([Ai, A2i], dim=1).float() @ Wi.float().t()).to(torch.bfloat16).float())
 
 
+@pytest.mark.parametrize("M", [128, 4096 + 37, 28672])
+def test_ff_fused(ctx, M):
+    """out = ff.net.2(GEGLU(ff.net.0(LayerNorm(x)))) + residual in one kernel (C = 320) vs the fp32 chain; rows are independent
+    (ragged last tile included)."""
+    C, Fh = 320, 1280
+    g = torch.Generator(device="cuda").manual_seed(M)
+    x = bf(torch.randn(M, C, device="cuda", generator=g) * 1.5 + 0.2)
+    gamma = 1 + 0.2 * torch.randn(C, device="cuda", generator=g)
+    beta = 0.1 * torch.randn(C, device="cuda", generator=g)
+    w1 = torch.randn(2 * Fh, C, device="cuda", generator=g) / math.sqrt(C)
+    b1 = 0.1 * torch.randn(2 * Fh, device="cuda", generator=g)
+    w2 = torch.randn(C, Fh, device="cuda", generator=g) / math.sqrt(Fh)
+    b2 = 0.1 * torch.randn(C, device="cuda", generator=g)
+    res = bf(torch.randn(M, C, device="cuda", generator=g))
+    out = torch.empty_like(x)
+    ctx.check(ctx.lib.svg_op_ff_fused(ctx.h, u16(x), gamma.data_ptr(), beta.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                      u16(res), out.data_ptr(), M, C, stream()), "ff_fused")
+    h = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5) @ w1.t() + b1
+    ref = (h[:, :Fh] * F.gelu(h[:, Fh:])) @ w2.t() + b2 + res.float()
+    assert torch.isfinite(out.float()).all()
+    assert rel_l2(out.float(), ref) < BF16_TOL
+    # a row's result does not depend on the rows around it
+    sub = torch.empty(128, C, device="cuda", dtype=torch.bfloat16)
+    ctx.check(ctx.lib.svg_op_ff_fused(ctx.h, u16(x[:128].contiguous()), gamma.data_ptr(), beta.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                                      b2.data_ptr(), u16(res[:128].contiguous()), sub.data_ptr(), 128, C, stream()), "ff_fused")
+    assert torch.equal(sub, out[:128])
+
+
 def test_conv3x3_halo_integer_exact(ctx):
     """halo kernel on integer data: patch gather, image borders, block seams and the tap shifts checked bit for bit."""
     g = torch.Generator(device="cuda").manual_seed(6)

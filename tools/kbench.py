@@ -72,6 +72,20 @@ def main():
             ms, fl, _ = timeit(ctx, "gemm", lambda: ctx.check(ctx.lib.svg_op_gemm(
                 ctx.h, A.data_ptr(), W.data_ptr(), bias.data_ptr(), res.data_ptr() if res is not None else None, out.data_ptr(), M, N, K, act, 0, stream()), "gemm"))
             print("%7d %6d %6d %d  %8.3f ms  %7.1f TF" % (M, N, K, act, ms, fl / ms / 1e9))
+    if "ff" in a.what:
+        print("== fused GEGLU feed-forward C=320 (B=%d): M  ms  TFLOP/s" % B)
+        C, Fh = 320, 1280
+        for M in (4096 * B,):
+            x = torch.randn(M, C, device="cuda").to(bf)
+            gamma = torch.ones(C, device="cuda"); beta = torch.zeros(C, device="cuda")
+            w1 = torch.randn(2 * Fh, C, device="cuda") / math.sqrt(C); b1 = torch.zeros(2 * Fh, device="cuda")
+            w2 = torch.randn(C, Fh, device="cuda") / math.sqrt(Fh); b2 = torch.zeros(C, device="cuda")
+            res = torch.randn(M, C, device="cuda").to(bf)
+            out = torch.empty_like(x)
+            ms, fl, _ = timeit(ctx, "gemm", lambda: ctx.check(ctx.lib.svg_op_ff_fused(
+                ctx.h, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), res.data_ptr(),
+                out.data_ptr(), M, C, stream()), "ff"))
+            print("%7d  %8.3f ms  %7.1f TF" % (M, ms, fl / ms / 1e9))
     if "attn" in a.what:
         print("== attention (B=%d): Sq Skv d  ms  TFLOP/s" % B)
         for (Sq, Skv, d) in ((4096, 4096, 40), (1024, 1024, 80), (256, 256, 160), (64, 64, 160), (4096, 77, 40), (1024, 77, 80), (256, 77, 160)):
