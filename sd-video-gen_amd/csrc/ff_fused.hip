@@ -104,9 +104,12 @@ __global__ void __launch_bounds__(512, 2) ff_fused_kernel(const FfArgs a) {
   const float* const sB1 = sS1 + 2 * FH;
 
   // ---- main loop.  All eight waves walk the slabs in lock step (one barrier per slab); the two waves of a SIMD alternate by
-  // themselves: while one issues its 8 MFMAs of a k half the other reads its 8 fragments.  (A finer software pipeline — the
-  // fragments of the next quarter step read before the MFMAs of the current one, pinned with sched_barrier — measured 10-19 %
-  // SLOWER: 0.495-0.533 ms against 0.448 ms for 114688 rows; LDS bandwidth, one fragment read per MFMA, is the co-limit.)
+  // themselves: while one issues its 8 MFMAs of a k half the other reads its 8 fragments.  Measured alternatives, all SLOWER
+  // than this form (0.448 ms for 114688 rows, kbench): a finer software pipeline (fragments of the next quarter step read
+  // before the MFMAs of the current one, pinned with sched_barrier) 0.495-0.533 ms; six slabs in flight instead of four
+  // 0.473 ms; the ping-pong schedule of conv_halo.hip (waves 4-7 one barrier behind, reads and MFMAs in separate phases)
+  // 0.483 ms.  Per slab a wave issues 2 LDS-DMA pieces + 16 fragment reads for only 16 MFMAs (one fragment read per MFMA:
+  // 16 rows per wave): the in-order issue stream of each wave, not a single resource, sets the pace.
   int q = 0;
   auto step_begin = [&]() {                                // retire slab q, barrier, refill the slot F_DEPTH ahead
     if (q + F_DEPTH - 1 < NQ) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // 2 * (F_DEPTH - 1): the steady state

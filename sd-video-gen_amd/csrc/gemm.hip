@@ -398,7 +398,8 @@ static int plan_splitk(const GemmArgs& g);
 int gemm_emits_gn(const GemmArgs& g0) {
   GemmArgs g = g0;
   if (g.n_valid <= 0) g.n_valid = g.N;
-  if (g.batch != 1 || g.out_f32 || g.act == ACT_GEGLU || g.N > g.ldc) return 0;
+  if (g.out_f32 || g.act == ACT_GEGLU || g.N > g.ldc) return 0;
+  if (g.batch != 1) return 0;
   if (plan_splitk(g) > 1) return 0;
   g.splitk = 1;
   if (conv_halo_supported(g)) return 256;

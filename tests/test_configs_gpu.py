@@ -133,10 +133,11 @@ def test_config1_rollout_8_frames_start25(ctx, nets):
     lat, _ = _rollout("1_19_ball_complex_L1_64", g, nets)
     for k in range(g["pred_frames"]):
         print("[parity] cfg1 frame %d rel-L2 %.3e" % (k, rel_l2(lat[:, 4 + k], g["all_latents"][:, 4 + k])))
-    # 25 free-running DDIM steps per frame: the chaotic regime of test_config2_full_frame_50_steps (saturation), then three
-    # uint8 round trips and the next frame's Transformer step on top
-    margin("cfg1 8-frame rollout (25 steps / frame), all generated latents", rel_l2(lat[:, 4:], g["all_latents"][:, 4:]), SATURATION)
-    margin("cfg1 8-frame rollout, first generated frame", rel_l2(lat[:, 4], g["all_latents"][:, 4]), SATURATION)
+    # start step 25 enters the loop at t = 480, past the early steps (t >= 800, division by sqrt(alpha_t) <= 0.2) that make the
+    # 50-step loop of test_config2_full_frame_50_steps chaotic: 25 free-running steps + three uint8 round trips per frame,
+    # eight frames deep, stay at the single-call error (measured 1.07e-2 overall, 0.99e-2 .. 1.30e-2 per frame)
+    margin("cfg1 8-frame rollout (25 steps / frame), all generated latents", rel_l2(lat[:, 4:], g["all_latents"][:, 4:]), 3e-2)
+    margin("cfg1 8-frame rollout, worst frame", max(rel_l2(lat[:, 4 + k], g["all_latents"][:, 4 + k]) for k in range(g["pred_frames"])), 3.5e-2)
 
 
 def test_config3_rollout_16_frames_f128(ctx, nets):

@@ -63,6 +63,22 @@ def test_unet_step_full_size(ctx, full_unet):
     assert torch.equal(e2[:1], e2[1:])                                   # identical rows inside one launch are bit-identical
 
 
+def test_unet_step_full_size_batch7(ctx, full_unet):
+    """seven samples in one call: 28672 rows at the 64 x 64 level, the regime of the bench — the fused GEGLU feed-forward
+    (ff_fused.hip), the per-sample GroupNorm-folded proj_in weights and the epilogue GroupNorm sums run at full size;
+    per-sample timesteps and contexts."""
+    g = torch.Generator().manual_seed(4)
+    N = 7
+    x = torch.randn(N, 4, 64, 64, generator=g)
+    c = torch.randn(N, 77, 768, generator=g)
+    t = torch.tensor([980.0, 860.0, 700.0, 500.0, 320.0, 120.0, 0.0])
+    e = ctx.unet_forward(x.cuda(), t.cuda(), c.cuda()).cpu()
+    assert torch.isfinite(e).all()
+    for b in range(N):
+        ref = SO.unet_forward(full_unet, x[b:b + 1], float(t[b]), c[b:b + 1])
+        margin("full-size UNet, sample %d of a batch of 7 (t=%d)" % (b, int(t[b])), rel_l2(e[b:b + 1], ref), 2.5e-2)
+
+
 def test_vae_full_size_128(ctx, full_vae):
     g = torch.Generator().manual_seed(2)
     img = torch.randint(0, 256, (2, 128, 128, 3), dtype=torch.uint8, generator=g)

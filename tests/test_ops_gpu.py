@@ -30,7 +30,8 @@ def stream():
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 320, 320), (77, 640, 768), (4096, 320, 2880),
-                                   (64, 1280, 11520), (1, 1280, 320), (257, 4, 128), (1000, 8, 512)])
+                                   (64, 1280, 11520), (1, 1280, 320), (257, 4, 128), (1000, 8, 512),
+                                   (28672, 320, 320), (24576 + 37, 640, 320), (65536, 320, 320)])     # the bench's 64 x 64 projections
 def test_gemm_bias_residual(ctx, M, N, K):
     g = torch.Generator(device="cuda").manual_seed(M * 7 + N * 3 + K)
     A = bf(torch.randn(M, K, device="cuda", generator=g))
