@@ -42,6 +42,8 @@ def parse():
     p.add_argument("--start_step", type=int, default=0)
     p.add_argument("--config", type=str, default="1_16_kitti_L1_64")
     p.add_argument("--no-denoise", action="store_true")
+    p.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16",
+                   help="fp8 = BASELINE configs[4]: qualifying dense projections of the UNet in MX block-scaled fp8 (the rest stays bf16)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     return p.parse_args()
@@ -264,7 +266,8 @@ def main():
     cfg = svg_config.load_config(args.config)
     dev = torch.device("cuda", local_rank)
     torch.manual_seed(0)
-    sd_utils = SDUtils(weights="synthetic", seed=0, verbose=(rank == 0))
+    fp8 = args.dtype == "fp8"
+    sd_utils = SDUtils(weights="synthetic", seed=0, verbose=(rank == 0), fp8=fp8)
     torch.manual_seed(0)
     model = Transformer(num_tokens=0, dim_model=cfg.DIM_MODEL[0], num_heads=cfg.NUM_HEADS[0],
                         num_encoder_layers=cfg.NUM_ENCODER_LAYERS[0], num_decoder_layers=cfg.NUM_DECODER_LAYERS[0],
@@ -281,7 +284,7 @@ def main():
     for _ in range(1, args.streams):
         c2 = _lib.Context(local_rank)
         torch.manual_seed(0)
-        sdu2 = SDUtils(weights="synthetic", seed=0, verbose=False, ctx=c2)
+        sdu2 = SDUtils(weights="synthetic", seed=0, verbose=False, ctx=c2, fp8=fp8)
         torch.manual_seed(0)
         m2 = Transformer(num_tokens=0, dim_model=cfg.DIM_MODEL[0], num_heads=cfg.NUM_HEADS[0],
                          num_encoder_layers=cfg.NUM_ENCODER_LAYERS[0], num_decoder_layers=cfg.NUM_DECODER_LAYERS[0],
@@ -324,7 +327,8 @@ def main():
         "generated frames/sec, 64x64 no-denoise (latent Transformer only)"
     line = {"metric": metric, "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if denoise else "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ("fp8 (MX e4m3 projections) + bf16" if fp8 else "bf16") if denoise else "f32", "data": "synthetic",
             "config": {"workload": "configs[2]: %s F=%d, --denoise --denoise_start_step %d (%d DDIM steps of the SD-v1.4 UNet at 64x64 latents, "
                                    "VAE enc/dec at 512x512), guidance_scale 0" % (args.config, F, args.start_step, 50 - args.start_step)
                        if denoise else "%s F=%d no --denoise (latent Transformer only)" % (args.config, F),

@@ -65,7 +65,9 @@ const char* svg_version(void);
  *   text-conditioned variant, whose first layer is named project_image_embedding instead of embedding).
  * VAE keys: block_out (128,256,512,512), layers (2), groups (32), latent (4).
  * UNet keys: block_out (320,640,1280,1280), layers (2), heads (8), ctx_dim (768), groups (32),
- *            in_ch (4), out_ch (4), attn (1,1,1,0: cross-attention per down block).
+ *            in_ch (4), out_ch (4), attn (1,1,1,0: cross-attention per down block), fp8 (0; 1 = BASELINE configs[4]: the
+ *            dense projections with K % 128 == 0 that carry no folded LayerNorm / GEGLU run in MX block-scaled fp8 —
+ *            OCP e4m3 + E8M0 per 32 — with activations quantised on the way in; everything else stays bf16).
  * CLIP text keys: vocab (49408), d_model (768), heads (12), layers (12), ffn (3072), max_pos (77); tensors by their
  *   transformers names without the "text_model." prefix (embeddings.token_embedding.weight, encoder.layers.N.*, ...). */
 int svg_model_configure(svg_ctx* ctx, int model, const char* kv);
@@ -156,6 +158,14 @@ int svg_op_gemm_cat(svg_ctx* ctx, const uint16_t* A, const uint16_t* A2, const u
 int svg_op_ff_fused(svg_ctx* ctx, const uint16_t* x, const float* ln_gamma, const float* ln_beta, const float* w1,
                     const float* b1, const float* w2, const float* b2, const uint16_t* residual, uint16_t* out, int M,
                     int C, void* stream);
+/* MX block-scaled fp8 (BASELINE configs[4]): OCP e4m3 elements with one E8M0 scale per 32 consecutive K elements.
+ * svg_op_quant_mx: x (rows,K) bf16 -> q (rows,K) e4m3 bytes, scales (rows,K/32) bytes; shared exponent floor(log2(amax)) - 8,
+ * round to nearest even, saturating at +-448 (OCP MX v1.0).  K % 32 == 0. */
+int svg_op_quant_mx(svg_ctx* ctx, const uint16_t* x, uint8_t* q, uint8_t* scales, int64_t rows, int K, void* stream);
+/* C[M,N] = act(Q(A)[M,K] Q(W)[N,K]^T + bias + residual) on v_mfma_scale_f32_16x16x128_f8f6f4 (f32 accumulate), both operands
+ * quantised on the fly by the routine above; act 0 none, 1 SiLU, 2 GELU.  K % 128 == 0, N % 4 == 0. */
+int svg_op_gemm_fp8(svg_ctx* ctx, const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* residual, void* C,
+                    int M, int N, int K, int act, int out_f32, void* stream);
 /* GroupNorm (+SiLU) on NHWC bf16. */
 int svg_op_groupnorm(svg_ctx* ctx, const uint16_t* x, const float* gamma, const float* beta,
                      uint16_t* out, int B, int HW, int C, int groups, float eps, int silu,

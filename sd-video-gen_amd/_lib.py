@@ -42,6 +42,8 @@ SIGNATURES = {
     "svg_op_conv3x3_gn": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, C.POINTER(_i), _vp],
     "svg_op_gemm_cat": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "svg_op_ff_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "svg_op_quant_mx": [_vp, _vp, _vp, _vp, _i64, _i, _vp],
+    "svg_op_gemm_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "svg_op_groupnorm": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "svg_op_layernorm": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "svg_op_attention": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _f, _vp],

@@ -72,6 +72,13 @@ void gemm_init_device();
 void gemm_pp_init_device();
 void conv_halo_init_device();
 void ff_fused_init_device();
+void gemm_fp8_init_device();
+
+// ---- MX block-scaled fp8 (OCP e4m3 elements, one E8M0 scale per 32 K elements): quantiser and GEMM (gemm_fp8.hip)
+void quant_mx_bf16(svg_ctx* ctx, const bf16* x, int ldx, uint8_t* q, uint8_t* sc, int64_t rows, int K, hipStream_t s);
+void quant_mx_f32(const float* x, int ldx, uint8_t* q, uint8_t* sc, int64_t rows, int K, hipStream_t s);
+bool gemm_fp8_supported(int M, int N, int K);
+void gemm_fp8(svg_ctx* ctx, const uint8_t* A, const uint8_t* As, const uint8_t* W, const uint8_t* Ws, const GemmArgs& g, hipStream_t s);
 
 // fused GEGLU feed-forward (C = 320): out = (GEGLU(LN(x) W1^T + b1)) W2^T + b2 + residual; the M x 4C intermediate stays on chip
 bool ff_fused_supported(int C, int M);

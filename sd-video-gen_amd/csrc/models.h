@@ -32,6 +32,10 @@ inline void run_planned(svg_ctx* ctx, F&& body) {
 
 // packed bf16 weight matrix [N][K] (+ f32 bias)
 struct PackedLinear {
+  // MX fp8 copy of w (gemm_fp8.hip): e4m3 elements + one E8M0 scale per 32 K elements; present when the owning model was
+  // configured with fp8=1 and the layer qualifies (K % 128 == 0, no folded LayerNorm, no GEGLU)
+  uint8_t* w8 = nullptr;
+  uint8_t* w8s = nullptr;
   bf16* w = nullptr;
   float* b = nullptr;
   float* ln_s = nullptr;     // row sums of w when a LayerNorm (gamma, beta) has been folded into w / b at load
@@ -102,6 +106,7 @@ struct UnetModel {
   std::vector<int> block_out{320, 640, 1280, 1280};
   std::vector<int> attn{1, 1, 1, 0};
   int layers = 2, heads = 8, ctx_dim = 768, groups = 32, in_ch = 4, out_ch = 4;
+  int fp8 = 0;                       // configure key fp8=1: qualifying dense projections run in MX block-scaled fp8
   bool ready = false;
   int temb_dim = 0;
   PackedLinear time1, time2, temb_all;     // temb_all: every resnet's time_emb_proj stacked [sum Cout][temb_dim]
@@ -150,6 +155,8 @@ ConvW load_conv3x3(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int
 PackedLinear load_linear(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int N, int K, bool bias, hipStream_t s,
                          const NormW* fold = nullptr);
 NormW load_norm(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int C);
+// adds the MX fp8 copy of a packed linear when it qualifies (see PackedLinear::w8)
+void add_fp8_copy(svg_ctx* ctx, PackedLinear& pl, hipStream_t s);
 float* keep_f32(svg_ctx* ctx, WeightStore& ws, const std::string& name, int64_t numel);
 // out (B,Ho,Wo,Cout) = conv3x3(x) + bias [+ per-sample bias] [+ residual]
 void conv3x3(svg_ctx* ctx, const bf16* x, const ConvW& cw, void* out, int B, int H, int W, int amode, const float* bias_bn,

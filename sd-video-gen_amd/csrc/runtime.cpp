@@ -166,6 +166,7 @@ int svg_create(int device_id, svg_ctx** out) {
   gemm_pp_init_device();
   conv_halo_init_device();
   ff_fused_init_device();
+  gemm_fp8_init_device();
   ctx = new svg_ctx();
   ctx->device = device_id;
   ctx->prof_entries.resize(PK_COUNT);
@@ -380,6 +381,32 @@ int svg_op_ff_fused(svg_ctx* ctx, const uint16_t* x, const float* ln_gamma, cons
     }
     ln_stats(ctx, (const bf16*)x, rs, rm, M, C, 1e-5f, s);
     ff_fused(ctx, (const bf16*)x, C, w1p, b1p, s1, rs, rm, w2p, b2d, (const bf16*)residual, C, (bf16*)out, C, M, s);
+  });
+  API_END(ctx)
+}
+
+// MX fp8 quantiser: x (rows,K) bf16 -> q (rows,K) e4m3 bytes + scales (rows,K/32) E8M0 bytes
+int svg_op_quant_mx(svg_ctx* ctx, const uint16_t* x, uint8_t* q, uint8_t* scales, int64_t rows, int K, void* stream) {
+  API_BEGIN
+  quant_mx_bf16(ctx, (const bf16*)x, K, q, scales, rows, K, (hipStream_t)stream);
+  API_END(ctx)
+}
+
+// C = act(Q(A) Q(W)^T + bias + residual) with both operands quantised to MX fp8 on the fly (test hook / benchmark of the fp8 GEMM)
+int svg_op_gemm_fp8(svg_ctx* ctx, const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* residual, void* C, int M, int N,
+                    int K, int act, int out_f32, void* stream) {
+  API_BEGIN
+  hipStream_t s = (hipStream_t)stream;
+  run_planned(ctx, [&]() {
+    uint8_t* aq = ctx->arena.get<uint8_t>((int64_t)M * K);
+    uint8_t* as = ctx->arena.get<uint8_t>((int64_t)M * (K / 32));
+    uint8_t* wq = ctx->arena.get<uint8_t>((int64_t)N * K);
+    uint8_t* wsc = ctx->arena.get<uint8_t>((int64_t)N * (K / 32));
+    quant_mx_bf16(ctx, (const bf16*)A, K, aq, as, M, K, s);
+    quant_mx_bf16(ctx, (const bf16*)W, K, wq, wsc, N, K, s);
+    GemmArgs g;
+    g.M = M; g.N = N; g.K = K; g.bias = bias; g.residual = (const bf16*)residual; g.ldr = N; g.act = act; g.out_f32 = out_f32; g.C = C; g.ldc = N;
+    gemm_fp8(ctx, aq, as, wq, wsc, g, s);
   });
   API_END(ctx)
 }

@@ -63,6 +63,14 @@ PackedLinear load_linear(svg_ctx* ctx, WeightStore& ws, const std::string& prefi
   return pl;
 }
 
+void add_fp8_copy(svg_ctx* ctx, PackedLinear& pl, hipStream_t s) {
+  if (!pl.w || pl.ln_s || pl.K % 128 != 0 || pl.N % 4 != 0 || pl.w8) return;
+  pl.w8 = (uint8_t*)ctx->dalloc((int64_t)pl.N * pl.K);
+  pl.w8s = (uint8_t*)ctx->dalloc((int64_t)pl.N * (pl.K / 32));
+  quant_mx_bf16(ctx, pl.w, pl.K, pl.w8, pl.w8s, pl.N, pl.K, s);
+  HIP_OK(hipStreamSynchronize(s));
+}
+
 NormW load_norm(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int C) {
   NormW n;
   n.C = C;
@@ -141,6 +149,18 @@ void linear(svg_ctx* ctx, const bf16* A, int lda, const PackedLinear& pl, void* 
                residual ? residual + (int64_t)m0 * ldr : nullptr, ldr, out_f32, s, ln_rs ? ln_rs + m0 : nullptr, ln_rm ? ln_rm + m0 : nullptr);
       return;
     }
+  }
+  if (pl.w8 && !A2 && !ln_rs && act != ACT_GEGLU && M >= 1024 && lda == pl.K && gemm_fp8_supported(M, pl.N, pl.K)) {
+    // MX fp8: the activations are quantised per 32-element block on the way in (one extra pass over A), f32 accumulate
+    ctx->arena.push();
+    uint8_t* aq = ctx->arena.get<uint8_t>((int64_t)M * pl.K);
+    uint8_t* as = ctx->arena.get<uint8_t>((int64_t)M * (pl.K / 32));
+    quant_mx_bf16(ctx, A, lda, aq, as, M, pl.K, s);
+    GemmArgs g8;
+    g8.M = M; g8.N = pl.N; g8.K = pl.K; g8.bias = pl.b; g8.act = act; g8.residual = residual; g8.ldr = ldr; g8.C = C; g8.ldc = ldc; g8.out_f32 = out_f32;
+    gemm_fp8(ctx, aq, as, pl.w8, pl.w8s, g8, s);
+    ctx->arena.pop();
+    return;
   }
   GemmArgs g;
   g.ln_rs = ln_rs; g.ln_rm = ln_rm; g.ln_s = pl.ln_s;

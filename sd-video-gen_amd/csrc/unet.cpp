@@ -12,6 +12,7 @@ void UnetModel::configure(const char* kv) {
   if (m.count("attn")) { attn.clear(); for (auto v : m["attn"]) attn.push_back((int)v); }
   geti("layers", layers); geti("heads", heads); geti("ctx_dim", ctx_dim); geti("groups", groups);
   geti("in_ch", in_ch); geti("out_ch", out_ch);
+  fp8 = 0; geti("fp8", fp8);
   ready = false;
 }
 
@@ -194,6 +195,19 @@ void UnetModel::finalize(svg_ctx* ctx, int64_t* n_params) {
     }
     up_res.push_back(rs); up_attn.push_back(as);
     if (i < nb - 1) up_s.push_back(load_conv3x3(ctx, ws, bp + ".upsamplers.0.conv", cin, cin, s));
+  }
+  if (fp8) {
+    // BASELINE configs[4]: the dense projections that qualify get an MX fp8 copy (attention out-projections, ff.net.2, proj_out,
+    // 1x1 shortcuts, cross-attention k / v at the 32 x 32 level and below: K = 640 ... 5120); the 64 x 64 level (K = 320) and
+    // every LayerNorm-folded / GEGLU projection stay bf16, as do the convolutions
+    auto add_xf = [&](XfBlockW& b) {
+      for (PackedLinear* pl : {&b.proj_out, &b.o1, &b.o2, &b.ff2, &b.k2, &b.v2}) add_fp8_copy(ctx, *pl, s);
+    };
+    for (auto& v : down_attn) for (auto& b : v) add_xf(b);
+    for (auto& v : up_attn) for (auto& b : v) add_xf(b);
+    add_xf(mid_attn);
+    for (auto& v : down_res) for (auto& r : v) if (r.has_sc) add_fp8_copy(ctx, r.sc, s);
+    for (auto& v : up_res) for (auto& r : v) if (r.has_sc) add_fp8_copy(ctx, r.sc, s);
   }
   norm_out = load_norm(ctx, ws, "conv_norm_out", c0);
   conv_out = load_conv3x3(ctx, ws, "conv_out", c0, out_ch, s);

@@ -184,7 +184,7 @@ def _local_clip_arch(dirname):
 
 
 class SDUtils():
-    def __init__(self, weights=None, text_embeddings=None, seed=0, verbose=True, arch=None, ctx=None):
+    def __init__(self, weights=None, text_embeddings=None, seed=0, verbose=True, arch=None, ctx=None, fp8=None):
         self.config, self.args = parse_config_args()             # sd_utils.py:22
         self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
         if self.device.type != "cuda":
@@ -199,6 +199,8 @@ class SDUtils():
         self._seed = seed
         self._verbose = verbose
         self._text_embeddings = text_embeddings
+        # BASELINE configs[4]: MX block-scaled fp8 for the qualifying dense projections of the UNet (svg_hip.h, key fp8)
+        self.fp8 = bool(int(os.environ.get("SVG_UNET_FP8", "0"))) if fp8 is None else bool(fp8)
         # `arch` overrides the SD v1.4 widths (reduced-size parity tests): {'vae': {...}, 'unet': {...}}
         # (a local diffusers directory's config.json plays the same role, as it does for from_pretrained)
         local = os.environ.get("SVG_SD_WEIGHTS")
@@ -262,7 +264,7 @@ class SDUtils():
         c = self.unet_arch
         sd, self.unet_source = self._weights_for("unet", weights, lambda: sd_layout.unet_shapes(c), self._seed + 2)
         ctx.configure(_lib.SVG_UNET, block_out=list(c["block_out"]), layers=c["layers"], heads=c["heads"], ctx_dim=c["ctx_dim"],
-                      groups=c["groups"], in_ch=4, out_ch=4, attn=list(c["attn"]))
+                      groups=c["groups"], in_ch=4, out_ch=4, attn=list(c["attn"]), fp8=int(self.fp8))
         ctx.load_state_dict(_lib.SVG_UNET, sd)
         unet = _UNet(ctx, ctx.finalize(_lib.SVG_UNET))
         del sd

@@ -1,0 +1,118 @@
+"""GPU: the MX block-scaled fp8 path (BASELINE configs[4] "fp8 MFMA on CDNA4"): OCP e4m3 elements with one E8M0 scale per 32 K
+elements, v_mfma_scale_f32_16x16x128_f8f6f4.  The quantiser is checked bit for bit against a torch restatement of the OCP MX
+v1.0 conversion (float8_e4m3fn, round to nearest even, saturating); the GEMM is checked (a) exactly on integer data, (b) against
+the f32 product of the DEQUANTISED operands (only the accumulation order differs), and (c) against the unquantised product with
+the stated fp8 tolerance."""
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+from conftest import margin, rel_l2
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+FP8_TOL = 6e-2        # MX e4m3 (3 mantissa bits, shared power-of-two scale per 32): measured 3.6e-2 .. 3.9e-2 rel-L2 on N(0,1) operands
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def mx_quant_ref(x):
+    """x (rows,K) float -> (e4m3 bytes (rows,K) uint8, E8M0 bytes (rows,K/32) uint8, dequantised float)"""
+    rows, K = x.shape
+    xb = x.float().reshape(rows, K // 32, 32)
+    am = xb.abs().amax(dim=-1)
+    e = torch.where(am > 0, torch.floor(torch.log2(am.double())).float() - 8, torch.full_like(am, -127.0)).clamp(-127, 126)
+    # exact floor(log2) from the exponent bits (log2 in floating point can be off by one at powers of two)
+    bits = am.view(torch.int32)
+    e_bits = torch.where(am > 0, ((bits >> 23) & 0xff).float() - 127 - 8, torch.full_like(am, -127.0)).clamp(-127, 126)
+    e = e_bits
+    scaled = (xb * torch.exp2(-e)[..., None]).clamp(-448, 448)
+    q = scaled.to(torch.float8_e4m3fn)
+    deq = q.float() * torch.exp2(e)[..., None]
+    return q.view(torch.uint8).reshape(rows, K), (e + 127).to(torch.uint8), deq.reshape(rows, K)
+
+
+@pytest.mark.parametrize("rows,K", [(7, 128), (300, 640), (4096, 1280)])
+def test_quant_mx_matches_ocp_reference(ctx, rows, K):
+    g = torch.Generator(device="cuda").manual_seed(rows + K)
+    x = (torch.randn(rows, K, device="cuda", generator=g) * torch.exp2(torch.randint(-6, 7, (rows, 1), device="cuda", generator=g).float())).to(torch.bfloat16)
+    x[0, :32] = 0                                              # an all-zero block
+    x[1, 5] = 448.0 * 2 ** 3                                    # a block whose maximum sits on e4m3's largest value
+    q = torch.empty(rows, K, device="cuda", dtype=torch.uint8)
+    sc = torch.empty(rows, K // 32, device="cuda", dtype=torch.uint8)
+    ctx.check(ctx.lib.svg_op_quant_mx(ctx.h, x.data_ptr(), q.data_ptr(), sc.data_ptr(), rows, K, stream()), "quant_mx")
+    q_ref, sc_ref, _ = mx_quant_ref(x.float())
+    assert torch.equal(sc, sc_ref)
+    # e4m3 has +0 / -0: compare values, not bit patterns of zero
+    same = (q == q_ref) | (((q & 0x7f) == 0) & ((q_ref & 0x7f) == 0))
+    assert same.all(), int((~same).sum())
+
+
+def test_gemm_fp8_integer_exact(ctx):
+    """integers in [-8, 8]: every block quantises exactly (amax 8 -> elements x * 32 <= 256, three mantissa bits suffice) and every
+    product / partial sum is an exact f32: the GEMM equals the integer product bit for bit — operand and scale lane maps included."""
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for (M, N, K) in [(128, 128, 128), (300, 320, 640), (1000, 64, 256), (257, 644, 1280)]:
+        A = torch.randint(-8, 9, (M, K), device="cuda", generator=g).float()
+        W = torch.randint(-8, 9, (N, K), device="cuda", generator=g).float()
+        A[:, :32] *= 0.5                                       # blocks with different shared exponents along K and across rows
+        W[::3, 32:64] *= 4
+        A, W = A.to(torch.bfloat16), W.to(torch.bfloat16)
+        out = torch.empty(M, N, device="cuda", dtype=torch.float32)
+        ctx.check(ctx.lib.svg_op_gemm_fp8(ctx.h, A.data_ptr(), W.data_ptr(), None, None, out.data_ptr(), M, N, K, 0, 1, stream()), "gemm_fp8")
+        ref = A.double() @ W.double().t()
+        assert torch.equal(out.double(), ref), (M, N, K, float((out.double() - ref).abs().max()))
+
+
+@pytest.mark.parametrize("M,N,K,act", [(4096, 640, 640, 0), (1024, 1280, 2560, 0), (7168, 1280, 1280, 1), (513, 324, 768, 2)])
+def test_gemm_fp8(ctx, M, N, K, act):
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g)
+    R = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16)
+    out = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    ctx.check(ctx.lib.svg_op_gemm_fp8(ctx.h, A.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr(), out.data_ptr(), M, N, K, act, 1, stream()), "gemm_fp8")
+    _, _, Ad = mx_quant_ref(A.float())
+    _, _, Wd = mx_quant_ref(W.float())
+    f = {0: lambda t: t, 1: torch.nn.functional.silu, 2: torch.nn.functional.gelu}[act]
+    ref_q = f(Ad @ Wd.t() + b + R.float())
+    ref = f(A.float() @ W.float().t() + b + R.float())
+    assert rel_l2(out, ref_q) < 2e-5                            # same quantised operands: accumulation order only
+    pre = lambda t: t - b - R.float() if act == 0 else t        # the product itself (bias and residual would mask its error)
+    margin("MX fp8 GEMM %dx%dx%d vs unquantised product" % (M, N, K), rel_l2(pre(out), pre(ref)), FP8_TOL)
+    outb = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ctx.check(ctx.lib.svg_op_gemm_fp8(ctx.h, A.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr(), outb.data_ptr(), M, N, K, act, 0, stream()), "gemm_fp8")
+    assert rel_l2(outb.float(), out) < 4e-3
+
+
+def test_unet_step_fp8_full_size(ctx):
+    """configs[4]: the full-size SD v1.4 UNet with fp8=1 (out-projections, ff.net.2, proj_out, 1x1 shortcuts, cross k at the
+    32 x 32 level and below in MX fp8) against the fp32 oracle, and against the bf16 path of the same library."""
+    from oracle import sd_oracle as SO
+    from sd_video_gen_amd import _lib
+    usd = SO.seeded_weights(SO.unet_shapes(), 31)
+    c = SO.SD_UNET
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 4, 64, 64, generator=g)
+    cc = torch.randn(2, 77, 768, generator=g)
+    t = torch.tensor([500.0, 40.0])
+    outs = {}
+    for fp8 in (0, 1):
+        ctx.configure(_lib.SVG_UNET, block_out=list(c["block_out"]), layers=2, heads=8, ctx_dim=768, groups=32, attn=list(c["attn"]), fp8=fp8)
+        ctx.load_state_dict(_lib.SVG_UNET, usd)
+        assert ctx.finalize(_lib.SVG_UNET) == 859_520_964
+        outs[fp8] = ctx.unet_forward(x.cuda(), t.cuda(), cc.cuda()).cpu()
+    ref = torch.cat([SO.unet_forward(usd, x[b:b + 1], float(t[b]), cc[b:b + 1]) for b in range(2)])
+    e16 = rel_l2(outs[0], ref)
+    margin("full-size UNet call, bf16 (same inputs)", e16, 2.5e-2)
+    margin("full-size UNet call with fp8=1 vs the fp32 oracle", rel_l2(outs[1], ref), 9e-2)
+    margin("full-size UNet call, fp8=1 vs bf16 path", rel_l2(outs[1], outs[0]), 9e-2)
+    assert not torch.equal(outs[0], outs[1])                    # the fp8 projections really ran

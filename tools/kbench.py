@@ -72,6 +72,28 @@ def main():
             ms, fl, _ = timeit(ctx, "gemm", lambda: ctx.check(ctx.lib.svg_op_gemm(
                 ctx.h, A.data_ptr(), W.data_ptr(), bias.data_ptr(), res.data_ptr() if res is not None else None, out.data_ptr(), M, N, K, act, 0, stream()), "gemm"))
             print("%7d %6d %6d %d  %8.3f ms  %7.1f TF" % (M, N, K, act, ms, fl / ms / 1e9))
+    if "fp8" in a.what:
+        print("== MX fp8 GEMM vs bf16 GEMM (B=%d): M N K  fp8 ms (TF, incl. nothing else)  quantise-A ms  bf16 ms (TF)" % B)
+        for (hw, N, K) in ((256, 1280, 5120), (256, 1280, 1280), (256, 2560, 1280), (1024, 640, 2560), (1024, 1280, 640), (1024, 640, 640), (4096, 320, 1280), (4096, 640, 640)):
+            M = hw * B
+            A = torch.randn(M, K, device="cuda").to(bf)
+            W = (torch.randn(N, K, device="cuda") / math.sqrt(K)).to(bf)
+            out = torch.empty(M, N, device="cuda", dtype=bf)
+
+            def run8():
+                ctx.check(ctx.lib.svg_op_gemm_fp8(ctx.h, A.data_ptr(), W.data_ptr(), None, None, out.data_ptr(), M, N, K, 0, 0, stream()), "fp8")
+            run8(); torch.cuda.synchronize()
+            ctx.prof_reset(); ctx.prof_enable(True, detail=True)
+            for _ in range(5):
+                run8()
+            torch.cuda.synchronize()
+            rep = ctx.prof_report(); ctx.prof_enable(False)
+            g8 = [v for k, v in rep.items() if k.startswith("@gemm|fp8")][0]
+            qa = [v for k, v in rep.items() if k.startswith("@eltwise|quant_mx_rows%d_" % M)][0]
+            ms16, fl, _ = timeit(ctx, "gemm", lambda: ctx.check(ctx.lib.svg_op_gemm(
+                ctx.h, A.data_ptr(), W.data_ptr(), None, None, out.data_ptr(), M, N, K, 0, 0, stream()), "gemm"))
+            ms8 = g8["ms"] / g8["calls"]
+            print("%7d %6d %6d  %8.3f ms %7.1f TF   quant %7.3f ms   bf16 %8.3f ms %7.1f TF" % (M, N, K, ms8, fl / ms8 / 1e9, qa["ms"] / qa["calls"], ms16, fl / ms16 / 1e9))
     if "ff" in a.what:
         print("== fused GEGLU feed-forward C=320 (B=%d): M  ms  TFLOP/s" % B)
         C, Fh = 320, 1280
