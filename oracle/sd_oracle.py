@@ -402,3 +402,54 @@ def gen_i2i_latents(sd, text_embeddings, latents, num_inference_steps=50, guidan
         latents = sch.step(eps, int(t), latents)
         hist.append(latents)
     return torch.cat(hist, dim=0) if return_all_latents else latents
+
+
+class LMS:
+    """diffusers 0.2.3 LMSDiscreteScheduler as constructed at utils/sd_utils.py:70-72 and driven by denoise_img_latents
+    (utils/sd_utils.py:97-126): restated from the published algorithm (third-party source absent from /root/reference)."""
+
+    def __init__(self, beta_start=0.00085, beta_end=0.012, num_train=1000):
+        betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train, dtype=np.float32) ** 2
+        ac = np.cumprod(1.0 - betas, axis=0)
+        self.train_sigmas = ((1 - ac) / ac) ** 0.5
+        self.num_train = num_train
+
+    def set_timesteps(self, n):
+        self.timesteps = np.linspace(self.num_train - 1, 0, n, dtype=float)
+        lo, hi = np.floor(self.timesteps).astype(int), np.ceil(self.timesteps).astype(int)
+        fr = np.mod(self.timesteps, 1.0)
+        self.sigmas = np.concatenate([(1 - fr) * self.train_sigmas[lo] + fr * self.train_sigmas[hi], [0.0]])
+        self.derivatives = []
+
+    def coeff(self, order, t, cur):
+        from scipy import integrate
+
+        def f(tau):
+            p = 1.0
+            for k in range(order):
+                if k != cur:
+                    p *= (tau - self.sigmas[t - k]) / (self.sigmas[t - cur] - self.sigmas[t - k])
+            return p
+        return integrate.quad(f, self.sigmas[t], self.sigmas[t + 1], epsrel=1e-4)[0]
+
+    def step(self, eps, i, x, order=4):
+        self.derivatives.append(eps)                      # (x - (x - sigma eps)) / sigma
+        if len(self.derivatives) > order:
+            self.derivatives.pop(0)
+        order = min(i + 1, order)
+        return x + sum(self.coeff(order, i, o) * d for o, d in zip(range(order), reversed(self.derivatives)))
+
+
+def denoise_img_latents(sd, text_embeddings, latents, num_inference_steps=50, guidance_scale=7.5, cfg=SD_UNET, unet=None):
+    """utils/sd_utils.py:97-126 on a CPU host (fp32)."""
+    unet = unet or (lambda x, t, c: unet_forward(sd, x, t, c, cfg))
+    sch = LMS()
+    sch.set_timesteps(num_inference_steps)
+    latents = latents * float(sch.sigmas[0])
+    for i, t in enumerate(sch.timesteps):
+        sigma = float(sch.sigmas[i])
+        inp = torch.cat([latents] * 2) / ((sigma ** 2 + 1) ** 0.5)
+        eps = unet(inp, float(t), text_embeddings)
+        e_u, e_t = eps.chunk(2)
+        latents = sch.step(e_u + guidance_scale * (e_t - e_u), i, latents)
+    return latents

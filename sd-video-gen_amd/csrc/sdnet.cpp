@@ -81,7 +81,8 @@ NormW load_norm(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int C)
 
 // fills emit->st when the launch gemm_auto() picks for g can leave the output's GroupNorm column sums (whole row tiles per sample)
 static void plan_gn_emit(GemmArgs& g, GnEmit* emit, int rows_per_sample) {
-  if (!emit || !emit->buf || rows_per_sample < 1024) return;     // small images take the single-launch GroupNorm (one read)
+  static const int use_epi = getenv("SVG_GN_EPI") ? atoi(getenv("SVG_GN_EPI")) : 1;   // 0: A/B switch, statistics pass as before
+  if (!use_epi || !emit || !emit->buf || rows_per_sample < 1024) return;   // small images take the single-launch GroupNorm (one read)
   const int rows = gemm_emits_gn(g);
   if (rows <= 0 || rows_per_sample % rows != 0) return;
   g.gn_part = emit->buf;

@@ -236,6 +236,7 @@ def main(argv=None):
     """Same flags and flow as the reference's __main__; datasets: 'synthetic-ball' (built in) or a folder of PNG
     clips via --folder.  Clips are sharded over ranks when launched under torch.distributed.run."""
     import os
+    import numpy as np
     from . import config as svg_config, sharding
     from .sd_utils import SDUtils
     from .transformer import Transformer
@@ -269,10 +270,27 @@ def main(argv=None):
     F = config.FRAME_SIZE
     if args.dataset in ("synthetic-ball", "synthetic"):
         clips = bouncing_ball_clips(8, F, 5, seed=0)
+    elif args.dataset in ("ball", "kitti"):                                                               # predict.py:56-58,111-114
+        from .loaders import BouncingBall, Kitti
+        if not args.folder:
+            raise ValueError("dataset '%s' needs --folder (directory with a test/ stage of PNG frame folders)" % args.dataset)
+        # unshuffled: clip c keeps its index (and its seed) whatever the world size — the reference shuffles (batch_size 1)
+        ds = (BouncingBall if args.dataset == "ball" else Kitti)(num_frames=5, stride=1, dir=args.folder, stage="test", shuffle=False)
+        items = [ds[i][1] for i in range(len(ds)) if len(ds.dataset[i]) == 5]
+        if not items:
+            raise ValueError("no 5-frame clips under %s" % os.path.join(args.folder, "test"))
+        clips = torch.from_numpy(np.stack(items))
+        if clips.shape[2] != F or clips.shape[3] != F:
+            raise ValueError("frames are %dx%d but config %s has FRAME_SIZE %d" % (clips.shape[2], clips.shape[3], args.config, F))
+    elif "ucf" in args.dataset:
+        if args.dataset not in ("ucf", "ucf-wallpushups", "ucf-workout", "ucf-instruments") and not args.dataset.endswith(("wallpushups", "workout", "instruments")):
+            raise ValueError("Invalid dataset name")                                                      # predict.py:70
+        if not args.folder:
+            raise ValueError("UCF-101 clips are read from video files by torchvision / PyAV in the reference (predict.py:60-109); "
+                             "extract frames to PNG folders and pass --folder")
+        clips = _png_clips(args.folder, F)
     elif args.folder:
         clips = _png_clips(args.folder, F)
-    elif args.dataset in ("ball", "kitti") or "ucf" in args.dataset:
-        raise ValueError("dataset '%s' needs --folder with PNG clips (the reference's loaders/datasets are not bundled)" % args.dataset)
     else:
         raise ValueError("Invalid dataset name")                                                          # predict.py:70
     n = clips.shape[0]

@@ -183,6 +183,54 @@ def _local_clip_arch(dirname):
     return {v: int(c[k]) for k, v in m.items() if k in c}
 
 
+class LMSDiscreteScheduler:
+    """The scheduler the reference builds at sd_utils.py:70-72 (diffusers 0.2.3 LMSDiscreteScheduler(beta_start=0.00085,
+    beta_end=0.012, beta_schedule='scaled_linear', num_train_timesteps=1000)) and uses in denoise_img_latents
+    (sd_utils.py:97-126): sigmas = sqrt((1 - abar) / abar), `set_timesteps` interpolates them on linspace(999, 0, n) and
+    appends 0, `step` is the linear multistep update of order <= 4 whose coefficients integrate the Lagrange basis of the last
+    sigmas (scipy.integrate.quad, as diffusers does).  Host-side arithmetic on a handful of scalars; the tensors stay on the GPU."""
+
+    def __init__(self, beta_start=0.00085, beta_end=0.012, num_train_timesteps=1000):
+        betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=np.float32) ** 2
+        self.alphas_cumprod = np.cumprod(1.0 - betas, axis=0)
+        self.train_sigmas = ((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5
+        self.num_train_timesteps = num_train_timesteps
+        self.set_timesteps(num_train_timesteps)
+
+    def set_timesteps(self, num_inference_steps):
+        self.num_inference_steps = num_inference_steps
+        self.timesteps = np.linspace(self.num_train_timesteps - 1, 0, num_inference_steps, dtype=float)
+        low = np.floor(self.timesteps).astype(int)
+        high = np.ceil(self.timesteps).astype(int)
+        frac = np.mod(self.timesteps, 1.0)
+        sig = (1 - frac) * self.train_sigmas[low] + frac * self.train_sigmas[high]
+        self.sigmas = np.concatenate([sig, [0.0]])
+        self.derivatives = []
+
+    def get_lms_coefficient(self, order, t, current_order):
+        from scipy import integrate
+
+        def lms_derivative(tau):
+            prod = 1.0
+            for k in range(order):
+                if current_order == k:
+                    continue
+                prod *= (tau - self.sigmas[t - k]) / (self.sigmas[t - current_order] - self.sigmas[t - k])
+            return prod
+        return integrate.quad(lms_derivative, self.sigmas[t], self.sigmas[t + 1], epsrel=1e-4)[0]
+
+    def step(self, model_output, timestep, sample, order=4):
+        sigma = float(self.sigmas[timestep])
+        pred_original_sample = sample - sigma * model_output
+        self.derivatives.append((sample - pred_original_sample) / sigma)
+        if len(self.derivatives) > order:
+            self.derivatives.pop(0)
+        order = min(timestep + 1, order)
+        coeffs = [self.get_lms_coefficient(order, timestep, o) for o in range(order)]
+        prev = sample + sum(c * d for c, d in zip(coeffs, reversed(self.derivatives)))
+        return {"prev_sample": prev}
+
+
 class SDUtils():
     def __init__(self, weights=None, text_embeddings=None, seed=0, verbose=True, arch=None, ctx=None, fp8=None):
         self.config, self.args = parse_config_args()             # sd_utils.py:22
@@ -268,9 +316,9 @@ class SDUtils():
         ctx.load_state_dict(_lib.SVG_UNET, sd)
         unet = _UNet(ctx, ctx.finalize(_lib.SVG_UNET))
         del sd
-        # (the reference also builds an LMSDiscreteScheduler here, sd_utils.py:70-72; gen_i2i_latents never uses it — the DDIM
-        # schedule of sd_utils.py:233-237 lives in the library)
-        return vae, tokenizer, text_encoder, unet, None
+        # sd_utils.py:70-72: the LMS scheduler of the text-to-image sampler (denoise_img_latents); gen_i2i_latents builds its own
+        # DDIM schedule (sd_utils.py:233-237), which lives in the library
+        return vae, tokenizer, text_encoder, unet, LMSDiscreteScheduler()
 
     def _load_clip(self, weights):
         ctx, c = self.ctx, self.clip_arch
@@ -327,6 +375,39 @@ class SDUtils():
         with torch.no_grad():
             uncond_embeddings = self.text_encoder(uncond_input.input_ids.to(self.device))[0]
         return torch.cat([uncond_embeddings, text_embeddings])
+
+    # ---- sd_utils.py:97-126 ----------------------------------------------------------------------------
+    def denoise_img_latents(self, text_embeddings, height=512, width=512, num_inference_steps=50, guidance_scale=7.5, latents=None,
+                            start_step=None):
+        """text-conditioned LMS sampling from noise (the reference's text-to-image path): UNet calls at batch 2N in the library,
+        the classifier-free-guidance combine and the multistep update on the (N,4,h,w) latents as device tensor arithmetic."""
+        if self.unet is None:
+            raise RuntimeError("denoise_img_latents needs the UNet: construct SDUtils with --denoise")
+        if latents is None:
+            latents = torch.randn((text_embeddings.shape[0] // 2, self.unet.in_channels, height // 8, width // 8))
+        latents = latents.to(self.device).float()
+        text_embeddings = text_embeddings.to(self.device)
+        self.scheduler.set_timesteps(num_inference_steps)
+        latents = latents * float(self.scheduler.sigmas[0])
+        with torch.no_grad():
+            for i, t in enumerate(self.scheduler.timesteps):
+                latent_model_input = torch.cat([latents] * 2)
+                sigma = float(self.scheduler.sigmas[i])
+                latent_model_input = latent_model_input / ((sigma ** 2 + 1) ** 0.5)
+                noise_pred = self.unet(latent_model_input, float(t), encoder_hidden_states=text_embeddings)["sample"]
+                noise_pred_uncond, noise_pred_text = noise_pred.chunk(2)
+                noise_pred = noise_pred_uncond + guidance_scale * (noise_pred_text - noise_pred_uncond)
+                latents = self.scheduler.step(noise_pred, i, latents)["prev_sample"]
+        return latents
+
+    # ---- sd_utils.py:171-189 ---------------------------------------------------------------------------
+    def prompt_to_img(self, prompts, height=512, width=512, num_inference_steps=50, guidance_scale=7.5, latents=None):
+        if isinstance(prompts, str):
+            prompts = [prompts]
+        text_embeds = self.encode_text(prompts)
+        latents = self.denoise_img_latents(text_embeds, height=height, width=width, latents=latents,
+                                           num_inference_steps=num_inference_steps, guidance_scale=guidance_scale)
+        return self.decode_img_latents(latents)
 
     # ---- sd_utils.py:128-154 ---------------------------------------------------------------------------
     def encode_img(self, imgs, eps=None):

@@ -1,0 +1,92 @@
+"""CPU: dataset front-end (sd_video_gen_amd.loaders) — the directory crawl / clip grouping rules of the reference's
+loaders/bouncing_ball_loader.py:41-91 and loaders/kitti_loader.py:43-100, and the LMS scheduler closed forms."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def write_png(path, value, hw=(8, 8)):
+    from PIL import Image
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    img = np.zeros(hw + (3,), dtype=np.uint8)
+    img[..., 0] = value            # R
+    img[..., 2] = 255 - value      # B
+    Image.fromarray(img).save(path)
+
+
+def make_tree(root, stage, folders):
+    """folders: {parent name: number of frames}; files named frame_NNN.png"""
+    for parent, n in folders.items():
+        for i in range(n):
+            write_png(os.path.join(root, stage, parent, "frame_%03d.png" % i), (int(parent) * 16 + i) % 256)
+
+
+def test_bouncing_ball_crawl(tmp_path):
+    from sd_video_gen_amd.loaders import BouncingBall
+    make_tree(str(tmp_path), "test", {"0001": 12, "0002": 7})
+    ds = BouncingBall(num_frames=5, stride=1, dir=str(tmp_path), stage="test", shuffle=False)
+    # 19 frames sorted by int(parent + NNN): clips start every 5 frames: 0-4, 5-9, (10,11 then folder changes -> short clip of 2)
+    assert [len(x) for x in ds.dataset] == [5, 5, 2]           # the reference keeps the clip cut short by the folder change
+    assert ds.indices[0] == [1000, 1001, 1002, 1003, 1004] and ds.indices[1][0] == 1005 and ds.indices[2] == [1010, 1011]
+    idx, frames = ds[1]
+    assert idx == ds.indices[1] and frames.shape == (5, 8, 8, 3) and frames.dtype == np.uint8
+    v = (1 * 16 + 5) % 256
+    assert frames[0, 0, 0, 2] == v and frames[0, 0, 0, 0] == 255 - v        # BGR like cv2.imread: R was written as `value`
+    # stride 2: clips of frames i, i+2, ... taken every 10 frames, only for i % stride == 0
+    ds2 = BouncingBall(num_frames=5, stride=2, dir=str(tmp_path), stage="test", shuffle=False)
+    assert ds2.indices[0] == [1000, 1002, 1004, 1006, 1008]
+    # shuffle permutes the file lists (seeded through numpy, like the reference)
+    np.random.seed(0)
+    ds3 = BouncingBall(num_frames=5, stride=1, dir=str(tmp_path), stage="test", shuffle=True)
+    assert sorted(map(tuple, ds3.dataset)) == sorted(map(tuple, ds.dataset))
+    import loaders.bouncing_ball_loader as ref_path
+    assert ref_path.BouncingBall is BouncingBall
+
+
+def test_kitti_crawl_and_transform(tmp_path):
+    from PIL import Image
+    from sd_video_gen_amd import config as svg_config
+    from sd_video_gen_amd.loaders import Kitti, resize_bilinear_u8
+    svg_config.set_args(["--dataset", "kitti", "--config", "1_16_kitti_L1_64"])
+    root = str(tmp_path)
+    for parent, n in {"0003": 5, "0004": 5, "0005": 3, "0006": 7}.items():
+        for i in range(n):
+            p = os.path.join(root, "test", parent, "%010d_%03d.png" % (i, i))
+            os.makedirs(os.path.dirname(p), exist_ok=True)
+            g = np.random.default_rng(i)
+            Image.fromarray(g.integers(0, 256, size=(96, 160, 3), dtype=np.uint8)).save(p)
+    ds = Kitti(num_frames=5, stride=1, dir=root, stage="test", shuffle=False)
+    # 20 frames, clips start every 5: 0003 (whole), 0004 (whole), then 0005's 3 frames + 0006's first 2 (straddles: dropped,
+    # kitti_loader.py:77), then 0006 frames 2-6
+    assert [len(x) for x in ds.dataset] == [5, 5, 5]
+    assert ds.indices[0] == [3000, 3001, 3002, 3003, 3004] and ds.indices[1][0] == 4000 and ds.indices[2] == [6002, 6003, 6004, 6005, 6006]
+    idx, frames = ds[0]
+    assert frames.shape == (5, 64, 64, 3)                       # centre square (96 x 96 of 96 x 160), resized to FRAME_SIZE
+    # geometry of the resize: identity at equal size, exact 2x2 averages at a factor 2 (half-pixel centres)
+    a = np.random.default_rng(1).integers(0, 256, size=(16, 16, 3), dtype=np.uint8)
+    assert np.array_equal(resize_bilinear_u8(a, 16, 16), a)
+    half = resize_bilinear_u8(a, 8, 8)
+    avg = a.reshape(8, 2, 8, 2, 3).astype(np.float64).mean(axis=(1, 3))
+    assert np.abs(half.astype(np.float64) - avg).max() <= 0.5 + 1e-9
+    src = np.asarray(Image.open(ds.dataset[0][0]).convert("RGB"))[..., ::-1]
+    assert np.array_equal(frames[0], resize_bilinear_u8(src[:, 32:128], 64, 64))
+
+
+def test_lms_scheduler_closed_forms():
+    from oracle import sd_oracle as SO
+    from sd_video_gen_amd.sd_utils import LMSDiscreteScheduler
+    s = LMSDiscreteScheduler()
+    s.set_timesteps(50)
+    assert abs(s.sigmas[0] - 14.6146) < 1e-3 and s.sigmas[-1] == 0.0 and len(s.sigmas) == 51      # SD's sigma_max
+    assert s.timesteps[0] == 999.0 and s.timesteps[-1] == 0.0
+    o = SO.LMS()
+    o.set_timesteps(50)
+    assert np.allclose(s.sigmas, o.sigmas) and np.allclose(s.timesteps, o.timesteps)
+    # first step is Euler: the single coefficient is sigma_1 - sigma_0
+    assert abs(s.get_lms_coefficient(1, 0, 0) - (s.sigmas[1] - s.sigmas[0])) < 1e-6
+    assert abs(sum(s.get_lms_coefficient(4, 10, k) for k in range(4)) - (s.sigmas[11] - s.sigmas[10])) < 1e-5   # Lagrange basis sums to 1

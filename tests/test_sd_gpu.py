@@ -189,3 +189,24 @@ def test_missing_weight_is_reported(ctx):
         ctx.finalize(_lib.SVG_UNET)
     with pytest.raises((RuntimeError, ValueError)):
         ctx.unet_forward(torch.zeros(1, 4, 16, 16).cuda(), torch.zeros(1).cuda(), torch.zeros(1, 7, 64).cuda())
+
+
+def test_lms_text_to_image_sampler(ctx):
+    """utils/sd_utils.py:97-126,171-189: denoise_img_latents (LMS, classifier-free guidance) and prompt_to_img on reduced-width
+    networks, against the oracle's restatement of the same loop."""
+    from sd_video_gen_amd import config as svg_config
+    from sd_video_gen_amd.sd_utils import SDUtils
+    svg_config.set_args(["--dataset", "synthetic-ball", "--config", "model_10_26", "--denoise", "1"])
+    vcfg = dict(block_out=(64, 128, 128, 128), layers=1, groups=32, latent=4)
+    ucfg = dict(block_out=(64, 128), layers=1, heads=4, ctx_dim=768, groups=32, in_ch=4, out_ch=4, attn=(1, 0))
+    vsd, usd = SO.seeded_weights(SO.vae_shapes(vcfg), 3), SO.seeded_weights(SO.unet_shapes(ucfg), 4)
+    g = torch.Generator().manual_seed(5)
+    emb = torch.randn(4, 77, 768, generator=g)                 # [uncond x2 ; text x2]
+    sdu = SDUtils(weights={"vae": vsd, "unet": usd}, arch={"vae": vcfg, "unet": ucfg}, verbose=False, text_embeddings=emb)
+    lat0 = torch.randn(2, 4, 16, 16, generator=g)
+    got = sdu.denoise_img_latents(emb, height=128, width=128, num_inference_steps=6, guidance_scale=7.5, latents=lat0.clone()).cpu()
+    want = SO.denoise_img_latents(usd, emb, lat0.clone(), 6, 7.5, cfg=ucfg)
+    margin("LMS text-to-image, 6 steps at guidance 7.5 (tiny UNet)", rel_l2(got, want), NET_TOL)
+    assert abs(sdu.scheduler.sigmas[0] - 14.6146) < 1e-3
+    imgs = sdu.prompt_to_img(["a photo"], height=128, width=128, num_inference_steps=3, latents=lat0[:1].clone())
+    assert imgs.shape == (1, 128, 128, 3) and imgs.dtype.name == "uint8"
