@@ -193,9 +193,6 @@ int svg_prof_reset(svg_ctx* ctx);
 int svg_prof_report(svg_ctx* ctx, char* buf, int buflen);
 /* workspace bytes currently reserved by the context */
 int64_t svg_workspace_bytes(svg_ctx* ctx);
-/* capture the DDIM loop body into a hipGraph and replay it (1) or launch eagerly (0, default) */
-int svg_set_graph_mode(svg_ctx* ctx, int on);
-
 #ifdef __cplusplus
 }
 #endif

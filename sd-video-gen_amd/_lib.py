@@ -52,7 +52,6 @@ SIGNATURES = {
     "svg_prof_reset": [_vp],
     "svg_prof_report": [_vp, C.c_char_p, _i],
     "svg_workspace_bytes": [_vp],
-    "svg_set_graph_mode": [_vp, _i],
 }
 _RESTYPES = {"svg_destroy": None, "svg_last_error": C.c_char_p, "svg_version": C.c_char_p,
              "svg_workspace_bytes": _i64}
@@ -277,8 +276,6 @@ class Context:
     def workspace_bytes(self):
         return int(self.lib.svg_workspace_bytes(self.h))
 
-    def set_graph_mode(self, on):
-        self.lib.svg_set_graph_mode(self.h, 1 if on else 0)
 
 
 _default_ctx = {}

@@ -96,7 +96,6 @@ struct svg_ctx {
   DevBuf arena_buf;
   bool prof = false;
   bool prof_detail = false;            // svg_prof_enable(ctx, 2): additionally one entry per call-site signature ("@kind|shape")
-  bool graph_mode = false;
   std::vector<ProfEntry> prof_entries;
   std::unordered_map<std::string, ProfEntry> prof_shapes;
   std::vector<hipEvent_t> ev_pool;

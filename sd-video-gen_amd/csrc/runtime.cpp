@@ -189,12 +189,6 @@ const char* svg_last_error(svg_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err
 
 int64_t svg_workspace_bytes(svg_ctx* ctx) { return ctx ? ctx->arena_buf.bytes : 0; }
 
-int svg_set_graph_mode(svg_ctx* ctx, int on) {
-  if (!ctx) return -1;
-  ctx->graph_mode = on != 0;
-  return 0;
-}
-
 int svg_prof_enable(svg_ctx* ctx, int on) {
   if (!ctx) return -1;
   ctx->prof = on != 0;
