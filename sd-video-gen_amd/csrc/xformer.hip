@@ -104,6 +104,132 @@ __global__ void __launch_bounds__(512) xf_gemm_kernel(const float* __restrict__ 
   }
 }
 
+// ---- column-block form: a workgroup = 4 waves = 64 output columns (one 16-column tile per wave) over a K range; the X rows of
+// a 32-wide K step are staged ONCE per workgroup in LDS (LDS-direct loads, swizzled 128-byte rows) and shared by the four
+// waves — the form above re-reads all of X from L2 in every 16-column workgroup, which bounds it at M >= 48.  W streams
+// straight to registers, four steps ahead (8 KiB per wave in flight).  lane (l15, lq) holds k = k0 + 4 lq .. + 3 and
+// k0 + 16 + 4 lq .. + 3 of its W row (the two float4 a row's 128-byte line is read with); X uses the same k order: LDS chunks lq
+// and lq + 4, conflict free under the row & 7 swizzle.  Always split-K capable: partial sums to slabs, fixed-order finish.
+// NST LDS stages: the X rows of step s + NST - 1 and the W fragments of step s + NST - 1 are requested during step s, so NST - 1
+// steps of both streams are in flight (vmcnt retires in order: whatever is older than the stage awaited is complete, so the
+// W prefetch can only be as deep as the X staging).  Small M (the HBM-bound regime) affords five 8-KiB stages.
+template <int MT, int NST>
+__global__ void __launch_bounds__(256) xf_gemm2_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, const float* __restrict__ residual,
+                                                        float* __restrict__ Y, int M, int N, int K, int act_in, int ksplit) {
+  extern __shared__ __attribute__((aligned(16))) char xs[];   // NST stages x (MT * 16 rows) x 128 B, then a 4-KiB sink
+  constexpr int STAGE = MT * 16 * 128;
+  constexpr int D = NST - 1;                                // prefetch distance in K steps
+  constexpr int NPIECE = MT * 2;                            // 8-row pieces of a stage
+  constexpr int NPW = (NPIECE + 3) / 4;                     // DMA instructions per wave and stage (padded with sink writes)
+  constexpr int VMC = (D - 1) * (NPW + 2) + 2;              // operations younger than the DMAs of stage s + 1 at the end of step s
+  static_assert(VMC <= 63, "vmcnt immediate");
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wid);
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int n0 = blockIdx.x * 64 + wave_u * 16;
+  const int kz = blockIdx.y;
+  const int steps_total = (K + 31) / 32;
+  const int per = (steps_total + ksplit - 1) / ksplit;
+  const int st0 = kz * per, st1 = min(steps_total, st0 + per);
+  const int n = n0 + l15;
+  const bool n_ok = n < N;
+  const float* wrow = W + (int64_t)(n_ok ? n : 0) * K + 4 * lq;
+  const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // X staging: a wave instruction fills 8 LDS rows (64 lanes x 16 B); lane (r = lane >> 3, p = lane & 7) fetches chunk p ^ (row & 7)
+  const __amdgpu_buffer_rsrc_t srdX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (unsigned)((int64_t)M * K * 4), 0x00020000);
+  constexpr unsigned INVALID = 0x80000000u;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  auto stage_x = [&](int step) {                            // always NPW instructions per wave (the counted wait relies on it)
+    const int buf = (step - st0) % NST;
+    const int k0 = step * 32;
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int piece = i * 4 + wave_u;
+      const int row = piece * 8 + (lane >> 3);
+      const int ch = (lane & 7) ^ (row & 7);
+      const bool ok = step < st1 && piece < NPIECE && row < M && k0 + ch * 4 < K;        // K % 4 == 0
+      const unsigned voff = ok ? (unsigned)(((int64_t)row * K + k0 + ch * 4) * 4) : INVALID;
+      char* dst = piece < NPIECE ? xs + buf * STAGE + piece * 1024 : xs + NST * STAGE + wave_u * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdX, (lds_ptr_t)dst, 16, voff, 0, 0, 0);
+    }
+  };
+  f32x4 wq[D][2];
+  auto load_w = [&](int step, f32x4 (&w)[2]) {              // always two loads (out of range: row 0 / masked to zero below)
+    const int k = step * 32 + 4 * lq;
+    const bool in = step < st1;
+    const f32x4 a = *(const f32x4*)(wrow + (in && k < K ? step * 32 : 0));
+    const f32x4 b = *(const f32x4*)(wrow + (in && k + 16 < K ? step * 32 + 16 : 0));
+    w[0] = (n_ok && in && k < K) ? a : zero;
+    w[1] = (n_ok && in && k + 16 < K) ? b : zero;
+  };
+  f32x4 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = zero;
+
+  if (st0 < st1) {
+    // prologue: stages and W fragments of steps st0 .. st0 + D - 1, in the steady-state issue order
+#pragma unroll
+    for (int d = 0; d < D; ++d) { stage_x(st0 + d); load_w(st0 + d, wq[d]); }
+    if (D > 1) {
+      // stage st0 must have landed: younger than its DMAs are load_w(st0) and the (D - 1) later stage / W pairs
+      constexpr int C0 = (D - 1) * (NPW + 2) + 2;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C0) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    const int xoff0 = l15 * 128 + ((lq ^ (l15 & 7)) << 4), xoff1 = l15 * 128 + (((lq + 4) ^ (l15 & 7)) << 4);
+    for (int st = st0; st < st1; st += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int step = st + d;
+        if (step < st1) {
+          const int buf = (step - st0) % NST;
+          stage_x(step + D);                                 // into the stage last read in step - 1 (a barrier ago)
+          const f32x4 w0 = wq[d][0], w1 = wq[d][1];
+          load_w(step + D, wq[d]);
+          const char* xb = xs + buf * STAGE;
+#pragma unroll
+          for (int t = 0; t < MT; ++t) {
+            f32x4 x0 = *(const f32x4*)(xb + t * 2048 + xoff0), x1 = *(const f32x4*)(xb + t * 2048 + xoff1);
+            if (act_in == 1) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { x0[j] = fmaxf(x0[j], 0.f); x1[j] = fmaxf(x1[j], 0.f); }
+            } else if (act_in == 2) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { x0[j] = x0[j] / (1.f + __expf(-1.702f * x0[j])); x1[j] = x1[j] / (1.f + __expf(-1.702f * x1[j])); }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[j], x0[j], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[j], x1[j], acc[t], 0, 0, 0);
+          }
+          // stage step + 1 has to have landed (everything older with it), and every wave has to be done reading this stage
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMC) : "memory");
+          __syncthreads();
+        }
+      }
+    }
+  }
+  // D layout: col j = lane&15 -> m, row i = (lane>>4)*4 + reg -> n
+  float* out = Y + (ksplit > 1 ? (int64_t)kz * M * N : 0);
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int m = t * 16 + l15;
+    const int nn = n0 + 4 * lq;
+    if (m < M && nn < N) {
+      f32x4 v = acc[t];
+      if (ksplit == 1) {
+        if (bias) v += *(const f32x4*)(bias + nn);
+        if (residual) v += *(const f32x4*)(residual + (int64_t)m * N + nn);
+      }
+      *(f32x4*)(out + (int64_t)m * N + nn) = v;
+    }
+  }
+}
+
 // Y[m][n] = sum_z slabs[z][m][n] + bias[n], z ascending (deterministic)
 __global__ void __launch_bounds__(256) xf_splitk_finish_kernel(const float* __restrict__ slabs, const float* __restrict__ bias,
                                                                 const float* __restrict__ residual, float* __restrict__ Y, int64_t MN,
@@ -282,10 +408,67 @@ static void xf_launch(dim3 grid, hipStream_t s, const float* X, const float* W, 
   hipLaunchKernelGGL((xf_gemm_kernel<MT>), grid, dim3(512), 0, s, X, W, bias, residual, Y, M, N, K, act_in, ksplit);
 }
 
+template <int MT>
+static void xf2_launch(dim3 grid, hipStream_t s, const float* X, const float* W, const float* bias, const float* residual, float* Y,
+                       int M, int N, int K, int act_in, int ksplit) {
+  constexpr int NST = MT <= 4 ? 5 : (MT <= 8 ? 3 : 2);
+  constexpr int smem = NST * MT * 16 * 128 + 4096;
+  static bool attr[16] = {};                                // per device (smem <= 86 KB needs the opt-in above 64 KB)
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+  if (smem > 65536 && dev < 16 && !attr[dev]) {
+    HIP_OK(hipFuncSetAttribute((const void*)xf_gemm2_kernel<MT, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr[dev] = true;
+  }
+  hipLaunchKernelGGL((xf_gemm2_kernel<MT, NST>), grid, dim3(256), smem, s, X, W, bias, residual, Y, M, N, K, act_in, ksplit);
+}
+
+// column-block form (X shared through LDS): grid (N / 64, ksplit)
+static void xf_gemm_v2(svg_ctx* ctx, const float* X, const float* W, const float* bias, float* Y, int M, int N, int K, int act_in,
+                       hipStream_t s, const float* residual) {
+  const int nb = cdiv(N, 64);
+  const int steps = cdiv(K, 32);
+  // enough workgroups for two per CU while each keeps >= 8 steps (two rounds of its 4-deep pipeline)
+  int ksplit = 1;
+  while (nb * ksplit < 512 && steps / (ksplit * 2) >= 8 && ksplit < 16) ksplit *= 2;
+  static const int ks_env = getenv("SVG_XF_KSPLIT") ? atoi(getenv("SVG_XF_KSPLIT")) : 0;
+  if (ks_env > 0) ksplit = ks_env;
+  float* slabs = nullptr;
+  if (ksplit > 1) { ctx->arena.push(); slabs = ctx->arena.get<float>((int64_t)ksplit * M * N); ctx->arena.pop(); }
+  if (!SVG_LAUNCHING(ctx)) return;
+  char tag[64];
+  snprintf(tag, sizeof(tag), "v2_M%d_N%d_K%d_ks%d", M, N, K, ksplit);
+  ProfScope ps(ctx, PK_XF_GEMM, s, 2.0 * M * (double)N * K, 4.0 * ((double)N * K + (double)M * K + (double)M * N), tag);
+  dim3 grid(nb, ksplit);
+  float* dst = ksplit > 1 ? slabs : Y;
+  const int mt = cdiv(M, 16);
+  if (mt <= 1) xf2_launch<1>(grid, s, X, W, bias, residual, dst, M, N, K, act_in, ksplit);
+  else if (mt <= 2) xf2_launch<2>(grid, s, X, W, bias, residual, dst, M, N, K, act_in, ksplit);
+  else if (mt <= 3) xf2_launch<3>(grid, s, X, W, bias, residual, dst, M, N, K, act_in, ksplit);
+  else if (mt <= 4) xf2_launch<4>(grid, s, X, W, bias, residual, dst, M, N, K, act_in, ksplit);
+  else if (mt <= 6) xf2_launch<6>(grid, s, X, W, bias, residual, dst, M, N, K, act_in, ksplit);
+  else if (mt <= 8) xf2_launch<8>(grid, s, X, W, bias, residual, dst, M, N, K, act_in, ksplit);
+  else if (mt <= 11) xf2_launch<11>(grid, s, X, W, bias, residual, dst, M, N, K, act_in, ksplit);
+  else if (mt <= 16) xf2_launch<16>(grid, s, X, W, bias, residual, dst, M, N, K, act_in, ksplit);
+  else xf2_launch<21>(grid, s, X, W, bias, residual, dst, M, N, K, act_in, ksplit);
+  check_launch("xf_gemm2");
+  if (ksplit > 1) {
+    const int64_t MN = (int64_t)M * N;
+    hipLaunchKernelGGL(xf_splitk_finish_kernel, dim3((unsigned)std::min<int64_t>((MN / 4 + 255) / 256, 1024)), dim3(256), 0, s, slabs, bias, residual,
+                       Y, MN, N, ksplit);
+    check_launch("xf_splitk_finish");
+  }
+}
+
 void xf_gemm(svg_ctx* ctx, const float* X, const float* W, const float* bias, float* Y, int M, int N, int K, int act_in,
              hipStream_t s, const float* residual) {
   SVG_CHECK(K % 8 == 0 && N % 4 == 0, "xf_gemm: K=%d must be a multiple of 8 and N=%d of 4", K, N);
   SVG_CHECK(M >= 1 && M <= 16 * XF_MAXMT, "xf_gemm: M=%d must be in 1..%d", M, 16 * XF_MAXMT);
+  // Two forms (same-box kbench, profiles/README.md): up to 47 rows the 16-column form below (every wave streams its own K slice,
+  // X straight from L2: 1.6-3.1 TB/s at 6 rows) is ahead; from 48 rows on X re-reads bound it and the column-block form (X
+  // shared through LDS) wins: 71 vs 53 TFLOP/s at 168 x 6144 x 2048.  SVG_XF_V forces one.
+  static const int ver = getenv("SVG_XF_V") ? atoi(getenv("SVG_XF_V")) : 0;
+  if (ver == 2 || (ver == 0 && M >= 48)) { xf_gemm_v2(ctx, X, W, bias, Y, M, N, K, act_in, s, residual); return; }
   const int nb = cdiv(N, 16);
   // K split: enough workgroups to put >= 2 on every CU while every wave keeps >= 2 steps of 32 (its load pipeline)
   const int steps = cdiv(K, 32);
