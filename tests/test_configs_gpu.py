@@ -174,6 +174,40 @@ def test_config4_guidance_7p5_full_size(ctx, nets):
     margin("cfg4 3 DDIM steps at guidance 7.5", rel_l2(got, want), 1.5e-2)                       # measured 5.5e-3
 
 
+def test_config4_text_loop_with_prompt_and_guidance(ctx, nets):
+    """configs[4] end to end at full size: 11_27_ucf_text_final (text-conditioned Transformer d = 2432, F = 128), the CLIP text
+    encoder on the class prompt, guidance_scale 7.5 (evaluation/predict_fvd2_denoise.py:203,227-229): two generated frames with
+    two DDIM steps each against the loop oracle driven with the same CLIP oracle embeddings."""
+    from oracle import clip_oracle as CO, loop_oracle
+    from sd_video_gen_amd import config as svg_config, sd_layout
+    from sd_video_gen_amd.predict import sample_clips, bouncing_ball_clips
+    from sd_video_gen_amd.sd_utils import SDUtils
+    from sd_video_gen_amd.transformer_text import Transformer as TextTransformer
+    usd, vsd = nets
+    svg_config.set_args(["--dataset", "ucf", "--config", "11_27_ucf_text_final", "--denoise", "1"])
+    cfg = svg_config.load_config("11_27_ucf_text_final")
+    sdu = SDUtils(weights={"vae": vsd, "unet": usd, "text_encoder": "synthetic"}, verbose=False, seed=2)
+    torch.manual_seed(9)
+    m = TextTransformer(dim_model=cfg.DIM_MODEL[0], num_heads=cfg.NUM_HEADS[0], num_encoder_layers=cfg.NUM_ENCODER_LAYERS[0],
+                        num_decoder_layers=cfg.NUM_DECODER_LAYERS[0]).eval()
+    names = ["WallPushups"]
+    prompt = ["a person doing WallPushups"]
+    emb = sdu.encode_text(prompt)                                   # (2,77,768) = [uncond(''); text(prompt)] from the HIP CLIP tower
+    csd = {k: v.cpu() for k, v in sd_layout.seeded_weights(sd_layout.clip_text_shapes(), 2 + 3).items()}
+    emb_ref = CO.encode_text(csd, prompt)
+    margin("cfg4 CLIP embeddings of the prompt", rel_l2(emb.cpu(), emb_ref), 2e-5)
+    clip = bouncing_ball_clips(1, cfg.FRAME_SIZE, 5, seed=GG.CLIP_SEED)
+    S, N = 48, 2
+    lat = sample_clips(m, sdu, clip.cuda(), N, denoise=True, start_step=S, seeds=[GG.NOISE_SEED], text_embeddings=emb,
+                       guidance_scale=7.5, cls_list=names, cpu_noise=True).cpu()
+    noise = GG.loop_noise(GG.NOISE_SEED, cfg.FRAME_SIZE, N, S)
+    ref = loop_oracle.sample_clip({k: v for k, v in m.state_dict().items()}, cfg.NUM_HEADS[0], vsd, clip[0], N, noise, denoise=True, start_step=S,
+                                  unet_sd=usd, text_emb=emb_ref, txt=m.encode_classes(names), guidance_scale=7.5)
+    assert lat.shape == ref.shape == (1, 4 + N, 1024)
+    margin("cfg4 conditioning latents (VAE encode @128)", rel_l2(lat[:, :4], ref[:, :4]), 1.5e-2)
+    margin("cfg4 text + guidance 7.5 loop, generated frames", rel_l2(lat[:, 4:], ref[:, 4:]), 1.5e-1)
+
+
 def test_config4_text_transformer_full_size(ctx):
     """configs[4]: 11_27_ucf_text_final — d = 2048 + 384 = 2432 (head dim 304), D_lat 1024, 4 + 8 layers, 0.6 G parameters."""
     from sd_video_gen_amd import config as svg_config

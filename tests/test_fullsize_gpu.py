@@ -95,6 +95,23 @@ def test_vae_full_size_128(ctx, full_vae):
     margin("full-size VAE decoder share of pixels off by > 2 LSB", 1.0 - (d <= 2).float().mean(), 0.03, unit="fraction")
 
 
+def test_vae_full_size_512(ctx, full_vae):
+    """the denoise resolution itself: one 512 x 512 image through the full-size encoder (1117 GFLOP) and decoder (2515 GFLOP)
+    against the fp32 oracle (about 2 s of CPU)."""
+    g = torch.Generator().manual_seed(12)
+    img = torch.randint(0, 256, (1, 512, 512, 3), dtype=torch.uint8, generator=g)
+    eps = torch.randn(1, 4, 64, 64, generator=g)
+    z, mom = ctx.vae_encode(img.cuda(), eps=eps.cuda(), return_moments=True)
+    x = 2 * ((img / 255.0).float().permute(0, 3, 1, 2) - 0.5)
+    margin("full-size VAE encoder moments @512", rel_l2(mom.cpu(), SO.vae_encode_moments(full_vae, x)), 4.5e-2)
+    zz = torch.randn(1, 4, 64, 64, generator=g) * 0.4
+    out, fl = ctx.vae_decode(zz.cuda(), return_float=True)
+    ref_img, ref_fl = SO.decode_img_latents(full_vae, zz, return_float=True)
+    margin("full-size VAE decoder float output @512", rel_l2(fl.cpu(), ref_fl), 6e-2)
+    d = (out.cpu().int() - ref_img.int()).abs().float()
+    margin("full-size VAE decoder @512 uint8 frame mean |diff|", d.mean(), 1.5, unit="LSB")
+
+
 def test_vae_512_properties(ctx, full_vae):
     """512x512 (the denoise resolution): finite, deterministic, and the fused resize == explicit resize."""
     g = torch.Generator().manual_seed(3)
