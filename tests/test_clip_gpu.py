@@ -36,7 +36,7 @@ def test_clip_text_forward(ctx, cfg, B, T):
     out = ctx.clip_text_forward(ids, cfg["d_model"]).cpu()
     assert out.shape == (B, T, cfg["d_model"])
     margin("CLIP text tower %s B=%d T=%d (f32 MFMA vs fp32 oracle)" % ("ViT-L/14" if cfg is CO.SD_CLIP else "tiny", B, T),
-           rel_l2(out, CO.forward(sd, ids, cfg)), 2e-5)
+           rel_l2(out, CO.forward(sd, ids, cfg)), 2.2e-6)
     # causal: a token's state does not depend on later tokens
     ids2 = ids.clone()
     ids2[:, T // 2:] = (ids2[:, T // 2:] + 1) % cfg["vocab"]
@@ -71,10 +71,10 @@ def test_encode_text_matches_the_reference_algorithm(tmp_path, monkeypatch):
     prompts = ["a person doing WallPushups", "PlayingGuitar"]
     emb = sdu.encode_text(prompts)
     assert emb.shape == (4, 77, 768) and emb.is_cuda
-    margin("encode_text(2 prompts) vs oracle", rel_l2(emb.cpu(), CO.encode_text(csd, prompts)), 2e-5)
+    margin("encode_text(2 prompts) vs oracle", rel_l2(emb.cpu(), CO.encode_text(csd, prompts)), 2.1e-6)
     e0 = sdu.encode_text([""])                                                   # prediction/predict.py:148
     assert e0.shape == (2, 77, 768) and torch.equal(e0[0], e0[1])                # [uncond(''); text('')]
-    margin("encode_text(['']) vs oracle", rel_l2(e0.cpu(), CO.encode_text(csd, [""])), 2e-5)
+    margin("encode_text(['']) vs oracle", rel_l2(e0.cpu(), CO.encode_text(csd, [""])), 2.1e-6)
     del sdu
     # local directory, transformers 4.x naming ("text_model." prefix + the position_ids buffer), tiny architecture
     d = tmp_path / "sd"
@@ -95,4 +95,4 @@ def test_encode_text_matches_the_reference_algorithm(tmp_path, monkeypatch):
     assert s2.clip_source.startswith("local:") and s2.clip_arch["layers"] == 2
     e = s2.encode_text(["Archery"])
     ids = CO.stand_in_ids(["Archery"], 77, 1000)
-    margin("encode_text from a local text_encoder/ directory", rel_l2(e[1:].cpu(), CO.forward(tsd, ids, tcfg)), 2e-5)
+    margin("encode_text from a local text_encoder/ directory", rel_l2(e[1:].cpu(), CO.forward(tsd, ids, tcfg)), 1.7e-6)

@@ -195,7 +195,7 @@ def test_config4_text_loop_with_prompt_and_guidance(ctx, nets):
     emb = sdu.encode_text(prompt)                                   # (2,77,768) = [uncond(''); text(prompt)] from the HIP CLIP tower
     csd = {k: v.cpu() for k, v in sd_layout.seeded_weights(sd_layout.clip_text_shapes(), 2 + 3).items()}
     emb_ref = CO.encode_text(csd, prompt)
-    margin("cfg4 CLIP embeddings of the prompt", rel_l2(emb.cpu(), emb_ref), 2e-5)
+    margin("cfg4 CLIP embeddings of the prompt", rel_l2(emb.cpu(), emb_ref), 2.1e-6)
     clip = bouncing_ball_clips(1, cfg.FRAME_SIZE, 5, seed=GG.CLIP_SEED)
     S, N = 48, 2
     lat = sample_clips(m, sdu, clip.cuda(), N, denoise=True, start_step=S, seeds=[GG.NOISE_SEED], text_embeddings=emb,
@@ -205,7 +205,7 @@ def test_config4_text_loop_with_prompt_and_guidance(ctx, nets):
                                   unet_sd=usd, text_emb=emb_ref, txt=m.encode_classes(names), guidance_scale=7.5)
     assert lat.shape == ref.shape == (1, 4 + N, 1024)
     margin("cfg4 conditioning latents (VAE encode @128)", rel_l2(lat[:, :4], ref[:, :4]), 1.5e-2)
-    margin("cfg4 text + guidance 7.5 loop, generated frames", rel_l2(lat[:, 4:], ref[:, 4:]), 1.5e-1)
+    margin("cfg4 text + guidance 7.5 loop, generated frames", rel_l2(lat[:, 4:], ref[:, 4:]), 1.0e-1)
 
 
 def test_config4_text_transformer_full_size(ctx):
@@ -225,6 +225,6 @@ def test_config4_text_transformer_full_size(ctx):
     out = m(X.cuda(), names, X.cuda(), m.get_tgt_mask(6).cuda(), pe_row=torch.zeros(2, dtype=torch.int32)).cpu()
     for b in range(2):
         ref = TO.forward(sd, X[b:b + 1], X[b:b + 1], 8, TO.get_tgt_mask(6), txt=txt[b:b + 1])
-        margin("cfg4 text Transformer d=2432 forward, clip %d" % b, rel_l2(out[:, b:b + 1], ref), 8e-6)
+        margin("cfg4 text Transformer d=2432 forward, clip %d" % b, rel_l2(out[:, b:b + 1], ref), 4.5e-6)
     p = predict_text(m, X[:1].cuda(), names[:1]).cpu()
-    margin("cfg4 predict_text (D_lat,)", rel_l2(p, TO.predict(sd, X[:1], 8, txt=txt[:1])), 8e-6)
+    margin("cfg4 predict_text (D_lat,)", rel_l2(p, TO.predict(sd, X[:1], 8, txt=txt[:1])), 3.8e-6)

@@ -113,6 +113,6 @@ def test_unet_step_fp8_full_size(ctx):
     ref = torch.cat([SO.unet_forward(usd, x[b:b + 1], float(t[b]), cc[b:b + 1]) for b in range(2)])
     e16 = rel_l2(outs[0], ref)
     margin("full-size UNet call, bf16 (same inputs)", e16, 2.5e-2)
-    margin("full-size UNet call with fp8=1 vs the fp32 oracle", rel_l2(outs[1], ref), 9e-2)
-    margin("full-size UNet call, fp8=1 vs bf16 path", rel_l2(outs[1], outs[0]), 9e-2)
+    margin("full-size UNet call with fp8=1 vs the fp32 oracle", rel_l2(outs[1], ref), 7.4e-2)
+    margin("full-size UNet call, fp8=1 vs bf16 path", rel_l2(outs[1], outs[0]), 7.5e-2)
     assert not torch.equal(outs[0], outs[1])                    # the fp8 projections really ran
