@@ -27,13 +27,25 @@ namespace {
 constexpr int KVT = 64;     // keys per tile
 constexpr int VROW = 136;   // bytes per V^T LDS row (64 kv * 2 B + 8)
 
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// max over the lane pair (l, l^32) without the LDS crossbar: v_permlane32_swap exchanges the upper half of one register
+// with the lower half of the other, leaving {lo,lo} and {hi,hi}
+__device__ __forceinline__ float max_xor32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 // BC ("bias column", needs >= 3 spare columns in the padded contraction, i.e. d = 40 or 8): the softmax runs VALU-bound
 // (per tile and query block: 32 exp2 + 32 fma + ~25 max + 16 cvt against 14 MFMAs), so the scale-and-shift fma is moved
 // onto the matrix pipe: Q is pre-multiplied by scale*log2(e), the K pad columns d..d+2 hold 1.0 and the matching Q pad
 // elements hold -m (running shift) split into three bf16 pieces (24 bits, exact in the f32 accumulate), so the MFMA
 // delivers S*c - m ready for exp2.  The shift is lazy: it moves only when a score exceeds it by more than 2^TAU (first
 // tile: always), which is exact for the result (softmax is shift invariant; P keeps bf16's relative precision).
-template <int D, int QB, int NSTW, bool BC>  // head dim (multiple of 8); 32-query blocks per wave; LDS stages wanted
+template <int D, int QB, int NSTW, bool BC, bool HV = false>  // head dim (multiple of 8); 32-query blocks per wave; LDS stages wanted; HV: V^T fragments read ahead of the softmax
 __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
   constexpr int KS = (D + 15) / 16;           // k-steps of the QK^T contraction
   constexpr int DK = KS * 16;
@@ -181,6 +193,21 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
         S1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[qb][ks], S1[qb], 0, 0, 0);
       }
     }
+    // ---- HV: the V^T fragments of this tile do not depend on the softmax — issue their LDS reads now, so that the
+    //      latency runs under the QK^T MFMAs and the max / exp2 phase instead of in front of every PV MFMA
+    uint4 vfr[HV ? 4 * DVT : 1];
+    if (HV) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int dt = 0; dt < DVT; ++dt) {
+          const char* p = sV + (32 * dt + r) * VROW + (16 * i + 4 * h) * 2;
+          const uint2 lo = *(const uint2*)p;
+          const uint2 hi = *(const uint2*)(p + 16);
+          vfr[i * DVT + dt] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // ---- mask keys past Skv (last tile only) ----------------------------------------------------
     if (t * KVT + KVT > a.Skv) {
       const int base = t * KVT + 4 * h;
@@ -199,11 +226,11 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
     for (int qb = 0; qb < QB; ++qb) {
       float v = fmaxf(S0[qb][0], S1[qb][0]);
 #pragma unroll
-      for (int j = 1; j < 16; ++j) v = fmaxf(v, fmaxf(S0[qb][j], S1[qb][j]));
+      for (int j = 1; j < 16; ++j) v = max3(v, S0[qb][j], S1[qb][j]);
       mx[qb] = v;
     }
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) mx[qb] = fmaxf(mx[qb], __shfl_xor(mx[qb], 32));
+    for (int qb = 0; qb < QB; ++qb) mx[qb] = max_xor32(mx[qb]);
     if (BC) {
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
@@ -282,10 +309,15 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
         const int kvoff = (32 * st + 16 * s2 + 4 * h) * 2;   // bytes
 #pragma unroll
         for (int dt = 0; dt < DVT; ++dt) {
-          const char* p = sV + (32 * dt + r) * VROW + kvoff;
-          uint2 lo = *(const uint2*)p;
-          uint2 hi = *(const uint2*)(p + 16);
-          uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          uint4 v;
+          if (HV) {
+            v = vfr[(2 * st + s2) * DVT + dt];
+          } else {
+            const char* p = sV + (32 * dt + r) * VROW + kvoff;
+            const uint2 lo = *(const uint2*)p;
+            const uint2 hi = *(const uint2*)(p + 16);
+            v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          }
 #pragma unroll
           for (int qb = 0; qb < QB; ++qb)
             O[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8*)&v, pf[qb], O[qb][dt], 0, 0, 0);
@@ -336,11 +368,13 @@ void launch(const AttnArgs& a, hipStream_t s) {
   static const int nst_env = getenv("SVG_ATTN_NST") ? atoi(getenv("SVG_ATTN_NST")) : 1;   // same-box A/B: one stage + two barriers is 1-2 % faster than two stages + one barrier
   static const int qb_env = getenv("SVG_ATTN_QB") ? atoi(getenv("SVG_ATTN_QB")) : 2;
   static const int bc_env = getenv("SVG_ATTN_BC") ? atoi(getenv("SVG_ATTN_BC")) : 1;
+  static const int hv_env = getenv("SVG_ATTN_HV") ? atoi(getenv("SVG_ATTN_HV")) : 1;   // same-box A/B at 28 x 8 x 4096^2 x 40: 1.006 vs 1.026 ms
   constexpr int QB = (D <= 64) ? 2 : 1;
   constexpr bool CAN_BC = (D % 16) == 8;        // three spare pad columns in lane-half 1 of the last k-step (d = 8, 40)
   if (QB == 2 && qb_env == 2 && a.Sq >= 512) {
     dim3 grid(cdiv(a.Sq, 256) * a.heads * a.B);
-    if (CAN_BC && bc_env) hipLaunchKernelGGL((attn_kernel<D, QB, 1, CAN_BC>), grid, dim3(256), 0, s, a);
+    if (CAN_BC && bc_env && hv_env) hipLaunchKernelGGL((attn_kernel<D, QB, 1, CAN_BC, true>), grid, dim3(256), 0, s, a);
+    else if (CAN_BC && bc_env) hipLaunchKernelGGL((attn_kernel<D, QB, 1, CAN_BC>), grid, dim3(256), 0, s, a);
     else if (nst_env == 2) hipLaunchKernelGGL((attn_kernel<D, QB, 2, false>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((attn_kernel<D, QB, 1, false>), grid, dim3(256), 0, s, a);
   } else {
