@@ -92,6 +92,33 @@ int svg_transformer_forward(svg_ctx* ctx, const float* src, const float* tgt, in
 int svg_transformer_forward_text(svg_ctx* ctx, const float* src, const float* tgt, const float* text, int B, int Ts,
                                  int Tt, const float* mask, const int32_t* pe_row, float* out, void* stream);
 
+/* ---- latent Transformer: training step ------------------------------------------------------- */
+/* Replaces the body of trainers/trainer.py:111-190 (train_loop: forward in train mode, criterion, loss.backward(),
+ * opt.step()) and :192-260 (validation_loop: the same loss in eval mode) for the latent Transformer; the Stable
+ * Diffusion side is frozen there too (encode_batch = svg_vae_encode).  f32 throughout like the reference trainer.
+ * criterion() of trainers/trainer.py:65-109 is  w_mse*MSE + w_l1*L1 + w_gdl*GDL(alpha) + w_contrastive*BiPatchNCE(temperature)
+ * (models/contrastive_loss.py:7-60) on the last frames_to_predict positions; w_* = use_* x lambda_*. */
+typedef struct svg_train_cfg {
+  int frames_to_predict;          /* F: loss on pred[-F:] (trainer.py:145) */
+  int feat_h, feat_w;             /* FRAME_SIZE / 8: latent (4, feat_h, feat_w) */
+  float w_mse, w_l1, w_gdl, gdl_alpha, w_contrastive, temperature;
+  float dropout_p;                /* nn.Transformer / PositionalEncoding dropout (train mode only) */
+  uint64_t seed;                  /* dropout masks are a pure function of (seed, site, element): pass a new seed every step */
+} svg_train_cfg;
+/* src (B,Ts,D_lat), tgt (B,Tt,D_lat), expected (B,Tt,D_lat) batch-first f32 (trainer.py:124-131: new_batch, new_batch[:,:-1],
+ * new_batch[:,1:]); text (B,text_dim) or NULL; mask (Tt,Tt) additive or NULL.  backward = 0: eval-mode forward + criterion only;
+ * 1: train mode (dropout) and the gradient of every parameter (overwriting the previous step's: zero_grad + backward).
+ * losses: host float[5] = {total, mse, l1, gdl, contrastive} (synchronises the stream), or NULL.  B <= 64, Ts, Tt <= 32. */
+int svg_transformer_loss(svg_ctx* ctx, const svg_train_cfg* cfg, const float* src, const float* tgt, const float* expected,
+                         const float* text, int B, int Ts, int Tt, const float* mask, int backward, float* losses, void* stream);
+/* torch.optim.Adam(lr, betas=(beta1, beta2), eps) step on the gradients of the last svg_transformer_loss(backward=1)
+ * (trainer.py:365: optim.Adam(model.parameters(), lr=lr) -> betas (0.9, 0.999), eps 1e-8, no weight decay). */
+int svg_transformer_adam_step(svg_ctx* ctx, float lr, float beta1, float beta2, float eps, void* stream);
+/* copies a parameter / its gradient / its Adam moments out (host or device `out`, numel floats; state_dict key names):
+ * what torch.save(model.state_dict()) at trainer.py:469-480 needs after steps taken in the library. */
+enum svg_tensor_kind { SVG_TENSOR_PARAM = 0, SVG_TENSOR_GRAD = 1, SVG_TENSOR_EXP_AVG = 2, SVG_TENSOR_EXP_AVG_SQ = 3 };
+int svg_transformer_tensor(svg_ctx* ctx, int kind, const char* name, float* out, int64_t numel, void* stream);
+
 /* ---- CLIP text encoder ---------------------------------------------------------------------- */
 /* input_ids (B,T) int32 token ids (T <= max_pos; the reference pads to 77); out (B,T,d_model) f32 = last_hidden_state.
  * Causal mask only (the reference passes no attention mask); f32 arithmetic like the reference. */
@@ -158,6 +185,8 @@ int svg_op_gemm_cat(svg_ctx* ctx, const uint16_t* A, const uint16_t* A2, const u
 int svg_op_ff_fused(svg_ctx* ctx, const uint16_t* x, const float* ln_gamma, const float* ln_beta, const float* w1,
                     const float* b1, const float* w2, const float* b2, const uint16_t* residual, uint16_t* out, int M,
                     int C, void* stream);
+/* dropout mask of one site of the training step: out[i] = 1/(1-p) (kept) or 0, i < n (tests regenerate the masks with it) */
+int svg_op_dropout_mask(svg_ctx* ctx, uint64_t seed, int site, float p, float* out, int64_t n, void* stream);
 /* MX block-scaled fp8 (BASELINE configs[4]): OCP e4m3 elements with one E8M0 scale per 32 consecutive K elements.
  * svg_op_quant_mx: x (rows,K) bf16 -> q (rows,K) e4m3 bytes, scales (rows,K/32) bytes; shared exponent floor(log2(amax)) - 8,
  * round to nearest even, saturating at +-448 (OCP MX v1.0).  K % 32 == 0. */

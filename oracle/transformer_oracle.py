@@ -48,8 +48,8 @@ def get_tgt_mask(size):
     return mask
 
 
-def _mha(sd, prefix, q_in, kv_in, num_heads, mask=None):
-    """nn.MultiheadAttention (seq-first): q_in (Tq,B,d), kv_in (Tk,B,d)."""
+def _mha(sd, prefix, q_in, kv_in, num_heads, mask=None, drop=None):
+    """nn.MultiheadAttention (seq-first): q_in (Tq,B,d), kv_in (Tk,B,d).  drop: train-mode dropout on the probabilities."""
     Tq, B, d = q_in.shape
     Tk = kv_in.shape[0]
     hd = d // num_heads
@@ -65,6 +65,8 @@ def _mha(sd, prefix, q_in, kv_in, num_heads, mask=None):
     if mask is not None:
         s = s + mask
     p = torch.softmax(s, dim=-1)
+    if drop is not None:
+        p = drop(p)
     o = torch.bmm(p, v).transpose(0, 1).reshape(Tq, B, d)
     return F.linear(o, sd[prefix + "out_proj.weight"], sd[prefix + "out_proj.bias"])
 
@@ -73,8 +75,10 @@ def _ln(sd, prefix, x):
     return F.layer_norm(x, (x.shape[-1],), sd[prefix + "weight"], sd[prefix + "bias"], LN_EPS)
 
 
-def _ffn(sd, prefix, x):
+def _ffn(sd, prefix, x, drop=None):
     h = F.relu(F.linear(x, sd[prefix + "linear1.weight"], sd[prefix + "linear1.bias"]))
+    if drop is not None:
+        h = drop(h)
     return F.linear(h, sd[prefix + "linear2.weight"], sd[prefix + "linear2.bias"])
 
 
@@ -85,8 +89,11 @@ def count_layers(sd, stem):
     return n
 
 
-def forward(sd, src, tgt, num_heads, tgt_mask=None, txt=None):
-    """transformer.py:47-68.  src/tgt (B,T,D_lat) -> (T_tgt,B,D_lat).  eval mode (no dropout).
+def forward(sd, src, tgt, num_heads, tgt_mask=None, txt=None, drop=None):
+    """transformer.py:47-68.  src/tgt (B,T,D_lat) -> (T_tgt,B,D_lat).  eval mode (no dropout) unless `drop` is given:
+    drop(x) is then applied at every dropout site of the train-mode module, in execution order — after the positional
+    encoding of src and of tgt (positional_encoding.py:35), and per nn.Transformer layer on the attention probabilities,
+    after each attention / feed-forward sublayer (dropout1/2/3) and inside the feed-forward (activation -> dropout -> linear2).
     With `txt` (B,384): the text-conditioned variant, models/transformer_text.py:71-111 — the embedding layer is
     `project_image_embedding` and every token is cat(proj(x), txt[b]) * sqrt(d), d = DIM_MODEL + 384 (:33-35,:82-92).
     (That file cannot be imported here — sentence_transformers is missing — so this branch is pinned through its exact
@@ -108,18 +115,21 @@ def forward(sd, src, tgt, num_heads, tgt_mask=None, txt=None):
     t = t + pe[: t.size(0)]
     s = s.permute(1, 0, 2)
     t = t.permute(1, 0, 2)
+    dr = drop if drop is not None else (lambda x: x)
+    s = dr(s)      # the sites see sequence-first tensors (the mask of an element does not depend on the layout)
+    t = dr(t)
     # encoder
     for i in range(count_layers(sd, "transformer.encoder.layers.")):
         p = "transformer.encoder.layers.%d." % i
-        s = _ln(sd, p + "norm1.", s + _mha(sd, p + "self_attn.", s, s, num_heads))
-        s = _ln(sd, p + "norm2.", s + _ffn(sd, p, s))
+        s = _ln(sd, p + "norm1.", s + dr(_mha(sd, p + "self_attn.", s, s, num_heads, drop=drop)))
+        s = _ln(sd, p + "norm2.", s + dr(_ffn(sd, p, s, drop)))
     mem = _ln(sd, "transformer.encoder.norm.", s)
     # decoder
     for i in range(count_layers(sd, "transformer.decoder.layers.")):
         p = "transformer.decoder.layers.%d." % i
-        t = _ln(sd, p + "norm1.", t + _mha(sd, p + "self_attn.", t, t, num_heads, tgt_mask))
-        t = _ln(sd, p + "norm2.", t + _mha(sd, p + "multihead_attn.", t, mem, num_heads))
-        t = _ln(sd, p + "norm3.", t + _ffn(sd, p, t))
+        t = _ln(sd, p + "norm1.", t + dr(_mha(sd, p + "self_attn.", t, t, num_heads, tgt_mask, drop=drop)))
+        t = _ln(sd, p + "norm2.", t + dr(_mha(sd, p + "multihead_attn.", t, mem, num_heads, drop=drop)))
+        t = _ln(sd, p + "norm3.", t + dr(_ffn(sd, p, t, drop)))
     t = _ln(sd, "transformer.decoder.norm.", t)
     return F.linear(t, sd["out.weight"], sd["out.bias"])
 

@@ -19,6 +19,17 @@ _lib = None
 
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
+SVG_TENSOR_PARAM, SVG_TENSOR_GRAD, SVG_TENSOR_EXP_AVG, SVG_TENSOR_EXP_AVG_SQ = 0, 1, 2, 3   # enum svg_tensor_kind
+
+
+class TrainCfg(C.Structure):
+    """struct svg_train_cfg (include/svg_hip.h)."""
+    _fields_ = [("frames_to_predict", _i), ("feat_h", _i), ("feat_w", _i),
+                ("w_mse", _f), ("w_l1", _f), ("w_gdl", _f), ("gdl_alpha", _f), ("w_contrastive", _f), ("temperature", _f),
+                ("dropout_p", _f), ("seed", C.c_uint64)]
+
+
+
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/svg_hip.h
 SIGNATURES = {
     "svg_create": [_i, C.POINTER(_vp)],
@@ -30,6 +41,9 @@ SIGNATURES = {
     "svg_finalize": [_vp, _i, C.POINTER(_i64)],
     "svg_transformer_forward": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "svg_transformer_forward_text": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "svg_transformer_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp],
+    "svg_transformer_adam_step": [_vp, _f, _f, _f, _f, _vp],
+    "svg_transformer_tensor": [_vp, _i, C.c_char_p, _vp, _i64, _vp],
     "svg_clip_text_forward": [_vp, _vp, _i, _i, _vp, _vp],
     "svg_vae_encode": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "svg_vae_decode": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp],
@@ -42,6 +56,7 @@ SIGNATURES = {
     "svg_op_conv3x3_gn": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, C.POINTER(_i), _vp],
     "svg_op_gemm_cat": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "svg_op_ff_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "svg_op_dropout_mask": [_vp, C.c_uint64, _i, _f, _vp, _i64, _vp],
     "svg_op_quant_mx": [_vp, _vp, _vp, _vp, _i64, _i, _vp],
     "svg_op_gemm_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "svg_op_groupnorm": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
@@ -181,6 +196,37 @@ class Context:
             return out
         self.check(self.lib.svg_transformer_forward(self.h, _ptr(src), _ptr(tgt_c), B, Ts, Tt, _ptr(mask), _ptr(pe_row),
                                                     _ptr(out), _stream()), "svg_transformer_forward")
+        return out
+
+    # ---- training step of the latent Transformer ---------------------------------------------------
+    def transformer_loss(self, cfg, src, tgt, expected, mask=None, text=None, backward=True):
+        """-> dict(total, mse, l1, gdl, contrastive).  backward=True: train mode, gradients left in the library."""
+        B, Ts, _ = src.shape
+        Tt = tgt.shape[1]
+        src = src.contiguous().float()
+        tgt = tgt.contiguous().float()
+        expected = expected.contiguous().float()
+        assert expected.shape == tgt.shape
+        mask = mask.contiguous().float() if mask is not None else None
+        text = text.to(device=src.device, dtype=torch.float32).contiguous() if text is not None else None
+        out = (_f * 5)()
+        self.check(self.lib.svg_transformer_loss(self.h, C.byref(cfg), _ptr(src), _ptr(tgt), _ptr(expected), _ptr(text), B, Ts, Tt,
+                                                 _ptr(mask), int(bool(backward)), out, _stream()), "svg_transformer_loss")
+        return dict(zip(("total", "mse", "l1", "gdl", "contrastive"), [float(v) for v in out]))
+
+    def transformer_adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8):
+        self.check(self.lib.svg_transformer_adam_step(self.h, lr, betas[0], betas[1], eps, _stream()), "svg_transformer_adam_step")
+
+    def transformer_tensor(self, name, like, kind=SVG_TENSOR_PARAM):
+        """Copy of parameter `name` (or its gradient / Adam moment) shaped like `like`, on the CPU."""
+        out = torch.empty(tuple(like.shape), dtype=torch.float32)
+        self.check(self.lib.svg_transformer_tensor(self.h, kind, name.encode(), out.data_ptr(), out.numel(), _stream()),
+                   "svg_transformer_tensor(%s)" % name)
+        return out
+
+    def dropout_mask(self, seed, site, p, n):
+        out = torch.empty(n, device="cuda", dtype=torch.float32)
+        self.check(self.lib.svg_op_dropout_mask(self.h, seed, site, p, _ptr(out), n, _stream()), "svg_op_dropout_mask")
         return out
 
     def clip_text_forward(self, input_ids, d_model=768):

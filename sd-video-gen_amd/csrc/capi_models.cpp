@@ -3,7 +3,7 @@
 #include "../../include/svg_hip.h"
 
 void destroy_models(svg_ctx* ctx) {
-  if (ctx->xf) { ctx->xf->ws.clear(); delete ctx->xf; ctx->xf = nullptr; }
+  if (ctx->xf) { xf_train_free(ctx->xf); ctx->xf->ws.clear(); delete ctx->xf; ctx->xf = nullptr; }
   if (ctx->vae) { ctx->vae->ws.clear(); delete ctx->vae; ctx->vae = nullptr; }
   if (ctx->unet) { ctx->unet->ws.clear(); delete ctx->unet; ctx->unet = nullptr; }
   if (ctx->clip) { ctx->clip->ws.clear(); delete ctx->clip; ctx->clip = nullptr; }
@@ -29,7 +29,7 @@ int svg_model_configure(svg_ctx* ctx, int model, const char* kv) {
     HIP_OK(hipDeviceSynchronize());
     for (void* p : ctx->owned[model]) hipFree(p);
     ctx->owned[model].clear();
-    if (model == SVG_TRANSFORMER) { ctx->xf->pe = nullptr; ctx->xf->iota = nullptr; }
+    if (model == SVG_TRANSFORMER) { xf_train_free(ctx->xf); ctx->xf->pe = nullptr; ctx->xf->iota = nullptr; }
     if (model == SVG_TRANSFORMER) ctx->xf->configure(kv);
     else if (model == SVG_VAE) ctx->vae->configure(kv);
     else if (model == SVG_CLIP_TEXT) ctx->clip->configure(kv);
@@ -44,7 +44,7 @@ int svg_load_weight(svg_ctx* ctx, int model, const char* name, const float* data
     WeightStore* ws = store_of(ctx, model, true);
     HIP_OK(hipSetDevice(ctx->device));
     ws->put(ctx, name, data, shape, ndim);
-    if (model == SVG_TRANSFORMER) ctx->xf->ready = false;
+    if (model == SVG_TRANSFORMER) { xf_train_free(ctx->xf); ctx->xf->ready = false; }   // new weights: a fresh optimizer state
     else if (model == SVG_VAE) ctx->vae->ready = false;
     else if (model == SVG_CLIP_TEXT) ctx->clip->ready = false;
     else ctx->unet->ready = false;

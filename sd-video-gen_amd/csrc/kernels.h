@@ -191,6 +191,36 @@ void xf_add_ln(const float* x, const float* r, const float* g, const float* b, f
 // text (B,d_txt) or null: channels >= d - d_txt of every token come from text[b] instead of emb (emb rows are d - d_txt wide)
 void xf_embed_post(const float* emb, const float* pe, const int32_t* pe_row, const float* text, int d_txt, float* y, int B, int T,
                    int d, float scale, hipStream_t s);
+// ---- training step of the latent Transformer (xf_train.hip) --------------------------------------------------------------
+// dropout site: mask element i of site `site` is a pure function of (seed, site, i); p = 0 disables it
+struct XfDrop { uint64_t seed; uint32_t site; float p; };
+struct XfAdamTensor { float* p; const float* g; float* m; float* v; };
+struct XfAdamChunk { int32_t ten; int32_t n; int64_t off; };
+void xf_drop_mask(const XfDrop d, float* out, int64_t n, hipStream_t s);
+// dW[N][K] (+)= dY[M][N]^T X[M][K]
+void xf_gemm_tn(const float* dY, int ldy, const float* X, int ldx, float* dW, int M, int N, int K, int accumulate, hipStream_t s);
+// out[M][K] = gate(dY[M][N] W[N][K]) + add;  gate (or null): x * (gate[i] > 0 ? gate_scale : 0);  slabs: xf_gemm_nn_slab_floats() floats
+int64_t xf_gemm_nn_slab_floats(int M, int N, int K);
+void xf_gemm_nn(const float* dY, int ldy, const float* W, float* slabs, float* out, int M, int N, int K, const float* gate, float gate_scale,
+                const float* add, hipStream_t s);
+void xf_colsum(const float* dY, int ldy, float* db, int M, int N, int accumulate, hipStream_t s);
+void xf_relu_drop(const float* h, float* r, int64_t n, const XfDrop d, hipStream_t s);
+void xf_add_ln_train(const float* x, const float* r, const XfDrop dr, const float* g, const float* b, float* y, float* xhat, float* rstd, int M,
+                     int d, float eps, hipStream_t s);
+void xf_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* g, float* dz, float* dz_drop, const XfDrop dr, float* dgamma,
+               float* dbeta, int M, int d, hipStream_t s);
+void xf_embed_post_train(const float* emb, const float* pe, const int32_t* pe_row, const float* text, int d_txt, float* y, int B, int T, int d,
+                         float scale, const XfDrop dr, hipStream_t s);
+void xf_embed_post_bwd(const float* dy, float* de, int B, int T, int d, int d_img, float scale, const XfDrop dr, hipStream_t s);
+void xf_attention_train(const float* q, int ldq, const float* k, const float* v, int ldk, const float* mask, float* o, float* P, int Tq, int Tk,
+                        int B, int heads, int hd, const XfDrop dr, hipStream_t s);
+void xf_attention_bwd(const float* dout, const float* q, int ldq, const float* k, const float* v, int ldk, const float* P, float* dq, int lddq,
+                      float* dk, float* dv, int lddk, int Tq, int Tk, int B, int heads, int hd, const XfDrop dr, hipStream_t s);
+// criterion of trainers/trainer.py:65-109 on pred (Tt,B,D) rows t >= t0 vs expected (B,Tt,D): losses[5] = {total, mse, l1, gdl, nce}, dpred
+void xf_criterion(const float* pred, const float* expected, float* dpred, float* part, float* part2, float* losses, int Tt, int B, int D, int t0,
+                  int fh, int fw, float w_mse, float w_l1, float w_gdl, float alpha, float w_nce, float temperature, hipStream_t s);
+void xf_adam(const XfAdamTensor* tens, const XfAdamChunk* chunks, int n_chunks, float lr, float beta1, float beta2, float eps, int step,
+             hipStream_t s);
 // seq-first MHA core on packed projections: q (Tq,B,ldq) k,v (Tk,B,ldk) -> o (Tq,B,d); mask (Tq,Tk) or null
 void xf_attention(const float* q, int ldq, const float* k, const float* v, int ldk, const float* mask,
                   float* o, int Tq, int Tk, int B, int heads, int hd, hipStream_t s);

@@ -51,6 +51,7 @@ struct XfModel {
   float* pe = nullptr;   // (64, d_model)
   int pe_d = 0;
   int32_t* iota = nullptr;
+  struct XfTrain* train = nullptr;   // gradients + Adam moments (xf_trainer.cpp); dropped whenever weights are (re)loaded
   void configure(const char* kv);
   void finalize(svg_ctx* ctx, int64_t* n_params);
   void forward(svg_ctx* ctx, const float* src, const float* tgt, int B, int Ts, int Tt, const float* mask,
@@ -138,6 +139,7 @@ struct ClipTextModel {
   void forward(svg_ctx* ctx, const int32_t* ids, int B, int T, float* out, hipStream_t s);
 };
 
+void xf_train_free(XfModel* m);
 void destroy_models(svg_ctx* ctx);
 
 // Request for the GroupNorm column sums of an output (GemmArgs::gn_part): the caller provides `buf` (gn_part_floats() floats, at

@@ -69,6 +69,9 @@ class Transformer(nn.Module):
         # since the last call: upload again unless the slot still holds THIS module's current parameters
         if self._ctx is ctx and ctx.owner(_lib.SVG_TRANSFORMER) is self and self._uploaded_version == self._weights_version():
             return ctx
+        if getattr(self, "_lib_ahead", False):
+            raise RuntimeError("this module's trained weights live in a library slot that was taken over (or its parameters were "
+                               "modified on the host) before pull_weights(); call state_dict()/pull_weights() after training steps")
         self._ctx = ctx
         ctx.configure(_lib.SVG_TRANSFORMER, d_lat=self.d_lat, d_model=self.dim_model, heads=self.num_heads,
                       enc_layers=self.num_encoder_layers, dec_layers=self.num_decoder_layers,
@@ -82,12 +85,55 @@ class Transformer(nn.Module):
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
         self._uploaded_version = None
+        self._lib_ahead = False
         return r
+
+    # ---- training step (trainers/trainer.py:111-190) ---------------------------------------------------
+    # The optimisation runs inside the library on the uploaded copy of the weights (gradients and Adam moments live there);
+    # the nn.Parameters of this module are refreshed from it by pull_weights(), which state_dict() does on its own.
+    def training_loss(self, cfg, new_batch, tgt_mask=None, text=None, backward=True):
+        """Loss of one trainer iteration on the encoded batch `new_batch` (B, T, D_lat): src = new_batch, tgt = new_batch[:, :-1],
+        expected = new_batch[:, 1:] (trainer.py:124-145).  backward=True runs in train mode (dropout_p of `cfg`) and leaves the
+        gradients in the library for adam_step(); False is the validation loss (eval mode).  -> dict of the loss terms."""
+        if not new_batch.is_cuda:
+            raise RuntimeError("the training step runs on the HIP library and needs CUDA tensors; there is no CPU fallback")
+        ctx = self._sync_weights()
+        y_input = new_batch[:, :-1]
+        if tgt_mask is None:
+            tgt_mask = self.get_tgt_mask(y_input.size(1)).to(new_batch.device)
+        return ctx.transformer_loss(cfg, new_batch, y_input, new_batch[:, 1:], tgt_mask, text, backward)
+
+    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8):
+        ctx = self._sync_weights()
+        ctx.transformer_adam_step(lr, betas, eps)
+        self._lib_ahead = True
+
+    def pull_weights(self):
+        """copies the library's (trained) weights back into this module's parameters"""
+        if not getattr(self, "_lib_ahead", False):
+            return
+        ctx = self._ctx
+        if ctx is None or ctx.owner(_lib.SVG_TRANSFORMER) is not self:
+            raise RuntimeError("the library slot that held this module's trained weights was taken by another model before pull_weights()")
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                p.copy_(ctx.transformer_tensor(name, p).to(p.device))
+        self._lib_ahead = False
+        self._uploaded_version = self._weights_version()      # the copy in the library IS these parameters: no re-upload
+
+    def grad_of(self, name):
+        """gradient of parameter `name` from the last training_loss(backward=True), as a CPU tensor"""
+        return self._ctx.transformer_tensor(name, dict(self.named_parameters())[name], _lib.SVG_TENSOR_GRAD)
+
+    def state_dict(self, *a, **k):
+        self.pull_weights()
+        return super().state_dict(*a, **k)
 
     # ---- forward (transformer.py:47-68) ---------------------------------------------------------------
     def forward(self, src, tgt, tgt_mask=None, src_pad_mask=None, tgt_pad_mask=None, pe_row=None):
         if self.training and self.positional_encoder.dropout_p > 0:
-            raise RuntimeError("the HIP path implements eval-mode sampling (dropout off); call model.eval()")
+            raise RuntimeError("forward() is the eval-mode sampling path (dropout off): call model.eval(); the train-mode forward "
+                               "is part of training_loss()")
         if src_pad_mask is not None or tgt_pad_mask is not None:
             raise NotImplementedError("key-padding masks are not on the sampling path (predict.py passes none)")
         if not src.is_cuda:

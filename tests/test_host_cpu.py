@@ -216,8 +216,14 @@ def test_cli_surface_parses_like_the_reference():
     from sd_video_gen_amd import config as svg_config
     import trainers.trainer as tr
     svg_config.set_args(["--dataset", "ball", "--config", "config_test", "--debug", "True"])
-    with pytest.raises(NotImplementedError):
-        tr.main()
+    assert callable(tr.main)
+    t = tr.Trainer(sd_utils=object())                       # the SD side is only needed once batches are encoded
+    assert t.SOS_token.shape == (1, 1, t.config.FRAME_SIZE ** 2 // 64 * 4) and float(t.SOS_token[0, 0, 0]) == 2.0
+    assert t.criterion(use_mse=True, use_L1=True) is None                              # trainer.py:107-109
+    c = t.criterion(use_mse=False, use_L1=True, use_gdl=True, lambda_gdl=0.5, alpha=1, use_contrastive=True, lambda_contrastive=0.025)
+    cfg = c.cfg(frames_to_predict=5, dropout_p=0.1, seed=7)
+    assert (cfg.w_mse, cfg.w_l1, cfg.w_gdl, cfg.gdl_alpha) == (0.0, 1.0, 0.5, 1.0) and abs(cfg.w_contrastive - 0.025) < 1e-9
+    assert cfg.feat_h == t.config.FRAME_SIZE // 8 and cfg.frames_to_predict == 5 and cfg.seed == 7
     import prediction.predict as pp
     assert callable(pp.predict) and callable(pp.main)
     import models.transformer, utils.config, utils.sd_utils   # noqa: F401,E401

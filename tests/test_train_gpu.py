@@ -1,0 +1,191 @@
+"""Training step of the latent Transformer (svg_transformer_loss / svg_transformer_adam_step) against the training oracle
+(oracle/train_oracle.py: torch autograd over the explicit-op forward, pinned to the live reference by tests/golden/train_tiny.pt)
+and against that fixture directly.  f32 on both sides: tolerances are accumulation-order noise."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from conftest import margin, rel_l2  # noqa: E402
+from oracle import train_oracle as TR  # noqa: E402
+from oracle import transformer_oracle as TO  # noqa: E402
+from sd_video_gen_amd import _lib  # noqa: E402
+from sd_video_gen_amd import config as svg_config  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(ROOT, "tests", "golden")
+GRAD_TOL = 1e-4
+
+
+def make_model(config_name, ctx, sd=None, seed=0, dropout_p=0.0, **kw):
+    from sd_video_gen_amd.transformer import Transformer
+    svg_config.set_args(["--dataset", "ball", "--config", config_name])
+    torch.manual_seed(seed)
+    m = Transformer(dropout_p=dropout_p, **kw).use_context(ctx)
+    if sd is not None:
+        m.load_state_dict(sd)
+    return m
+
+
+def cfg_of(F, feat, w, dropout_p=0.0, seed=0):
+    return _lib.TrainCfg(frames_to_predict=F, feat_h=feat, feat_w=feat, w_mse=w.get("w_mse", 0.0), w_l1=w.get("w_l1", 0.0), w_gdl=w.get("w_gdl", 0.0),
+                         gdl_alpha=float(w.get("alpha", 1)), w_contrastive=w.get("w_contrastive", 0.0), temperature=w.get("temperature", 0.07),
+                         dropout_p=dropout_p, seed=seed)
+
+
+def oracle_step(sd, heads, new_batch, F, feat, w, drop=None):
+    leaves = TR.leaf_state(sd)
+    total, terms = TR.loss(leaves, heads, new_batch, F, feat, drop=drop, **w)
+    total.backward()
+    return leaves, float(total), {k: float(v) for k, v in terms.items()}
+
+
+def check_grads(m, leaves, label, tol=GRAD_TOL):
+    worst, worst_k, errs = 0.0, None, []
+    for k, v in leaves.items():
+        if not v.requires_grad:
+            continue
+        g = m.grad_of(k)
+        ref = v.grad
+        # a gradient that is zero in exact arithmetic (e.g. the key bias of an attention) is rounding noise on both sides
+        if float(ref.norm()) < 1e-6 * max(float(v.detach().norm()), 1.0):
+            assert float(g.norm()) < 1e-5 * max(float(v.detach().norm()), 1.0), k
+            continue
+        e = rel_l2(g, ref)
+        errs.append((e, k))
+        if e > worst:
+            worst, worst_k = e, k
+    errs.sort(reverse=True)
+    print("[grads] %s: %d tensors, median %.2e; largest: %s" % (label, len(errs), errs[len(errs) // 2][0],
+                                                                  ", ".join("%s %.1e" % (k.replace("transformer.", ""), e) for e, k in errs[:6])))
+    margin("%s: worst parameter gradient (%s)" % (label, worst_k), worst, tol)
+
+
+def test_tiny_two_steps_against_the_live_reference_fixture(ctx):
+    fx = torch.load(os.path.join(GOLD, "train_tiny.pt"))
+    sd = torch.load(os.path.join(GOLD, "transformer_tiny.pt"))["state_dict"]
+    m = make_model("model_10_26", ctx, sd, dim_model=32, num_heads=4, num_encoder_layers=1, num_decoder_layers=2)
+    cfg = cfg_of(fx["frames_to_predict"], fx["feat"], fx["weights"])
+    nb = fx["new_batch"].cuda()
+    m.train()
+    for i, st in enumerate(fx["steps"]):
+        terms = m.training_loss(cfg, nb)
+        margin("train_tiny step %d total loss vs live reference" % i, abs(terms["total"] - float(st["total"])) / float(st["total"]), 7e-7, unit="rel")
+        for k in ("mse", "l1", "gdl", "contrastive"):
+            assert abs(terms[k] - float(st["terms"][k])) <= 5e-6 * abs(float(st["terms"][k])), (k, terms[k], float(st["terms"][k]))
+        worst = max(rel_l2(m.grad_of(k), g) for k, g in st["grads"].items() if float(g.norm()) > 1e-7)
+        margin("train_tiny step %d worst stored gradient vs live reference" % i, worst, GRAD_TOL)
+        for k, n in st["grad_norms"].items():
+            if float(n) > 1e-7:
+                assert abs(float(m.grad_of(k).norm()) - float(n)) <= 3e-5 * float(n), k
+        m.adam_step(fx["lr"])
+        got = m.state_dict()
+        for k, p in st["params_after"].items():
+            ok = st["grads"][k].abs() > 1e-5 * st["grads"][k].abs().max()     # see tests/test_oracle_train.py: Adam amplifies noise-level gradients
+            assert rel_l2(got[k].cpu()[ok], p[ok]) < 3e-5, k
+    # the trained weights are what the sampling path now sees (no stale re-upload), in eval mode
+    m.eval()
+    X = nb[:1, :6]
+    out = m(X, X, m.get_tgt_mask(6).cuda())
+    ref = TO.forward({k: v.cpu() for k, v in m.state_dict().items()}, X.cpu(), X.cpu(), 4, TO.get_tgt_mask(6))
+    assert rel_l2(out.cpu(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("w", [dict(w_mse=1.0), dict(w_l1=1.0), dict(w_gdl=1.0, alpha=1), dict(w_gdl=1.0, alpha=2), dict(w_gdl=0.3, alpha=1.5, w_l1=1.0),
+                               dict(w_contrastive=1.0, temperature=0.07), dict(w_mse=1.0, w_gdl=1.0, alpha=2, w_contrastive=0.1, temperature=0.2)])
+def test_each_loss_term_and_its_gradient(ctx, w):
+    sd = torch.load(os.path.join(GOLD, "transformer_tiny.pt"))["state_dict"]
+    m = make_model("model_10_26", ctx, sd, dim_model=32, num_heads=4, num_encoder_layers=1, num_decoder_layers=2)
+    torch.manual_seed(3)
+    nb = torch.cat([2.0 * torch.ones(4, 1, 256), 0.7 * torch.randn(4, 8, 256)], dim=1)
+    F, feat = 4, 8
+    leaves, total, terms = oracle_step(sd, 4, nb, F, feat, w)
+    m.train()
+    got = m.training_loss(cfg_of(F, feat, w), nb.cuda())
+    assert abs(got["total"] - total) <= 5e-6 * abs(total), (got, total)
+    check_grads(m, leaves, "loss %s" % sorted(w.items()))
+    # validation_loop: eval mode, no gradient pass — same value when dropout is off
+    ev = m.training_loss(cfg_of(F, feat, w), nb.cuda(), backward=False)
+    assert abs(ev["total"] - total) <= 5e-6 * abs(total)
+
+
+def test_dropout_masks_are_regenerated_in_backward(ctx):
+    """train mode with dropout_p = 0.25: the test draws every site's mask with svg_op_dropout_mask (same seed / site numbering
+    as the library's forward) and hands them to the oracle, so loss and gradients must agree as without dropout."""
+    sd = torch.load(os.path.join(GOLD, "transformer_tiny.pt"))["state_dict"]
+    p, seed = 0.25, 1234567
+    m = make_model("model_10_26", ctx, sd, dropout_p=p, dim_model=32, num_heads=4, num_encoder_layers=1, num_decoder_layers=2)
+    torch.manual_seed(5)
+    nb = torch.cat([2.0 * torch.ones(3, 1, 256), torch.randn(3, 6, 256)], dim=1)
+    w = dict(w_mse=1.0, w_gdl=0.5, alpha=1)
+    site = [0]
+    kept = []
+
+    def drop(x):
+        mask = ctx.dropout_mask(seed, site[0], p, x.numel()).cpu().reshape(x.shape)
+        site[0] += 1
+        kept.append(float((mask > 0).float().mean()))
+        return x * mask
+    leaves, total, _ = oracle_step(sd, 4, nb, 3, 8, w, drop=drop)
+    assert site[0] == 2 + 4 + 2 * 6
+    assert all(abs(k - (1 - p)) < 0.08 for k in kept), kept                         # keep rate of every site
+    m.train()
+    got = m.training_loss(cfg_of(3, 8, w, dropout_p=p, seed=seed), nb.cuda())
+    assert abs(got["total"] - total) <= 5e-6 * abs(total), (got["total"], total)
+    check_grads(m, leaves, "dropout 0.25")
+    # another seed: other masks, another loss; same seed again: the same bits
+    again = m.training_loss(cfg_of(3, 8, w, dropout_p=p, seed=seed), nb.cuda())
+    other = m.training_loss(cfg_of(3, 8, w, dropout_p=p, seed=seed + 1), nb.cuda())
+    assert again["total"] == got["total"] and other["total"] != got["total"]
+
+
+def test_full_size_training_step_config1(ctx):
+    """configs[1] model (1_16_kitti_L1_64: d=2048, 4+8 layers, 437.6 M parameters), the config's own batch: 8 clips x (5+5 frames + SOS),
+    L1 loss on the 5 predicted frames, one Adam step at the config's LR."""
+    svg_config.set_args(["--dataset", "kitti", "--config", "1_16_kitti_L1_64"])
+    cfgy = svg_config.parse_config_args()[0]
+    m = make_model("1_16_kitti_L1_64", ctx, None, seed=11, dim_model=cfgy.DIM_MODEL[0], num_heads=cfgy.NUM_HEADS[0],
+                   num_encoder_layers=cfgy.NUM_ENCODER_LAYERS[0], num_decoder_layers=cfgy.NUM_DECODER_LAYERS[0])
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    torch.manual_seed(12)
+    B, T, F = cfgy.BATCH_SIZE[0], cfgy.FRAMES_PER_CLIP[0] + cfgy.FRAMES_TO_PREDICT[0] + 1, cfgy.FRAMES_TO_PREDICT[0]
+    nb = torch.cat([2.0 * torch.ones(B, 1, 256), 0.8 * torch.randn(B, T - 1, 256)], dim=1)
+    w = dict(w_l1=1.0)
+    leaves, total, _ = oracle_step(sd, cfgy.NUM_HEADS[0], nb, F, 8, w)
+    m.train()
+    got = m.training_loss(cfg_of(F, 8, w), nb.cuda())
+    margin("cfg1 full-size training loss", abs(got["total"] - total) / abs(total), 4.5e-7, unit="rel")
+    # At this size the first layers are badly conditioned for f32 (tokens of magnitude sqrt(2048) saturate the softmax of the
+    # random-init attention: its backward is a difference of nearly equal numbers), so two correct f32 implementations differ by
+    # 1e-4 there.  Judge both against the same graph in float64: the HIP gradients must be as close to it as torch's own f32 ones.
+    sd64 = {k: v.double() for k, v in sd.items()}
+    l64, _, _ = oracle_step(sd64, cfgy.NUM_HEADS[0], nb.double(), F, 8, w)
+    rows = []
+    for k, v in leaves.items():
+        if not v.requires_grad or float(l64[k].grad.norm()) < 1e-9:
+            continue
+        rows.append((rel_l2(m.grad_of(k), l64[k].grad), rel_l2(v.grad, l64[k].grad), k))
+    rows.sort(reverse=True)
+    print("[grads] cfg1 vs float64: HIP f32 / torch-CPU f32 error per tensor, largest: " +
+          ", ".join("%s %.1e/%.1e" % (k.replace("transformer.", ""), a, b) for a, b, k in rows[:6]))
+    margin("cfg1 full-size (437.6 M parameters): worst gradient vs the float64 oracle", rows[0][0], 5.5e-4)
+    margin("cfg1 full-size: median gradient error vs the float64 oracle", rows[len(rows) // 2][0], 2.3e-6)
+    for a, b, k in rows:
+        assert a <= max(3.0 * b, 2e-5), (k, a, b)
+    # one Adam step: against torch.optim.Adam fed with the ORACLE's gradients, where the gradient is above the noise
+    names = [k for k, v in sorted(leaves.items()) if v.requires_grad]
+    opt = torch.optim.Adam([leaves[k] for k in names], lr=cfgy.LR[0])
+    opt.step()
+    m.adam_step(cfgy.LR[0])
+    trained = m.state_dict()
+    worst = 0.0
+    for k in names:
+        g = leaves[k].grad
+        ok = g.abs() > 1e-4 * g.abs().max()
+        upd_ref = (leaves[k].detach() - sd[k])[ok]
+        upd = (trained[k].cpu() - sd[k])[ok]
+        worst = max(worst, rel_l2(upd, upd_ref))
+    margin("cfg1 Adam update (lr %g) vs torch.optim.Adam" % cfgy.LR[0], worst, 8e-4)

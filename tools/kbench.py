@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-shape kernel timings through the op-level C ABI (hipEvent brackets inside the library).
-usage: python tools/kbench.py [conv|gemm|attn|gn|xf] [--b B]"""
+usage: python tools/kbench.py [conv|gemm|attn|gn|xf|train] [--b B]"""
 import argparse
 import math
 import os
@@ -142,6 +142,46 @@ def main():
             ms, _, by = timeit(ctx, "xf_gemm", lambda: ctx.check(ctx.lib.svg_op_xf_gemm(
                 ctx.h, X.data_ptr(), W.data_ptr(), None, Y.data_ptr(), M, N, K, 0, stream()), "xf"))
             print("%3d %5d %5d  %8.4f ms  %7.1f GB/s  %6.1f TFLOP/s (f32 MFMA peak 157)" % (M, N, K, ms, N * K * 4 / ms / 1e6, 2.0 * M * N * K / ms / 1e9))
+    if "train" in a.what:
+        # one optimisation step of the latent Transformer at the reference's training configuration (config 1_16_kitti_L1_64:
+        # d=2048, 4+8 layers, batch 8 x (5+5 frames + SOS)), wall clock with torch events around 10 steps
+        from sd_video_gen_amd import config as svg_config
+        from sd_video_gen_amd.transformer import Transformer
+        svg_config.set_args(["--dataset", "kitti", "--config", "1_16_kitti_L1_64"])
+        cfgy = svg_config.parse_config_args()[0]
+        torch.manual_seed(0)
+        m = Transformer(dim_model=cfgy.DIM_MODEL[0], num_heads=cfgy.NUM_HEADS[0], num_encoder_layers=cfgy.NUM_ENCODER_LAYERS[0],
+                        num_decoder_layers=cfgy.NUM_DECODER_LAYERS[0], dropout_p=cfgy.DROPOUT_P[0]).use_context(ctx)
+        n_par = sum(p.numel() for p in m.parameters())
+        for Bt in (8, 16, 32):
+            T = cfgy.FRAMES_PER_CLIP[0] + cfgy.FRAMES_TO_PREDICT[0] + 1
+            if Bt * T > 336 + 32:
+                continue
+            nb = torch.cat([2.0 * torch.ones(Bt, 1, 256), torch.randn(Bt, T - 1, 256)], dim=1).cuda()
+            cfg = _lib.TrainCfg(frames_to_predict=cfgy.FRAMES_TO_PREDICT[0], feat_h=8, feat_w=8, w_mse=0.0, w_l1=1.0, w_gdl=0.0, gdl_alpha=1.0,
+                                w_contrastive=0.0, temperature=0.07, dropout_p=cfgy.DROPOUT_P[0], seed=1)
+            m.train()
+            for _ in range(2):
+                m.training_loss(cfg, nb); m.adam_step(cfgy.LR[0])
+            torch.cuda.synchronize()
+            for part in ("fwd+loss (eval)", "fwd+bwd", "adam", "step"):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for i in range(10):
+                    cfg.seed = 10 + i
+                    if part == "fwd+loss (eval)":
+                        m.training_loss(cfg, nb, backward=False)
+                    elif part == "fwd+bwd":
+                        m.training_loss(cfg, nb)
+                    elif part == "adam":
+                        m.adam_step(cfgy.LR[0])
+                    else:
+                        m.training_loss(cfg, nb); m.adam_step(cfgy.LR[0])
+                e1.record(); torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 10
+                # HBM bytes a step has to move: W read by forward and by dX, dW written, Adam reads p,g,m,v and writes p,m,v
+                gb = {"fwd+loss (eval)": 1, "fwd+bwd": 3, "adam": 7, "step": 10}[part] * n_par * 4 / 1e9
+                print("train B=%2d (%3d rows) %-16s %8.3f ms   %6.2f GB algorithmic -> %6.0f GB/s" % (Bt, Bt * T, part, ms, gb, gb / ms * 1e3))
 
 
 if __name__ == "__main__":
