@@ -199,8 +199,9 @@ class Context:
         return out
 
     # ---- training step of the latent Transformer ---------------------------------------------------
-    def transformer_loss(self, cfg, src, tgt, expected, mask=None, text=None, backward=True):
-        """-> dict(total, mse, l1, gdl, contrastive).  backward=True: train mode, gradients left in the library."""
+    def transformer_loss(self, cfg, src, tgt, expected, mask=None, text=None, backward=True, read_losses=True):
+        """-> dict(total, mse, l1, gdl, contrastive).  backward=True: train mode, gradients left in the library.
+        read_losses=False: nothing is copied back and the stream is not synchronised (returns None)."""
         B, Ts, _ = src.shape
         Tt = tgt.shape[1]
         src = src.contiguous().float()
@@ -209,9 +210,11 @@ class Context:
         assert expected.shape == tgt.shape
         mask = mask.contiguous().float() if mask is not None else None
         text = text.to(device=src.device, dtype=torch.float32).contiguous() if text is not None else None
-        out = (_f * 5)()
+        out = (_f * 5)() if read_losses else None
         self.check(self.lib.svg_transformer_loss(self.h, C.byref(cfg), _ptr(src), _ptr(tgt), _ptr(expected), _ptr(text), B, Ts, Tt,
                                                  _ptr(mask), int(bool(backward)), out, _stream()), "svg_transformer_loss")
+        if out is None:
+            return None
         return dict(zip(("total", "mse", "l1", "gdl", "contrastive"), [float(v) for v in out]))
 
     def transformer_adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8):

@@ -197,13 +197,12 @@ struct XfDrop { uint64_t seed; uint32_t site; float p; };
 struct XfAdamTensor { float* p; const float* g; float* m; float* v; };
 struct XfAdamChunk { int32_t ten; int32_t n; int64_t off; };
 void xf_drop_mask(const XfDrop d, float* out, int64_t n, hipStream_t s);
-// dW[N][K] (+)= dY[M][N]^T X[M][K]
-void xf_gemm_tn(const float* dY, int ldy, const float* X, int ldx, float* dW, int M, int N, int K, int accumulate, hipStream_t s);
+// dW[N][K] (+)= dY[M][N]^T X[M][K];  db[N] (+)= column sums of dY (db may be null)
+void xf_gemm_tn(const float* dY, int ldy, const float* X, int ldx, float* dW, float* db, int M, int N, int K, int accumulate, hipStream_t s);
 // out[M][K] = gate(dY[M][N] W[N][K]) + add;  gate (or null): x * (gate[i] > 0 ? gate_scale : 0);  slabs: xf_gemm_nn_slab_floats() floats
 int64_t xf_gemm_nn_slab_floats(int M, int N, int K);
 void xf_gemm_nn(const float* dY, int ldy, const float* W, float* slabs, float* out, int M, int N, int K, const float* gate, float gate_scale,
                 const float* add, hipStream_t s);
-void xf_colsum(const float* dY, int ldy, float* db, int M, int N, int accumulate, hipStream_t s);
 void xf_relu_drop(const float* h, float* r, int64_t n, const XfDrop d, hipStream_t s);
 void xf_add_ln_train(const float* x, const float* r, const XfDrop dr, const float* g, const float* b, float* y, float* xhat, float* rstd, int M,
                      int d, float eps, hipStream_t s);

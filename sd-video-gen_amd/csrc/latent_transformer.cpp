@@ -83,7 +83,7 @@ struct XfRun {
   float* gemm(const float* X, const std::string& w, const std::string& b, int M, int N, int K, int relu_in = 0,
               int64_t woff = 0, int64_t boff = 0) {
     float* Y = ctx->arena.get<float>((int64_t)M * N);
-    if (SVG_LAUNCHING(ctx)) xf_gemm(ctx, X, W(w) + woff, W(b) + boff, Y, M, N, K, relu_in, s);
+    xf_gemm(ctx, X, W(w) + woff, W(b) + boff, Y, M, N, K, relu_in, s);
     return Y;
   }
   float* add_ln(const float* x, const float* r, const std::string& p, int M) {
@@ -152,7 +152,7 @@ static void xf_forward_chunk(svg_ctx* ctx, XfModel* m, const float* src, const f
     xt = r.add_ln(xt, r.ffn(p, xt, Mt), p + "norm3.", Mt);
   }
   xt = r.add_ln(xt, nullptr, "transformer.decoder.norm.", Mt);
-  if (SVG_LAUNCHING(ctx)) xf_gemm(ctx, xt, r.W("out.weight"), r.W("out.bias"), out_tb, Mt, m->d_lat, m->d_model, 0, s);
+  xf_gemm(ctx, xt, r.W("out.weight"), r.W("out.bias"), out_tb, Mt, m->d_lat, m->d_model, 0, s);
 }
 
 void XfModel::forward(svg_ctx* ctx, const float* src, const float* tgt, int B, int Ts, int Tt, const float* mask,

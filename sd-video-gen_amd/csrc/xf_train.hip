@@ -33,39 +33,65 @@ __global__ void drop_mask_kernel(const XfDrop d, float* __restrict__ out, int64_
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = drop_apply(d, i);
 }
 
-// ---- dW = dY^T X ---------------------------------------------------------------------------------------------------------
-// grid (ceil(K/128), ceil(N/128)), 4 waves as 2 x 2, wave tile 64 (n) x 64 (k)
+// ---- dW = dY^T X (+ db = column sums of dY) -------------------------------------------------------------------------------
+// grid (ceil(K/128), ceil(N/128)), 4 waves as 2 x 2, wave tile 64 (n) x 64 (k).  The contraction runs over the few rows m: the
+// operands come straight from L2 (dY and X are a few hundred KB), eight row-steps (32 rows) per batch with the next batch's loads in
+// flight under this batch's 128 MFMAs.  The waves of k-block 0 also reduce their dY values over m: db[n] (rows ascending per lane
+// group, then the four lane groups in order — fixed order).
+constexpr int TN_U = 8;
 __global__ void __launch_bounds__(256) xf_gemm_tn_kernel(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx,
-                                                          float* __restrict__ dW, int M, int N, int K, int accumulate) {
+                                                          float* __restrict__ dW, float* __restrict__ db, int M, int N, int K, int accumulate) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
   const int nb = blockIdx.y * 128 + (wid >> 1) * 64, kb = blockIdx.x * 128 + (wid & 1) * 64;
   const int n4 = nb + 4 * l15, k4 = kb + 4 * l15;
   const bool n_ok = n4 < N, k_ok = k4 < K;                   // N, K multiples of 4
+  const bool do_bias = db != nullptr && blockIdx.x == 0 && (wid & 1) == 0;
   const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 acc[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = zero;
-  auto load = [&](int m0, f32x4& a, f32x4& b) {
-    const int m = m0 + lq;
-    a = (m < M && n_ok) ? *(const f32x4*)(dY + (int64_t)m * ldy + n4) : zero;
-    b = (m < M && k_ok) ? *(const f32x4*)(X + (int64_t)m * ldx + k4) : zero;
+  f32x4 bsum = zero;
+  f32x4 a0[TN_U], b0[TN_U], a1[TN_U], b1[TN_U];
+  auto load = [&](int m0, f32x4* a, f32x4* b) {
+#pragma unroll
+    for (int u = 0; u < TN_U; ++u) {
+      const int m = m0 + 4 * u + lq;
+      a[u] = (m < M && n_ok) ? *(const f32x4*)(dY + (int64_t)m * ldy + n4) : zero;
+      b[u] = (m < M && k_ok) ? *(const f32x4*)(X + (int64_t)m * ldx + k4) : zero;
+    }
   };
-  f32x4 a0, b0, a1, b1;
+  auto mac = [&](const f32x4* a, const f32x4* b) {
+#pragma unroll
+    for (int u = 0; u < TN_U; ++u) {
+      if (do_bias) bsum += a[u];
+#pragma unroll
+      for (int jr = 0; jr < 4; ++jr)
+#pragma unroll
+        for (int jc = 0; jc < 4; ++jc) acc[jr][jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][jr], b[u][jc], acc[jr][jc], 0, 0, 0);
+    }
+  };
   load(0, a0, b0);
-  for (int m0 = 0; m0 < M; m0 += 8) {
-    load(m0 + 4, a1, b1);
+  for (int m0 = 0; m0 < M; m0 += 8 * TN_U) {
+    load(m0 + 4 * TN_U, a1, b1);
+    mac(a0, b0);
+    load(m0 + 8 * TN_U, a0, b0);
+    mac(a1, b1);
+  }
+  if (do_bias) {
+    // lane groups lq = 0..3 hold the rows m = lq mod 4: add them in order
+    f32x4 t = bsum;
 #pragma unroll
-    for (int jr = 0; jr < 4; ++jr)
-#pragma unroll
-      for (int jc = 0; jc < 4; ++jc) acc[jr][jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[jr], b0[jc], acc[jr][jc], 0, 0, 0);
-    load(m0 + 8, a0, b0);
-#pragma unroll
-    for (int jr = 0; jr < 4; ++jr)
-#pragma unroll
-      for (int jc = 0; jc < 4; ++jc) acc[jr][jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[jr], b1[jc], acc[jr][jc], 0, 0, 0);
+    for (int j = 0; j < 4; ++j) {
+      const float v0 = __shfl(bsum[j], l15), v1 = __shfl(bsum[j], l15 + 16), v2 = __shfl(bsum[j], l15 + 32), v3 = __shfl(bsum[j], l15 + 48);
+      t[j] = ((v0 + v1) + v2) + v3;
+    }
+    if (lq == 0 && n_ok) {
+      if (accumulate) t += *(const f32x4*)(db + n4);
+      *(f32x4*)(db + n4) = t;
+    }
   }
   if (!k_ok) return;
 #pragma unroll
@@ -170,15 +196,6 @@ __global__ void __launch_bounds__(256) xf_nn_finish_kernel(const float* __restri
   }
 }
 
-// db[n] (+)= sum_m dY[m][n]   (rows ascending)
-__global__ void colsum_kernel(const float* __restrict__ dY, int ldy, float* __restrict__ db, int M, int N, int accumulate) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  float s = 0.f;
-  for (int m = 0; m < M; ++m) s += dY[(int64_t)m * ldy + n];
-  db[n] = accumulate ? db[n] + s : s;
-}
-
 // ---- forward pieces that keep what backward needs ---------------------------------------------------------------------------
 // r = dropout(relu(h)): r > 0 exactly where the gradient passes (scaled by 1/(1-p))
 __global__ void relu_drop_kernel(const float* __restrict__ h, float* __restrict__ r, int64_t n, const XfDrop d) {
@@ -268,14 +285,22 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ d
   }
 }
 
-// dgamma[c] = sum_rows dy xhat, dbeta[c] = sum_rows dy  (rows ascending)
-__global__ void ln_bwd_params_kernel(const float* __restrict__ dy, const float* __restrict__ xhat, float* __restrict__ dg, float* __restrict__ db,
-                                     int M, int d) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= d) return;
+// dgamma[c] = sum_rows dy xhat, dbeta[c] = sum_rows dy: a block owns 64 columns, its 4 waves take the rows m = w mod 4 (ascending)
+// and are added in wave order
+__global__ void __launch_bounds__(256) ln_bwd_params_kernel(const float* __restrict__ dy, const float* __restrict__ xhat, float* __restrict__ dg,
+                                                             float* __restrict__ db, int M, int d) {
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   float sg = 0.f, sb = 0.f;
-  for (int m = 0; m < M; ++m) { const float v = dy[(int64_t)m * d + c]; sg += v * xhat[(int64_t)m * d + c]; sb += v; }
-  dg[c] = sg; db[c] = sb;
+  if (c < d)
+    for (int m = wid; m < M; m += 4) { const float v = dy[(int64_t)m * d + c]; sg += v * xhat[(int64_t)m * d + c]; sb += v; }
+  red[0][wid][lane] = sg; red[1][wid][lane] = sb;
+  __syncthreads();
+  if (wid == 0 && c < d) {
+    dg[c] = ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane];
+    db[c] = ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane];
+  }
 }
 
 // emb rows (b,t) batch-first, d_img wide -> y (t,b,d) = dropout(v * scale + pe); text channels as in xf_embed_post
@@ -549,9 +574,9 @@ void xf_drop_mask(const XfDrop d, float* out, int64_t n, hipStream_t s) {
   check_launch("drop_mask");
 }
 
-void xf_gemm_tn(const float* dY, int ldy, const float* X, int ldx, float* dW, int M, int N, int K, int accumulate, hipStream_t s) {
+void xf_gemm_tn(const float* dY, int ldy, const float* X, int ldx, float* dW, float* db, int M, int N, int K, int accumulate, hipStream_t s) {
   SVG_CHECK(N % 4 == 0 && K % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0, "xf_gemm_tn: N %d / K %d / strides must be multiples of 4", N, K);
-  hipLaunchKernelGGL(xf_gemm_tn_kernel, dim3(cdiv(K, 128), cdiv(N, 128)), dim3(256), 0, s, dY, ldy, X, ldx, dW, M, N, K, accumulate);
+  hipLaunchKernelGGL(xf_gemm_tn_kernel, dim3(cdiv(K, 128), cdiv(N, 128)), dim3(256), 0, s, dY, ldy, X, ldx, dW, db, M, N, K, accumulate);
   check_launch("xf_gemm_tn");
 }
 
@@ -584,11 +609,6 @@ void xf_gemm_nn(const float* dY, int ldy, const float* W, float* slabs, float* o
   check_launch("xf_gemm_nn");
 }
 
-void xf_colsum(const float* dY, int ldy, float* db, int M, int N, int accumulate, hipStream_t s) {
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, dY, ldy, db, M, N, accumulate);
-  check_launch("xf_colsum");
-}
-
 void xf_relu_drop(const float* h, float* r, int64_t n, const XfDrop d, hipStream_t s) {
   hipLaunchKernelGGL(relu_drop_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, h, r, n, d);
   check_launch("xf_relu_drop");
@@ -605,7 +625,7 @@ void xf_ln_bwd(const float* dy, const float* xhat, const float* rstd, const floa
                float* dbeta, int M, int d, hipStream_t s) {
   SVG_CHECK(d <= 3072, "xf_ln_bwd: d %d > 3072", d);
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(M), dim3(256), 0, s, dy, xhat, rstd, g, dz, dz_drop, dr, d);
-  hipLaunchKernelGGL(ln_bwd_params_kernel, dim3(cdiv(d, 64)), dim3(64), 0, s, dy, xhat, dgamma, dbeta, M, d);
+  hipLaunchKernelGGL(ln_bwd_params_kernel, dim3(cdiv(d, 64)), dim3(256), 0, s, dy, xhat, dgamma, dbeta, M, d);
   check_launch("xf_ln_bwd");
 }
 

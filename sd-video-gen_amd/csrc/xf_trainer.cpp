@@ -7,6 +7,7 @@
 #include "models.h"
 #include "../../include/svg_hip.h"
 #include <cmath>
+#include <cstring>
 
 struct XfTrain {
   struct Slot { float* g = nullptr; float* m = nullptr; float* v = nullptr; int64_t n = 0; };
@@ -16,6 +17,8 @@ struct XfTrain {
   int n_chunks = 0;
   int step = 0;
   float* d_losses = nullptr;     // [5]
+  float* h_losses = nullptr;     // pinned mirror: a device-to-pageable copy goes through the runtime's staging path and its host thread
+  std::unordered_map<uint64_t, int64_t> plan;   // workspace high-water mark per call shape (saves the dry planning pass)
   std::vector<void*> bufs;       // device allocations of the training state (freed with it)
   void* dalloc(int64_t bytes) {
     void* p = nullptr;
@@ -23,7 +26,7 @@ struct XfTrain {
     bufs.push_back(p);
     return p;
   }
-  ~XfTrain() { for (void* p : bufs) hipFree(p); }
+  ~XfTrain() { for (void* p : bufs) hipFree(p); if (h_losses) hipHostFree(h_losses); }
 };
 
 namespace {
@@ -58,9 +61,8 @@ struct Run {
   float* lin(LinTape& t, const float* x, const std::string& w, const std::string& b, int M, int N, int K, int64_t woff = 0, int64_t boff = 0) {
     t = LinTape{x, M, N, K, w, b, woff, boff};
     float* y = get<float>((int64_t)M * N);
-    if (go())
-      for (int m0 = 0; m0 < M; m0 += 336)     // xf_gemm streams W once per 336 rows
-        xf_gemm(ctx, x + (int64_t)m0 * K, W(w) + woff, W(b) + boff, y + (int64_t)m0 * N, std::min(336, M - m0), N, K, 0, s);
+    for (int m0 = 0; m0 < M; m0 += 336)       // xf_gemm streams W once per 336 rows (it plans its own split-K slabs in the dry pass)
+      xf_gemm(ctx, x + (int64_t)m0 * K, W(w) + woff, W(b) + boff, y + (int64_t)m0 * N, std::min(336, M - m0), N, K, 0, s);
     return y;
   }
   // dW, db of the layer; dx = gate(dy W) + add (dx == nullptr: not wanted)
@@ -68,8 +70,7 @@ struct Run {
                bool accumulate = false) {
     float* slabs = dx ? get<float>(xf_gemm_nn_slab_floats(t.M, t.N, t.K)) : nullptr;
     if (!go()) return;
-    xf_gemm_tn(dy, t.N, t.x, t.K, G(t.w) + t.woff, t.M, t.N, t.K, accumulate, s);
-    xf_colsum(dy, t.N, G(t.b) + t.boff, t.M, t.N, accumulate, s);
+    xf_gemm_tn(dy, t.N, t.x, t.K, G(t.w) + t.woff, G(t.b) + t.boff, t.M, t.N, t.K, accumulate, s);
     if (dx) xf_gemm_nn(dy, t.N, W(t.w) + t.woff, slabs, dx, t.M, t.N, t.K, gate, gate_scale, add, s);
   }
 
@@ -193,6 +194,7 @@ void ensure_train(svg_ctx* ctx, XfModel* m) {
   tr->d_tens = (XfAdamTensor*)tr->dalloc(tens.size() * sizeof(XfAdamTensor));
   tr->d_chunks = (XfAdamChunk*)tr->dalloc(chunks.size() * sizeof(XfAdamChunk));
   tr->d_losses = (float*)tr->dalloc(5 * sizeof(float));
+  HIP_OK(hipHostMalloc((void**)&tr->h_losses, 5 * sizeof(float), hipHostMallocDefault));
   HIP_OK(hipMemcpy(tr->d_tens, tens.data(), tens.size() * sizeof(XfAdamTensor), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(tr->d_chunks, chunks.data(), chunks.size() * sizeof(XfAdamChunk), hipMemcpyHostToDevice));
   tr->n_chunks = (int)chunks.size();
@@ -212,7 +214,8 @@ void loss_pass(svg_ctx* ctx, XfModel* m, const svg_train_cfg& cfg, const float* 
   ensure_train(ctx, m);
   XfTrain* tr = m->train;
   const int d = m->d_model, Ms = Ts * B, Mt = Tt * B;
-  run_planned(ctx, [&]() {
+  const uint64_t shape_key = ((uint64_t)B << 40) | ((uint64_t)Ts << 24) | ((uint64_t)Tt << 8) | (uint64_t)(backward ? 1 : 0);
+  auto body = [&]() {
     Run r{ctx, m, tr, s, B, cfg.seed, backward ? cfg.dropout_p : 0.f, backward != 0};
     r.text = text;
     LinTape e_src, e_tgt, l_out;
@@ -284,10 +287,20 @@ void loss_pass(svg_ctx* ctx, XfModel* m, const svg_train_cfg& cfg, const float* 
     }
     r.embed_bwd(e_src, d_src, dxs, Ts, false);
     r.embed_bwd(e_tgt, d_tgt, dxt, Tt, true);                 // the embedding layer is shared: second contribution accumulates
-  });
+  };
+  auto it = tr->plan.find(shape_key);
+  if (it == tr->plan.end()) {
+    run_planned(ctx, body);
+    tr->plan[shape_key] = ctx->arena.high;
+  } else {                                                    // same shapes as a planned call: the workspace need is known
+    ctx->ensure_arena(it->second);
+    ctx->arena.reset();
+    body();
+  }
   if (losses_host) {
-    HIP_OK(hipMemcpyAsync(losses_host, tr->d_losses, 5 * sizeof(float), hipMemcpyDefault, s));
+    HIP_OK(hipMemcpyAsync(tr->h_losses, tr->d_losses, 5 * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
+    memcpy(losses_host, tr->h_losses, 5 * sizeof(float));
   }
 }
 

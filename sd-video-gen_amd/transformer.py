@@ -91,7 +91,7 @@ class Transformer(nn.Module):
     # ---- training step (trainers/trainer.py:111-190) ---------------------------------------------------
     # The optimisation runs inside the library on the uploaded copy of the weights (gradients and Adam moments live there);
     # the nn.Parameters of this module are refreshed from it by pull_weights(), which state_dict() does on its own.
-    def training_loss(self, cfg, new_batch, tgt_mask=None, text=None, backward=True):
+    def training_loss(self, cfg, new_batch, tgt_mask=None, text=None, backward=True, read_losses=True):
         """Loss of one trainer iteration on the encoded batch `new_batch` (B, T, D_lat): src = new_batch, tgt = new_batch[:, :-1],
         expected = new_batch[:, 1:] (trainer.py:124-145).  backward=True runs in train mode (dropout_p of `cfg`) and leaves the
         gradients in the library for adam_step(); False is the validation loss (eval mode).  -> dict of the loss terms."""
@@ -101,7 +101,7 @@ class Transformer(nn.Module):
         y_input = new_batch[:, :-1]
         if tgt_mask is None:
             tgt_mask = self.get_tgt_mask(y_input.size(1)).to(new_batch.device)
-        return ctx.transformer_loss(cfg, new_batch, y_input, new_batch[:, 1:], tgt_mask, text, backward)
+        return ctx.transformer_loss(cfg, new_batch, y_input, new_batch[:, 1:], tgt_mask, text, backward, read_losses)
 
     def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8):
         ctx = self._sync_weights()

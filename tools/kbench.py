@@ -164,11 +164,12 @@ def main():
             for _ in range(2):
                 m.training_loss(cfg, nb); m.adam_step(cfgy.LR[0])
             torch.cuda.synchronize()
+            import time
             for part in ("fwd+loss (eval)", "fwd+bwd", "adam", "step"):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for i in range(10):
+                ts = []
+                for i in range(30):
                     cfg.seed = 10 + i
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
                     if part == "fwd+loss (eval)":
                         m.training_loss(cfg, nb, backward=False)
                     elif part == "fwd+bwd":
@@ -177,12 +178,13 @@ def main():
                         m.adam_step(cfgy.LR[0])
                     else:
                         m.training_loss(cfg, nb); m.adam_step(cfgy.LR[0])
-                e1.record(); torch.cuda.synchronize()
-                ms = e0.elapsed_time(e1) / 10
+                    torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+                ts.sort()
+                med, mean = ts[len(ts) // 2], sum(ts) / len(ts)
                 # HBM bytes a step has to move: W read by forward and by dX, dW written, Adam reads p,g,m,v and writes p,m,v
                 gb = {"fwd+loss (eval)": 1, "fwd+bwd": 3, "adam": 7, "step": 10}[part] * n_par * 4 / 1e9
-                print("train B=%2d (%3d rows) %-16s %8.3f ms   %6.2f GB algorithmic -> %6.0f GB/s" % (Bt, Bt * T, part, ms, gb, gb / ms * 1e3))
-
+                print("train B=%2d (%3d rows) %-16s median %7.3f ms (%5.0f GB/s of %5.2f GB algorithmic)   mean %7.3f ms, %d of 30 calls > 3x median"
+                      % (Bt, Bt * T, part, med, gb / med * 1e3, gb, mean, sum(1 for t in ts if t > 3 * med)))
 
 if __name__ == "__main__":
     main()
