@@ -189,3 +189,44 @@ def test_full_size_training_step_config1(ctx):
         upd = (trained[k].cpu() - sd[k])[ok]
         worst = max(worst, rel_l2(upd, upd_ref))
     margin("cfg1 Adam update (lr %g) vs torch.optim.Adam" % cfgy.LR[0], worst, 8e-4)
+
+
+def test_trainer_fit_end_to_end(tmp_path, monkeypatch):
+    """trainers/trainer.py:262-273 fit(): train_loop + validation_loop over a loader of uint8 clips — VAE encode (HIP), train-mode
+    step in the library, Adam; the loss goes down on a repeated batch, and the checkpoint written like trainer.py:478 gives the
+    same validation loss in a fresh model."""
+    from test_boundary_gpu import VCFG, UCFG
+    from sd_video_gen_amd.sd_utils import SDUtils
+    from sd_video_gen_amd import trainer as T
+    monkeypatch.chdir(tmp_path)
+    os.makedirs(tmp_path / "config")
+    import shutil
+    shutil.copy(os.path.join(ROOT, "config", "model_10_26.yml"), tmp_path / "config" / "model_10_26.yml")
+    svg_config.set_args(["--dataset", "ball", "--config", "model_10_26"])
+    c = _lib.Context(0)
+    sdu = SDUtils(weights="synthetic", arch={"vae": VCFG, "unet": UCFG}, verbose=False, ctx=c, text_embeddings=torch.zeros(2, 77, 768))
+    tr = T.Trainer(sd_utils=sdu)
+    logs = []
+    tr.log = logs.append
+    from sd_video_gen_amd.transformer import Transformer
+    torch.manual_seed(21)
+    model = Transformer(dim_model=32, num_heads=4, num_encoder_layers=1, num_decoder_layers=2, dropout_p=0.1).use_context(c)
+    g = torch.Generator().manual_seed(1)
+    clips = torch.randint(0, 256, (4, 8, 64, 64, 3), dtype=torch.uint8, generator=g)        # (B, frames, H, W, C) like the loaders
+    loader = [(torch.arange(4), clips)] * 12
+    loss_fn = tr.criterion(use_mse=True, use_L1=False, use_gdl=True, lambda_gdl=1, alpha=2, use_contrastive=True, lambda_contrastive=0.05)
+    opt = T.Adam(model, lr=2e-3)
+    first = tr.validation_loop(model, loss_fn, loader[:1], 3)
+    train_loss, val_loss = tr.fit(model=model, opt=opt, scheduler=None, loss_fn=loss_fn, train_dataloader=loader, val_dataloader=loader[:1],
+                                  frames_to_predict=3)
+    assert val_loss < 0.9 * first, (first, train_loss, val_loss)
+    assert {"train_loss", "mse_train", "L1_train", "gdl_train", "contrastive_train"} <= set(logs[1]) and "val_loss" in logs[2]
+    path = "./checkpoints/model_10_26_%d_test.pt" % tr.index
+    torch.save(model.state_dict(), path)
+    again = Transformer(dim_model=32, num_heads=4, num_encoder_layers=1, num_decoder_layers=2, dropout_p=0.1).use_context(_lib.Context(0))
+    again.load_state_dict(torch.load(path, weights_only=True))
+    # (encode_batch samples the VAE posterior, so two validation_loop calls differ by the draw: compare on fixed latents)
+    nb = torch.as_tensor(sdu.encode_batch(clips, use_sos=True)).cuda()
+    cfg = loss_fn.cfg(3)
+    a, b = model.training_loss(cfg, nb, backward=False), again.training_loss(cfg, nb, backward=False)
+    assert a["total"] == b["total"] and abs(a["total"] - val_loss) < 0.1 * val_loss
