@@ -16,6 +16,7 @@
 //   (wave-uniform branch): bit-identical to rescaling every tile with alpha = 1.
 // LDS row strides are padded (K: odd multiple of 16 B, V^T: 136 B) so fragment reads are conflict free.
 #include "kernels.h"
+#include "igemm_epi.h"
 #include <cstdlib>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -361,6 +362,271 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
   }
 }
 
+// ---- d = 40: K / V^T staged by LDS-DMA through a three-stage ring ---------------------------------------------------------
+// The register-staged form above spends a fifth of its time on staging (ablation: no loads / LDS writes / second barrier = -20 %):
+// address VALU, 6 ds_writes, a vmcnt(0) and two barriers per key tile.  Here every wave issues three `buffer_load ... lds` per tile
+// (7 wave-instructions of K rows + 5 of V^T rows, 12 = 3 x 4 waves) two tiles ahead, waits with a counted vmcnt (in order: the three
+// DMAs of the next tile stay in flight) and meets the other waves at ONE barrier per tile.  Two layout changes make the LDS side
+// DMA-friendly (a DMA writes 64 consecutive 16-byte chunks):
+//   * K rows sit in LDS in PERMUTED order: slot 16 s + 8 g + 4 h + e holds key 16 s + 8 h + 4 g + e.  Softmax does not care, and
+//     the eight P values a lane feeds into one PV MFMA (slots 16 s + {4 h + e, 8 + 4 h + e}) then belong to eight CONSECUTIVE keys
+//     16 s + 8 h .. + 7 — one 16-byte chunk of a natural-order V^T row instead of two 8-byte pieces.
+//   * V^T rows are 128 bytes, chunk c of row r at position c ^ ((r >> 1) & 7) (the DMA lane picks its global chunk accordingly):
+//     conflict-free ds_read_b128 for 16 consecutive rows at one chunk.
+// Lanes that would read past Skv get an out-of-range buffer offset (zero fill).  Same arithmetic as attn_kernel<40, 2, 1, true>.
+// Measured (28 x 8 x 4096^2 x 40, same box): 0.955-0.984 ms against 1.008-1.020 ms for the register-staged form.  Ablations of THIS
+// kernel (0.965 ms): no v_exp -0.155, no row max -0.045, no PV MFMAs -0.34, no QK^T MFMAs -0.205, no DMA / barrier -0.165 ms, QK^T
+// alone 0.54 ms — the costs add up: on this instruction mix the matrix phase and the softmax VALU do not overlap, neither inside a
+// wave nor between the two unsynchronised waves of a SIMD.  A variant that runs the two query blocks of a wave half a tile apart
+// (every MFMA group beside the other block's independent exp2 / max VALU in the same stream, sched_group_barrier interleave, four
+// LDS stages, tail keys masked through a -1e30 pad column instead of a pass over S) was correct and NOT faster (1.02-1.06 ms);
+// AGPR-form accumulators (no -amdgpu-mfma-vgpr-form) 1.26-1.65 ms.
+constexpr int DM_NST = 3;
+__global__ void __launch_bounds__(256) attn_dma40_kernel(const AttnArgs a) {
+  constexpr int D = 40, QB = 2, KS = 3, DVT = 2;
+  constexpr int KROW = 112;                    // 7 chunks: 5 data, 1 pad columns (bias columns), 1 spare
+  constexpr int K_BYTES = KVT * KROW;          // 7168
+  constexpr int V_BYTES = 64 * 128;            // rows 0..39 data, 40 ones, 41..63 zero
+  constexpr int STAGE = K_BYTES + V_BYTES;     // 15360
+  constexpr int LT = D / 32, LH = ((D % 32) >> 2) & 1, LR = ((D % 32) & 3) + 4 * ((D % 32) >> 3);
+  __shared__ __attribute__((aligned(16))) char smem[DM_NST * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  int b, head, qt;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
+    const int w = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int nqt = (a.Sq + 255) / 256;
+    qt = w % nqt;
+    const int bh = w / nqt;
+    head = bh % a.heads;
+    b = bh / a.heads;
+  }
+  const int q0 = qt * 256 + wid * 64;
+  const bf16* __restrict__ Q = a.q + (int64_t)b * a.qb + head * D;
+  const bf16* __restrict__ Kp = a.k + (int64_t)b * a.kb + head * D;
+  const bf16* __restrict__ Vt = a.vt + (int64_t)b * a.vtb + (int64_t)head * D * a.ldvt;
+  const uint64_t pk = (uint64_t)Kp, pv = (uint64_t)Vt;
+  const unsigned k_bytes = (unsigned)(((int64_t)a.Skv - 1) * a.ldk * 2 + D * 2);
+  const unsigned v_bytes = (unsigned)(((int64_t)D - 1) * a.ldvt * 2 + ((a.Skv + 7) / 8 * 8) * 2);
+  const v4i srdK = {(int)(unsigned)pk, (int)((pk >> 32) & 0xffff), (int)k_bytes, 0x00020000};
+  const v4i srdV = {(int)(unsigned)pv, (int)((pv >> 32) & 0xffff), (int)v_bytes, 0x00020000};
+  constexpr unsigned OOB = 0x80000000u;
+
+  // ---- this wave's three DMA instructions of a tile: indices wid, wid + 4, wid + 8 of (K0..K6, V0..V4) -------------------------
+  unsigned voff[3];            // per lane: byte offset inside the (sample, head) K or V^T view at tile 0 (OOB: lane inactive)
+  int vrow_kv[3];              // K: key (within the tile) this lane's row holds; V: first key of this lane's chunk
+  unsigned lds_off[3];         // wave-uniform: byte offset of the instruction's 1-KiB piece inside a stage
+  bool is_k[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int idx = wid + 4 * j;
+    is_k[j] = idx < 7;
+    if (is_k[j]) {
+      const int slot = idx * 64 + lane;                 // 448 = 64 rows x 7 chunks
+      const int rs = slot / 7, c = slot - rs * 7;
+      const int rho = rs & 31;
+      const int kv = (rs & 32) + (rho & 16) + ((rho & 4) << 1) + ((rho & 8) >> 1) + (rho & 3);   // swap bits 2 and 3
+      vrow_kv[j] = kv;
+      voff[j] = c < 5 ? (unsigned)(kv * a.ldk * 2 + c * 16) : OOB;
+      lds_off[j] = (unsigned)(idx * 1024);
+    } else {
+      const int slot = (idx - 7) * 64 + lane;           // 320 = 40 rows x 8 chunk positions
+      const int row = slot >> 3, pos = slot & 7;
+      const int c = pos ^ ((row >> 1) & 7);
+      vrow_kv[j] = 8 * c;
+      voff[j] = (unsigned)(row * a.ldvt * 2 + c * 16);
+      lds_off[j] = (unsigned)(K_BYTES + (idx - 7) * 1024);
+    }
+  }
+  const unsigned smem_base = (unsigned)(uintptr_t)smem;
+  const int ntiles = (a.Skv + KVT - 1) / KVT;
+  const bool ragged = (a.Skv % KVT) != 0;
+  auto issue = [&](int t) {
+    const unsigned st = smem_base + (unsigned)((t % DM_NST) * STAGE);
+    const bool last = ragged && t == ntiles - 1;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      unsigned vo = voff[j];
+      if (last && t * KVT + vrow_kv[j] >= a.Skv) vo = OOB;
+      if (is_k[j]) {
+        // pad-column lanes (chunks 5, 6) are masked off: their LDS bytes keep the bias-column constants
+        if (voff[j] != OOB) dma16(srdK, vo, t * KVT * a.ldk * 2, __builtin_amdgcn_readfirstlane(st + lds_off[j]));
+      } else {
+        dma16(srdV, vo, t * KVT * 2, __builtin_amdgcn_readfirstlane(st + lds_off[j]));
+      }
+    }
+  };
+
+  // ---- Q^T fragments, pre-multiplied by scale * log2(e) ----------------------------------------------------------------------
+  const float c = a.scale * 1.4426950408889634f;
+  bf16x8 qf[QB][KS];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int q = q0 + 32 * qb + r;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int col = ks * 16 + h * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (q < a.Sq && col < D) v = *(const uint4*)(Q + (int64_t)q * a.ldq + col);
+      qf[qb][ks] = *(bf16x8*)&v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[qb][ks][j] = (bf16)((float)qf[qb][ks][j] * c);
+    }
+  }
+  // ---- once per stage: K bias columns (1, 1, 1, 0...) and the spare chunk; V^T ones row 40 and zero rows 41..63 --------------
+#pragma unroll
+  for (int st = 0; st < DM_NST; ++st) {
+    char* const sK = smem + st * STAGE;
+    char* const sV = sK + K_BYTES;
+    if (tid < KVT) {
+      *(uint4*)(sK + tid * KROW + 80) = make_uint4(0x3F803F80u, 0x00003F80u, 0, 0);
+      *(uint4*)(sK + tid * KROW + 96) = make_uint4(0, 0, 0, 0);
+    }
+    for (int i = tid; i < 24 * 8; i += 256) {
+      const int row = 40 + i / 8, pos = i & 7;
+      *(uint4*)(sV + row * 128 + pos * 16) = row == 40 ? make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u) : make_uint4(0, 0, 0, 0);
+    }
+  }
+  __syncthreads();   // the constants are in place before any DMA lands next to them (and LDS-DMA writes are not ordered with ds_writes)
+
+  f32x16 O[QB][DVT];
+  float m_run[QB];
+  constexpr float TAU = 6.f;
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+    for (int i = 0; i < DVT; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) O[qb][i][j] = 0.f;
+    m_run[qb] = 0.f;
+  }
+
+  issue(0);
+  if (ntiles > 1) issue(1);
+  for (int t = 0; t < ntiles; ++t) {
+    if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                       // tile t is in LDS for everybody; everybody is done reading tile t - 1
+    if (t + 2 < ntiles) issue(t + 2);      // into the stage tile t - 1 used
+    const char* const sK = smem + (t % DM_NST) * STAGE;
+    const char* const sV = sK + K_BYTES;
+
+    f32x16 S0[QB], S1[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { S0[qb][j] = 0.f; S1[qb][j] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8 a0 = *(const bf16x8*)(sK + r * KROW + (ks * 2 + h) * 16);
+      const bf16x8 a1 = *(const bf16x8*)(sK + (32 + r) * KROW + (ks * 2 + h) * 16);
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        S0[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[qb][ks], S0[qb], 0, 0, 0);
+        S1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[qb][ks], S1[qb], 0, 0, 0);
+      }
+    }
+    // V^T fragments of this tile: one 16-byte read each, issued now so that their latency runs under the softmax
+    uint4 vfr[4 * DVT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int dt = 0; dt < DVT; ++dt) {
+        const int row = 32 * dt + r;
+        vfr[i * DVT + dt] = *(const uint4*)(sV + row * 128 + (((2 * i + h) ^ ((row >> 1) & 7)) << 4));
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    if (t * KVT + KVT > a.Skv) {           // keys past Skv: slot 8 (j >> 2) + 4 h + (j & 3) of a 32-slot block holds key 16 (j >> 3) + 8 h + 4 ((j >> 2) & 1) + (j & 3)
+      const int base = t * KVT + 8 * h;
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int kv = 16 * (j >> 3) + 4 * ((j >> 2) & 1) + (j & 3);
+          if (base + kv >= a.Skv) S0[qb][j] = -INFINITY;
+          if (base + 32 + kv >= a.Skv) S1[qb][j] = -INFINITY;
+        }
+    }
+    float mx[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      float v = fmaxf(S0[qb][0], S1[qb][0]);
+#pragma unroll
+      for (int j = 1; j < 16; ++j) v = max3(v, S0[qb][j], S1[qb][j]);
+      mx[qb] = max_xor32(v);
+    }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      if (t == 0 || __any(mx[qb] > TAU)) {
+        const float delta = (t == 0 || mx[qb] > 0.f) ? mx[qb] : 0.f;
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+        m_run[qb] += delta;
+#pragma unroll
+        for (int i = 0; i < DVT; ++i)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) O[qb][i][j] *= alpha;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { S0[qb][j] -= delta; S1[qb][j] -= delta; }
+        const float v0 = -m_run[qb];
+        const bf16 p1 = (bf16)v0;
+        const float r1 = v0 - (float)p1;
+        const bf16 p2 = (bf16)r1;
+        const bf16 p3 = (bf16)(r1 - (float)p2);
+        if (h == 1) { qf[qb][KS - 1][0] = p1; qf[qb][KS - 1][1] = p2; qf[qb][KS - 1][2] = p3; }
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        S0[qb][j] = __builtin_amdgcn_exp2f(S0[qb][j]);
+        S1[qb][j] = __builtin_amdgcn_exp2f(S1[qb][j]);
+      }
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 pf[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[qb][j] = (bf16)(st == 0 ? S0[qb][8 * s2 + j] : S1[qb][8 * s2 + j]);
+#pragma unroll
+        for (int dt = 0; dt < DVT; ++dt) {
+          const uint4 v = vfr[(2 * st + s2) * DVT + dt];
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb)
+            O[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&v, pf[qb], O[qb][dt], 0, 0, 0);
+        }
+      }
+  }
+
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const float l_tot = __shfl(O[qb][LT][LR], r + 32 * LH);
+    const float inv = 1.f / l_tot;
+    const int q = q0 + 32 * qb + r;
+    if (q < a.Sq) {
+      bf16* orow = a.out + (int64_t)b * a.ob + (int64_t)q * a.ldo + head * D;
+#pragma unroll
+      for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int dd = 32 * dt + 8 * g + 4 * h;
+          if (dd < D) {
+            bf16x4 w;
+            w[0] = (bf16)(O[qb][dt][4 * g + 0] * inv);
+            w[1] = (bf16)(O[qb][dt][4 * g + 1] * inv);
+            w[2] = (bf16)(O[qb][dt][4 * g + 2] * inv);
+            w[3] = (bf16)(O[qb][dt][4 * g + 3] * inv);
+            *(bf16x4*)(orow + dd) = w;
+          }
+        }
+    }
+  }
+}
+
 template <int D>
 void launch(const AttnArgs& a, hipStream_t s) {
   // Two query blocks per wave (QB = 2) when the registers allow two waves per SIMD (d <= 64: 222 VGPRs):
@@ -371,6 +637,11 @@ void launch(const AttnArgs& a, hipStream_t s) {
   static const int hv_env = getenv("SVG_ATTN_HV") ? atoi(getenv("SVG_ATTN_HV")) : 1;   // same-box A/B at 28 x 8 x 4096^2 x 40: 1.006 vs 1.026 ms
   constexpr int QB = (D <= 64) ? 2 : 1;
   constexpr bool CAN_BC = (D % 16) == 8;        // three spare pad columns in lane-half 1 of the last k-step (d = 8, 40)
+  static const int dma_env = getenv("SVG_ATTN_DMA") ? atoi(getenv("SVG_ATTN_DMA")) : 1;
+  if (D == 40 && dma_env && qb_env == 2 && bc_env && a.Sq >= 512) {
+    hipLaunchKernelGGL(attn_dma40_kernel, dim3(cdiv(a.Sq, 256) * a.heads * a.B), dim3(256), 0, s, a);
+    return;
+  }
   if (QB == 2 && qb_env == 2 && a.Sq >= 512) {
     dim3 grid(cdiv(a.Sq, 256) * a.heads * a.B);
     if (CAN_BC && bc_env && hv_env) hipLaunchKernelGGL((attn_kernel<D, QB, 1, CAN_BC, true>), grid, dim3(256), 0, s, a);

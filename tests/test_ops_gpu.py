@@ -228,7 +228,7 @@ def attention_ref(q, k, v, heads):
 
 @pytest.mark.parametrize("B,heads,Sq,Skv,d", [(1, 8, 4096, 4096, 40), (2, 8, 1024, 1024, 80), (2, 8, 256, 256, 160),
                                              (1, 8, 64, 64, 160), (2, 8, 4096, 77, 40), (1, 8, 256, 77, 160),
-                                             (1, 4, 100, 130, 16), (2, 2, 33, 65, 32), (1, 8, 1024, 77, 80), (1, 2, 200, 300, 8)])
+                                             (1, 4, 100, 130, 16), (2, 2, 33, 65, 32), (1, 8, 1024, 77, 80), (1, 2, 200, 300, 8), (1, 2, 600, 1000, 40), (2, 3, 513, 64, 40)])
 def test_attention(ctx, B, heads, Sq, Skv, d):
     g = torch.Generator(device="cuda").manual_seed(Sq + Skv + d)
     Cc = heads * d
