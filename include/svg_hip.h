@@ -111,6 +111,10 @@ typedef struct svg_train_cfg {
  * losses: host float[5] = {total, mse, l1, gdl, contrastive} (synchronises the stream), or NULL.  B <= 64, Ts, Tt <= 32. */
 int svg_transformer_loss(svg_ctx* ctx, const svg_train_cfg* cfg, const float* src, const float* tgt, const float* expected,
                          const float* text, int B, int Ts, int Tt, const float* mask, int backward, float* losses, void* stream);
+/* The train-mode forward on its own (models/transformer.py:47-68 with model.train(): dropout active, same sites and masks as
+ * svg_transformer_loss with this seed); out (Tt,B,D_lat).  text: (B,text_dim) for the text-conditioned variant, else NULL. */
+int svg_transformer_forward_train(svg_ctx* ctx, const float* src, const float* tgt, const float* text, int B, int Ts, int Tt,
+                                  const float* mask, float dropout_p, uint64_t seed, float* out, void* stream);
 /* torch.optim.Adam(lr, betas=(beta1, beta2), eps) step on the gradients of the last svg_transformer_loss(backward=1)
  * (trainer.py:365: optim.Adam(model.parameters(), lr=lr) -> betas (0.9, 0.999), eps 1e-8, no weight decay). */
 int svg_transformer_adam_step(svg_ctx* ctx, float lr, float beta1, float beta2, float eps, void* stream);

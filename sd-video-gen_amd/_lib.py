@@ -42,6 +42,7 @@ SIGNATURES = {
     "svg_transformer_forward": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "svg_transformer_forward_text": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "svg_transformer_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp],
+    "svg_transformer_forward_train": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _f, C.c_uint64, _vp, _vp],
     "svg_transformer_adam_step": [_vp, _f, _f, _f, _f, _vp],
     "svg_transformer_tensor": [_vp, _i, C.c_char_p, _vp, _i64, _vp],
     "svg_clip_text_forward": [_vp, _vp, _i, _i, _vp, _vp],
@@ -216,6 +217,19 @@ class Context:
         if out is None:
             return None
         return dict(zip(("total", "mse", "l1", "gdl", "contrastive"), [float(v) for v in out]))
+
+    def transformer_forward_train(self, src, tgt, mask=None, text=None, dropout_p=0.1, seed=0):
+        """train-mode forward (dropout active) -> (Tt, B, D_lat)"""
+        B, Ts, D = src.shape
+        Tt = tgt.shape[1]
+        src = src.contiguous().float()
+        tgt = tgt.contiguous().float()
+        mask = mask.contiguous().float() if mask is not None else None
+        text = text.to(device=src.device, dtype=torch.float32).contiguous() if text is not None else None
+        out = torch.empty((Tt, B, D), device=src.device, dtype=torch.float32)
+        self.check(self.lib.svg_transformer_forward_train(self.h, _ptr(src), _ptr(tgt), _ptr(text), B, Ts, Tt, _ptr(mask), float(dropout_p),
+                                                          int(seed) & (2 ** 64 - 1), _ptr(out), _stream()), "svg_transformer_forward_train")
+        return out
 
     def transformer_adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8):
         self.check(self.lib.svg_transformer_adam_step(self.h, lr, betas[0], betas[1], eps, _stream()), "svg_transformer_adam_step")

@@ -201,20 +201,23 @@ void ensure_train(svg_ctx* ctx, XfModel* m) {
   m->train = tr.release();
 }
 
+// expected == nullptr: forward only (train-mode dropout when backward != 0), the prediction (Tt,B,D_lat) goes to pred_out
 void loss_pass(svg_ctx* ctx, XfModel* m, const svg_train_cfg& cfg, const float* src, const float* tgt, const float* expected, const float* text,
-               int B, int Ts, int Tt, const float* mask, int backward, float* losses_host, hipStream_t s) {
+               int B, int Ts, int Tt, const float* mask, int backward, float* losses_host, hipStream_t s, float* pred_out = nullptr) {
   SVG_CHECK(m->ready, "transformer: svg_finalize has not been called");
   SVG_CHECK((m->text_dim > 0) == (text != nullptr), "transformer: the text-conditioned variant needs (and only it takes) a text embedding");
   SVG_CHECK(B >= 1 && B <= 64 && Ts >= 1 && Tt >= 1 && Ts <= 32 && Tt <= 32, "transformer training: B=%d Ts=%d Tt=%d unsupported (B <= 64, T <= 32)", B, Ts, Tt);
-  SVG_CHECK(cfg.frames_to_predict >= 1 && cfg.frames_to_predict <= Tt, "frames_to_predict %d out of range 1..%d", cfg.frames_to_predict, Tt);
   SVG_CHECK(cfg.dropout_p >= 0.f && cfg.dropout_p < 1.f, "dropout_p %g out of range", cfg.dropout_p);
-  SVG_CHECK(cfg.feat_h > 0 && cfg.feat_w > 0 && 4 * cfg.feat_h * cfg.feat_w == m->d_lat, "criterion: D_lat %d is not 4 x %d x %d", m->d_lat,
-            cfg.feat_h, cfg.feat_w);
-  SVG_CHECK(cfg.w_contrastive == 0.f || (cfg.temperature > 0.f && cfg.feat_h * cfg.feat_w <= 4096), "contrastive loss: bad temperature / patch count");
+  if (expected) {
+    SVG_CHECK(cfg.frames_to_predict >= 1 && cfg.frames_to_predict <= Tt, "frames_to_predict %d out of range 1..%d", cfg.frames_to_predict, Tt);
+    SVG_CHECK(cfg.feat_h > 0 && cfg.feat_w > 0 && 4 * cfg.feat_h * cfg.feat_w == m->d_lat, "criterion: D_lat %d is not 4 x %d x %d", m->d_lat,
+              cfg.feat_h, cfg.feat_w);
+    SVG_CHECK(cfg.w_contrastive == 0.f || (cfg.temperature > 0.f && cfg.feat_h * cfg.feat_w <= 4096), "contrastive loss: bad temperature / patch count");
+  }
   ensure_train(ctx, m);
   XfTrain* tr = m->train;
   const int d = m->d_model, Ms = Ts * B, Mt = Tt * B;
-  const uint64_t shape_key = ((uint64_t)B << 40) | ((uint64_t)Ts << 24) | ((uint64_t)Tt << 8) | (uint64_t)(backward ? 1 : 0);
+  const uint64_t shape_key = ((uint64_t)B << 40) | ((uint64_t)Ts << 24) | ((uint64_t)Tt << 8) | (uint64_t)(backward ? 1 : 0) | (expected ? 0u : 2u);
   auto body = [&]() {
     Run r{ctx, m, tr, s, B, cfg.seed, backward ? cfg.dropout_p : 0.f, backward != 0};
     r.text = text;
@@ -241,6 +244,10 @@ void loss_pass(svg_ctx* ctx, XfModel* m, const svg_train_cfg& cfg, const float* 
     }
     xt = r.add_ln(n_dec, xt, nullptr, "transformer.decoder.norm.", Mt, false);
     float* pred = r.lin(l_out, xt, "out.weight", "out.bias", Mt, m->d_lat, d);
+    if (!expected) {                                           // forward only
+      if (r.go()) HIP_OK(hipMemcpyAsync(pred_out, pred, (size_t)Mt * m->d_lat * sizeof(float), hipMemcpyDeviceToDevice, s));
+      return;
+    }
 
     // criterion on the last frames_to_predict positions (trainer.py:145)
     float* dpred = r.get<float>((int64_t)Mt * m->d_lat);
@@ -319,6 +326,19 @@ extern "C" int svg_transformer_loss(svg_ctx* ctx, const svg_train_cfg* cfg, cons
     SVG_CHECK(ctx && ctx->xf, "transformer: model not configured");
     SVG_CHECK(cfg && src && tgt && expected, "svg_transformer_loss: null argument");
     loss_pass(ctx, ctx->xf, *cfg, src, tgt, expected, text, B, Ts, Tt, mask, backward, losses, (hipStream_t)stream);
+    return 0;
+  } catch (const std::exception& e) { return svg_fail(ctx, e); }
+}
+
+extern "C" int svg_transformer_forward_train(svg_ctx* ctx, const float* src, const float* tgt, const float* text, int B, int Ts, int Tt,
+                                             const float* mask, float dropout_p, uint64_t seed, float* out, void* stream) {
+  try {
+    SVG_CHECK(ctx && ctx->xf, "transformer: model not configured");
+    SVG_CHECK(src && tgt && out, "svg_transformer_forward_train: null argument");
+    svg_train_cfg cfg{};
+    cfg.dropout_p = dropout_p;
+    cfg.seed = seed;
+    loss_pass(ctx, ctx->xf, cfg, src, tgt, nullptr, text, B, Ts, Tt, mask, /*train mode*/ 1, nullptr, (hipStream_t)stream, out);
     return 0;
   } catch (const std::exception& e) { return svg_fail(ctx, e); }
 }

@@ -30,7 +30,67 @@ class PositionalEncoding(nn.Module):
         self.register_buffer("pos_encoding", pos_encoding.unsqueeze(0).transpose(0, 1))
 
 
-class Transformer(nn.Module):
+class LibraryTraining:
+    """Training-step methods shared by the two host models (this file and transformer_text.py).  The optimisation runs inside
+    the library on the uploaded copy of the weights (gradients and Adam moments live there); the nn.Parameters of the module
+    are refreshed from it by pull_weights(), which state_dict() does on its own."""
+    _train_seed = 0
+
+    def _text_of(self, cls_list):
+        return None
+
+    def training_loss(self, cfg, new_batch, tgt_mask=None, cls_list=None, backward=True, read_losses=True):
+        """Loss of one trainer iteration on the encoded batch `new_batch` (B, T, D_lat): src = new_batch, tgt = new_batch[:, :-1],
+        expected = new_batch[:, 1:] (trainers/trainer.py:124-145; trainer_text.py passes the class names as well).  backward=True
+        runs in train mode (dropout_p of `cfg`) and leaves the gradients in the library for adam_step(); False is the validation
+        loss (eval mode).  -> dict of the loss terms."""
+        if not new_batch.is_cuda:
+            raise RuntimeError("the training step runs on the HIP library and needs CUDA tensors; there is no CPU fallback")
+        ctx = self._sync_weights()
+        y_input = new_batch[:, :-1]
+        if tgt_mask is None:
+            tgt_mask = self.get_tgt_mask(y_input.size(1)).to(new_batch.device)
+        return ctx.transformer_loss(cfg, new_batch, y_input, new_batch[:, 1:], tgt_mask, self._text_of(cls_list), backward, read_losses)
+
+    def _forward_train(self, src, tgt, tgt_mask, text):
+        """model.train() forward: dropout with a fresh seed per call (the masks are a function of (seed, site, element))"""
+        ctx = self._sync_weights()
+        LibraryTraining._train_seed += 1
+        return ctx.transformer_forward_train(src, tgt, tgt_mask, text, self.positional_encoder.dropout_p, LibraryTraining._train_seed)
+
+    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8):
+        ctx = self._sync_weights()
+        ctx.transformer_adam_step(lr, betas, eps)
+        self._lib_ahead = True
+
+    def pull_weights(self):
+        """copies the library's (trained) weights back into this module's parameters"""
+        if not getattr(self, "_lib_ahead", False):
+            return
+        ctx = self._ctx
+        if ctx is None or ctx.owner(_lib.SVG_TRANSFORMER) is not self:
+            raise RuntimeError("the library slot that held this module's trained weights was taken by another model before pull_weights()")
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                p.copy_(ctx.transformer_tensor(name, p).to(p.device))
+        self._lib_ahead = False
+        self._uploaded_version = self._weights_version()      # the copy in the library IS these parameters: no re-upload
+
+    def grad_of(self, name):
+        """gradient of parameter `name` from the last training_loss(backward=True), as a CPU tensor"""
+        return self._ctx.transformer_tensor(name, dict(self.named_parameters())[name], _lib.SVG_TENSOR_GRAD)
+
+    def state_dict(self, *a, **k):
+        self.pull_weights()
+        return super().state_dict(*a, **k)
+
+    def _check_not_ahead(self):
+        if getattr(self, "_lib_ahead", False):
+            raise RuntimeError("this module's trained weights live in a library slot that was taken over (or its parameters were "
+                               "modified on the host) before pull_weights(); call state_dict()/pull_weights() after training steps")
+
+
+class Transformer(LibraryTraining, nn.Module):
     def __init__(self, num_tokens=0, dim_model=256, num_heads=8, num_encoder_layers=6,
                  num_decoder_layers=6, dropout_p=0.1):
         super().__init__()
@@ -69,9 +129,7 @@ class Transformer(nn.Module):
         # since the last call: upload again unless the slot still holds THIS module's current parameters
         if self._ctx is ctx and ctx.owner(_lib.SVG_TRANSFORMER) is self and self._uploaded_version == self._weights_version():
             return ctx
-        if getattr(self, "_lib_ahead", False):
-            raise RuntimeError("this module's trained weights live in a library slot that was taken over (or its parameters were "
-                               "modified on the host) before pull_weights(); call state_dict()/pull_weights() after training steps")
+        self._check_not_ahead()
         self._ctx = ctx
         ctx.configure(_lib.SVG_TRANSFORMER, d_lat=self.d_lat, d_model=self.dim_model, heads=self.num_heads,
                       enc_layers=self.num_encoder_layers, dec_layers=self.num_decoder_layers,
@@ -88,57 +146,17 @@ class Transformer(nn.Module):
         self._lib_ahead = False
         return r
 
-    # ---- training step (trainers/trainer.py:111-190) ---------------------------------------------------
-    # The optimisation runs inside the library on the uploaded copy of the weights (gradients and Adam moments live there);
-    # the nn.Parameters of this module are refreshed from it by pull_weights(), which state_dict() does on its own.
-    def training_loss(self, cfg, new_batch, tgt_mask=None, text=None, backward=True, read_losses=True):
-        """Loss of one trainer iteration on the encoded batch `new_batch` (B, T, D_lat): src = new_batch, tgt = new_batch[:, :-1],
-        expected = new_batch[:, 1:] (trainer.py:124-145).  backward=True runs in train mode (dropout_p of `cfg`) and leaves the
-        gradients in the library for adam_step(); False is the validation loss (eval mode).  -> dict of the loss terms."""
-        if not new_batch.is_cuda:
-            raise RuntimeError("the training step runs on the HIP library and needs CUDA tensors; there is no CPU fallback")
-        ctx = self._sync_weights()
-        y_input = new_batch[:, :-1]
-        if tgt_mask is None:
-            tgt_mask = self.get_tgt_mask(y_input.size(1)).to(new_batch.device)
-        return ctx.transformer_loss(cfg, new_batch, y_input, new_batch[:, 1:], tgt_mask, text, backward, read_losses)
-
-    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8):
-        ctx = self._sync_weights()
-        ctx.transformer_adam_step(lr, betas, eps)
-        self._lib_ahead = True
-
-    def pull_weights(self):
-        """copies the library's (trained) weights back into this module's parameters"""
-        if not getattr(self, "_lib_ahead", False):
-            return
-        ctx = self._ctx
-        if ctx is None or ctx.owner(_lib.SVG_TRANSFORMER) is not self:
-            raise RuntimeError("the library slot that held this module's trained weights was taken by another model before pull_weights()")
-        with torch.no_grad():
-            for name, p in self.named_parameters():
-                p.copy_(ctx.transformer_tensor(name, p).to(p.device))
-        self._lib_ahead = False
-        self._uploaded_version = self._weights_version()      # the copy in the library IS these parameters: no re-upload
-
-    def grad_of(self, name):
-        """gradient of parameter `name` from the last training_loss(backward=True), as a CPU tensor"""
-        return self._ctx.transformer_tensor(name, dict(self.named_parameters())[name], _lib.SVG_TENSOR_GRAD)
-
-    def state_dict(self, *a, **k):
-        self.pull_weights()
-        return super().state_dict(*a, **k)
-
     # ---- forward (transformer.py:47-68) ---------------------------------------------------------------
     def forward(self, src, tgt, tgt_mask=None, src_pad_mask=None, tgt_pad_mask=None, pe_row=None):
-        if self.training and self.positional_encoder.dropout_p > 0:
-            raise RuntimeError("forward() is the eval-mode sampling path (dropout off): call model.eval(); the train-mode forward "
-                               "is part of training_loss()")
         if src_pad_mask is not None or tgt_pad_mask is not None:
-            raise NotImplementedError("key-padding masks are not on the sampling path (predict.py passes none)")
+            raise NotImplementedError("key-padding masks: no caller of the reference passes one (predict.py:36, trainer.py:141)")
         if not src.is_cuda:
             raise RuntimeError("Transformer.forward runs on the HIP library and needs CUDA tensors; "
                                "there is no CPU fallback")
+        if self.training and self.positional_encoder.dropout_p > 0:
+            if pe_row is not None:
+                raise NotImplementedError("pe_row is a sampling-path argument (eval mode)")
+            return self._forward_train(src, tgt, tgt_mask, None)
         ctx = self._sync_weights()
         return ctx.transformer_forward(src, tgt, tgt_mask, pe_row)
 

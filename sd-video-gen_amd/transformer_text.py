@@ -12,12 +12,12 @@ import torch.nn as nn
 
 from . import _lib
 from .config import parse_config_args
-from .transformer import PositionalEncoding
+from .transformer import LibraryTraining, PositionalEncoding
 
 TEXT_EMBED_DIM = 384
 
 
-class Transformer(nn.Module):
+class Transformer(LibraryTraining, nn.Module):
     def __init__(self, num_tokens=0, dim_model=256, num_heads=8, num_encoder_layers=6, num_decoder_layers=6,
                  dropout_p=0.1, text_encoder=None):
         super().__init__()
@@ -51,6 +51,11 @@ class Transformer(nn.Module):
             out.append(v / v.norm())
         return torch.stack(out)
 
+    def _text_of(self, cls_list):
+        if cls_list is None:
+            raise ValueError("the text-conditioned model needs the class names (or a (B,384) tensor) of the batch")
+        return cls_list if isinstance(cls_list, torch.Tensor) else self.encode_classes(cls_list)
+
     def use_context(self, ctx):
         self._bound_ctx = ctx
         self._uploaded_version = None
@@ -65,6 +70,7 @@ class Transformer(nn.Module):
         # since the last call: upload again unless the slot still holds THIS module's current parameters
         if self._ctx is ctx and ctx.owner(_lib.SVG_TRANSFORMER) is self and self._uploaded_version == self._weights_version():
             return ctx
+        self._check_not_ahead()
         self._ctx = ctx
         ctx.configure(_lib.SVG_TRANSFORMER, d_lat=self.d_lat, d_model=self.dim_model, heads=self.num_heads,
                       enc_layers=self.num_encoder_layers, dec_layers=self.num_decoder_layers, text_dim=self.text_embed_dim,
@@ -83,17 +89,18 @@ class Transformer(nn.Module):
         state_dict = {n: t for n, t in state_dict.items() if not n.startswith("sent_transformer.")}
         r = super().load_state_dict(state_dict, *a, **k)
         self._uploaded_version = None
+        self._lib_ahead = False
         return r
 
     def forward(self, src, cls_list, tgt, tgt_mask=None, src_pad_mask=None, tgt_pad_mask=None, pe_row=None):
         """transformer_text.py:71-111.  ``cls_list``: class names (one per batch row) or a (B,384) tensor."""
-        if self.training and self.positional_encoder.dropout_p > 0:
-            raise RuntimeError("the HIP path implements eval-mode sampling (dropout off); call model.eval()")
         if src_pad_mask is not None or tgt_pad_mask is not None:
-            raise NotImplementedError("key-padding masks are not on the sampling path")
+            raise NotImplementedError("key-padding masks: no caller of the reference passes one")
         if not src.is_cuda:
             raise RuntimeError("Transformer.forward runs on the HIP library and needs CUDA tensors; there is no CPU fallback")
-        txt = cls_list if isinstance(cls_list, torch.Tensor) else self.encode_classes(cls_list)
+        txt = self._text_of(cls_list)
+        if self.training and self.positional_encoder.dropout_p > 0:
+            return self._forward_train(src, tgt, tgt_mask, txt)
         ctx = self._sync_weights()
         return ctx.transformer_forward(src, tgt, tgt_mask, pe_row, text=txt)
 

@@ -230,3 +230,54 @@ def test_trainer_fit_end_to_end(tmp_path, monkeypatch):
     cfg = loss_fn.cfg(3)
     a, b = model.training_loss(cfg, nb, backward=False), again.training_loss(cfg, nb, backward=False)
     assert a["total"] == b["total"] and abs(a["total"] - val_loss) < 0.1 * val_loss
+
+
+def test_train_mode_forward_is_the_dropout_forward(ctx):
+    """model.train(); model(src, tgt, mask) (models/transformer.py:47-68 with dropout active) = the oracle forward with the masks of
+    the seed the call used; model.eval() gives the sampling path's result."""
+    sd = torch.load(os.path.join(GOLD, "transformer_tiny.pt"))["state_dict"]
+    p = 0.3
+    m = make_model("model_10_26", ctx, sd, dropout_p=p, dim_model=32, num_heads=4, num_encoder_layers=1, num_decoder_layers=2)
+    from sd_video_gen_amd.transformer import LibraryTraining
+    torch.manual_seed(8)
+    X = torch.randn(3, 6, 256)
+    mask = TO.get_tgt_mask(5)
+    m.train()
+    out = m(X.cuda(), X[:, :-1].cuda(), mask.cuda())
+    seed, site = LibraryTraining._train_seed, [0]
+
+    def drop(x):
+        mk = ctx.dropout_mask(seed, site[0], p, x.numel()).cpu().reshape(x.shape)
+        site[0] += 1
+        return x * mk
+    ref = TO.forward(sd, X, X[:, :-1], 4, mask, drop=drop)
+    assert rel_l2(out.cpu(), ref) < 5e-6
+    out2 = m(X.cuda(), X[:, :-1].cuda(), mask.cuda())
+    assert rel_l2(out2.cpu(), ref) > 1e-2                                  # next call: next seed, other masks
+    m.eval()
+    assert rel_l2(m(X.cuda(), X[:, :-1].cuda(), mask.cuda()).cpu(), TO.forward(sd, X, X[:, :-1], 4, mask)) < 5e-6
+
+
+def test_text_variant_training_step(ctx):
+    """trainers/trainer_text.py's step: the text-conditioned model (token = cat(proj(x), class embedding)) through the same library
+    path (text_dim = 384: the embedding gradient covers the image channels only)."""
+    from sd_video_gen_amd.transformer_text import Transformer as TextTransformer
+    svg_config.set_args(["--dataset", "ball", "--config", "model_10_26"])
+    torch.manual_seed(31)
+    m = TextTransformer(dim_model=16, num_heads=4, num_encoder_layers=1, num_decoder_layers=1, dropout_p=0.0).use_context(ctx)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    names = ["Archery", "WallPushups", "Archery"]
+    txt = m.encode_classes(names)
+    nb = torch.cat([2.0 * torch.ones(3, 1, 256), torch.randn(3, 5, 256)], dim=1)
+    w = dict(w_mse=1.0, w_gdl=1.0, alpha=2)
+    leaves = TR.leaf_state(sd)
+    total, _ = TR.loss(leaves, 4, nb, 2, 8, txt=txt, **w)
+    total.backward()
+    m.train()
+    got = m.training_loss(cfg_of(2, 8, w), nb.cuda(), cls_list=names)
+    assert abs(got["total"] - float(total)) <= 5e-6 * abs(float(total))
+    check_grads(m, leaves, "text variant d = 400")
+    with pytest.raises(ValueError):
+        m.training_loss(cfg_of(2, 8, w), nb.cuda())                        # class names are required
+    m.adam_step(1e-3)
+    assert not torch.equal(m.state_dict()["project_image_embedding.weight"].cpu(), sd["project_image_embedding.weight"])
