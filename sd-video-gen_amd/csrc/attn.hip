@@ -380,7 +380,12 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
 // wave nor between the two unsynchronised waves of a SIMD.  A variant that runs the two query blocks of a wave half a tile apart
 // (every MFMA group beside the other block's independent exp2 / max VALU in the same stream, sched_group_barrier interleave, four
 // LDS stages, tail keys masked through a -1e30 pad column instead of a pass over S) was correct and NOT faster (1.02-1.06 ms);
-// AGPR-form accumulators (no -amdgpu-mfma-vgpr-form) 1.26-1.65 ms.
+// AGPR-form accumulators (no -amdgpu-mfma-vgpr-form) 1.26-1.65 ms.  tools/probe/probe_overlap.hip shows why the costs add: in ONE
+// wave's stream 4 MFMAs + 16 v_exp take 180 cycles (140 / 160 alone), but an MFMA-phase wave beside a VALU-phase wave on the same
+// SIMD takes 400 — two unsynchronised workgroups per CU are exactly that.  The consequent form — one workgroup per CU, each region
+// a hand-ordered volatile-asm stream of 14 MFMAs with 4 v_exp / 2 cvt / 3 max between them and the LDS fragment reads six groups
+// ahead — was also correct and slower still (1.23-1.28 ms): at one wave per SIMD nothing covers the per-tile barrier, the DMA issue
+// code and the dependent max chain.
 constexpr int DM_NST = 3;
 __global__ void __launch_bounds__(256) attn_dma40_kernel(const AttnArgs a) {
   constexpr int D = 40, QB = 2, KS = 3, DVT = 2;
