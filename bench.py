@@ -209,6 +209,9 @@ def roofline_pass(args, sd_utils, step, denoise, C):
             continue
         e.update(launches=v["calls"], ms=v["ms"], share_of_kernel_time=v["ms"] / tot_ms, avg_launch_ms=v["ms"] / v["calls"],
                  algorithmic_bytes_per_launch=v["bytes"] / v["calls"], traffic=None)
+        if e["bound"] == "mfma":      # the other ceiling, for the short-K shapes whose operands bound them before the matrix pipe does
+            e["algorithmic_gb_per_s"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+            e["frac_of_hbm_peak"] = e["algorithmic_gb_per_s"] / (PEAK_HBM / 1e9)
         if pmc and k in pmc[1]["families"] and pmc[1]["families"][k]["launches"] == v["calls"]:
             e["traffic"] = pmc[1]["families"][k]["hbm_bytes_per_launch"]
             e["traffic_source"] = "profiles/%s (%s)" % (pmc[0], pmc[1].get("note", ""))
