@@ -281,3 +281,17 @@ def test_text_variant_training_step(ctx):
         m.training_loss(cfg_of(2, 8, w), nb.cuda())                        # class names are required
     m.adam_step(1e-3)
     assert not torch.equal(m.state_dict()["project_image_embedding.weight"].cpu(), sd["project_image_embedding.weight"])
+
+
+def test_more_rows_than_one_weight_pass(ctx):
+    """B x T = 40 x 10 = 400 source rows: the forward GEMMs take two passes of 336 rows, dX five blocks of 96, attention 40 batch rows."""
+    sd = torch.load(os.path.join(GOLD, "transformer_tiny.pt"))["state_dict"]
+    m = make_model("model_10_26", ctx, sd, dim_model=32, num_heads=4, num_encoder_layers=1, num_decoder_layers=2)
+    torch.manual_seed(17)
+    nb = torch.cat([2.0 * torch.ones(40, 1, 256), 0.5 * torch.randn(40, 9, 256)], dim=1)
+    w = dict(w_mse=1.0, w_l1=0.0, w_gdl=0.2, alpha=2)
+    leaves, total, _ = oracle_step(sd, 4, nb, 4, 8, w)
+    m.train()
+    got = m.training_loss(cfg_of(4, 8, w), nb.cuda())
+    assert abs(got["total"] - total) <= 5e-6 * abs(total)
+    check_grads(m, leaves, "400 rows")
