@@ -113,4 +113,4 @@ def test_text_conditioned_variant(ctx):
     p = predict_text(m, X[:1].cuda(), names[:1]).cpu()
     assert rel_l2(p, TO.predict(sd, X[:1], 8, txt=txt[:1])) < TOL
     with pytest.raises((RuntimeError, ValueError)):
-        ctx.transformer_forward(X.cuda(), X.cuda(), None, None)          # text model called without a text embedding
+        m._ctx.transformer_forward(X.cuda(), X.cuda(), None, None)       # text model (in ITS context) called without a text embedding
