@@ -22,6 +22,7 @@
  *   svg_clip_text_forward     utils/sd_utils.py:84,91 (self.text_encoder(input_ids)[0]: transformers CLIPTextModel of
  *                             'openai/clip-vit-large-patch14', last_hidden_state) — tokenisation stays on the host
  *   svg_resize_nearest_u8     prediction/predict.py:158,178 (F.interpolate on uint8, mode nearest)
+ *   svg_resize_bilinear_f32   evaluation/predict_fvd.py:165 (F.interpolate of the predicted latent, mode bilinear)
  *   svg_load_weight/finalize  utils/sd_utils.py:52-66 + prediction/predict.py:50-51 (from_pretrained /
  *                             load_state_dict: tensors are handed over by their state_dict names)
  *
@@ -160,6 +161,9 @@ int svg_ddim_step(svg_ctx* ctx, const float* x, const float* eps, float* prev, i
 
 int svg_resize_nearest_u8(svg_ctx* ctx, const uint8_t* src, int N, int sh, int sw, int C,
                           uint8_t* dst, int dh, int dw, void* stream);
+/* evaluation/predict_fvd.py:165 (nn.functional.interpolate(latent, (64, 64), mode='bilinear'), align_corners=False):
+ * `planes` f32 images of h x w -> oh x ow (NCHW latents: planes = N * 4). */
+int svg_resize_bilinear_f32(svg_ctx* ctx, const float* src, int planes, int h, int w, float* dst, int oh, int ow, void* stream);
 
 /* ---- operator level (the kernels the graphs are made of; used by the parity tests) ---------- */
 /* bf16 buffers are passed as uint16_t bit patterns. NHWC activations, weights [N][K] K-contiguous. */

@@ -19,7 +19,7 @@ from . import transformer_oracle as TO
 
 def sample_clip(xf_sd, num_heads, vae_sd, clip_u8, pred_frames, noise, denoise=False, start_step=40, unet_sd=None,
                 text_emb=None, vae_cfg=SO.SD_VAE, unet_cfg=SO.SD_UNET, res=512, num_inference_steps=50, txt=None,
-                guidance_scale=0.0, unet=None, trace=None):
+                guidance_scale=0.0, unet=None, trace=None, latent_denoise=False):
     """clip_u8 (5,F,F,3) uint8 -> all_latents (1, 4+N, D_lat).  `txt` (1,384): the class embedding of the
     text-conditioned loop (prediction/predict_text.py:186-262 — the same loop with predict(model, X, cls_list)).
     `guidance_scale`: 0 at predict.py:169, 7.5 at evaluation/predict_fvd2_denoise.py:228.  `unet(x, t, ctx)` may stand in
@@ -37,9 +37,12 @@ def sample_clip(xf_sd, num_heads, vae_sd, clip_u8, pred_frames, noise, denoise=F
     for k in range(pred_frames):
         pred = TO.predict(xf_sd, X, num_heads, txt=txt)
         if denoise:
-            img = SO.decode_img_latents(vae_sd, pred.reshape(1, 4, L, L), vae_cfg)
-            big = SO.resize_nearest_u8(img, res, res)
-            lat = SO.encode_img(vae_sd, big, noise["e512"][k][None], vae_cfg)
+            if latent_denoise:      # evaluation/predict_fvd.py:163-165: the latent itself goes to the 512-pixel latent grid
+                lat = torch.nn.functional.interpolate(pred.reshape(1, 4, L, L), (res // down, res // down), mode="bilinear")
+            else:
+                img = SO.decode_img_latents(vae_sd, pred.reshape(1, 4, L, L), vae_cfg)
+                big = SO.resize_nearest_u8(img, res, res)
+                lat = SO.encode_img(vae_sd, big, noise["e512"][k][None], vae_cfg)
             hist = SO.gen_i2i_latents(unet_sd, text_emb, lat, num_inference_steps, guidance_scale, start_step,
                                       noise=noise["add"][k][None] if start_step > 0 else None, cfg=unet_cfg,
                                       return_all_latents=True, unet=unet)

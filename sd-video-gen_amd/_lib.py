@@ -51,6 +51,7 @@ SIGNATURES = {
     "svg_unet_forward": [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp],
     "svg_ddim_loop": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _f, _vp, _vp, _vp],
     "svg_ddim_step": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+    "svg_resize_bilinear_f32": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp],
     "svg_resize_nearest_u8": [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp],
     "svg_op_gemm": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "svg_op_conv3x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -310,6 +311,14 @@ class Context:
         out = torch.empty_like(x)
         self.check(self.lib.svg_ddim_step(self.h, _ptr(x), _ptr(eps), _ptr(out), x.numel(), int(t), int(t_prev), _stream()),
                    "svg_ddim_step")
+        return out
+
+    def resize_bilinear_f32(self, x, oh, ow):
+        """(N,C,h,w) f32 -> (N,C,oh,ow), F.interpolate(mode='bilinear') semantics (evaluation/predict_fvd.py:165)"""
+        N, Cc, h, w = x.shape
+        x = x.contiguous().float()
+        out = torch.empty((N, Cc, oh, ow), device=x.device, dtype=torch.float32)
+        self.check(self.lib.svg_resize_bilinear_f32(self.h, _ptr(x), N * Cc, h, w, _ptr(out), oh, ow, _stream()), "svg_resize_bilinear_f32")
         return out
 
     def resize_nearest_u8(self, img, oh, ow):

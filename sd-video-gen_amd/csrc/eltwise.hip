@@ -244,6 +244,31 @@ void concat_channels(const bf16* a, int Ca, const bf16* b, int Cb, bf16* out, in
   hipLaunchKernelGGL(concat_kernel, grid_for(P * ((Ca + Cb) / 8)), dim3(256), 0, s, a, Ca, b, Cb, out, P);
   check_launch("concat");
 }
+// f32 planes (P, h, w) -> (P, oh, ow), bilinear with torch's align_corners=False convention (F.interpolate(mode='bilinear')):
+// src = max((dst + 0.5) * in / out - 0.5, 0), the upper neighbour clamped to the last row / column
+static __global__ void resize_bilinear_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int P, int h, int w, int oh, int ow) {
+  const int64_t total = (int64_t)P * oh * ow;
+  const float sy = (float)h / (float)oh, sx = (float)w / (float)ow;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % ow), y = (int)((i / ow) % oh);
+    const int64_t p = i / ((int64_t)ow * oh);
+    const float fy = fmaxf(((float)y + 0.5f) * sy - 0.5f, 0.f), fx = fmaxf(((float)x + 0.5f) * sx - 0.5f, 0.f);
+    const int y0 = min((int)fy, h - 1), x0 = min((int)fx, w - 1);
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float* s = src + p * h * w;
+    const float top = s[y0 * w + x0] * (1.f - lx) + s[y0 * w + x1] * lx;
+    const float bot = s[y1 * w + x0] * (1.f - lx) + s[y1 * w + x1] * lx;
+    dst[i] = top * (1.f - ly) + bot * ly;
+  }
+}
+
+void resize_bilinear_f32(const float* src, float* dst, int P, int h, int w, int oh, int ow, hipStream_t s) {
+  const int64_t total = (int64_t)P * oh * ow;
+  hipLaunchKernelGGL(resize_bilinear_f32_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, src, dst, P, h, w, oh, ow);
+  check_launch("resize_bilinear_f32");
+}
+
 void resize_nearest_u8(const uint8_t* src, uint8_t* dst, int N, int sh, int sw, int C, int dh, int dw, hipStream_t s) {
   hipLaunchKernelGGL(resize_u8_kernel, grid_for((int64_t)N * dh * dw), dim3(256), 0, s, src, dst, N, sh, sw, C, dh, dw);
   check_launch("resize_u8");

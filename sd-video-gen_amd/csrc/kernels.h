@@ -162,6 +162,7 @@ void pixel_linear_f32(const float* x, int ldx, const float* w, const float* b, f
 void vae_sample(const float* mom, int ldm, const float* eps_nchw, float* z_nchw, float* mom_nchw, int N,
                 int h, int w, hipStream_t s);
 void concat_channels(const bf16* a, int Ca, const bf16* b, int Cb, bf16* out, int64_t P, hipStream_t s);
+void resize_bilinear_f32(const float* src, float* dst, int P, int h, int w, int oh, int ow, hipStream_t s);
 void resize_nearest_u8(const uint8_t* src, uint8_t* dst, int N, int sh, int sw, int C, int dh, int dw,
                        hipStream_t s);
 void f32_to_bf16(const float* x, bf16* y, int64_t n, hipStream_t s);

@@ -440,6 +440,14 @@ int svg_op_xf_gemm(svg_ctx* ctx, const float* X, const float* W, const float* bi
   API_END(ctx)
 }
 
+int svg_resize_bilinear_f32(svg_ctx* ctx, const float* src, int planes, int h, int w, float* dst, int oh, int ow, void* stream) {
+  try {
+    SVG_CHECK(ctx && src && dst && planes > 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "svg_resize_bilinear_f32: bad arguments");
+    resize_bilinear_f32(src, dst, planes, h, w, oh, ow, (hipStream_t)stream);
+    return 0;
+  } catch (const std::exception& e) { return svg_fail(ctx, e); }
+}
+
 int svg_resize_nearest_u8(svg_ctx* ctx, const uint8_t* src, int N, int sh, int sw, int C, uint8_t* dst, int dh, int dw,
                           void* stream) {
   API_BEGIN

@@ -32,7 +32,7 @@ def clip_noise(seeds, shape, device):
 
 def sample_clips(model, sd_utils, clips_u8, pred_frames, denoise=False, start_step=40, seeds=None,
                  text_embeddings=None, num_inference_steps=50, guidance_scale=0.0, return_frames=False, res=512,
-                 cls_list=None, cpu_noise=False):
+                 cls_list=None, cpu_noise=False, latent_denoise=False):
     """The per-clip loop of prediction/predict.py:117-197 for C independent clips in lock step, device resident.
 
     clips_u8: (C,5,F,F,3) uint8 conditioning frames on the device.  Every stage is batched over clips; a clip's
@@ -42,6 +42,8 @@ def sample_clips(model, sd_utils, clips_u8, pred_frames, denoise=False, start_st
     (decode -> numpy -> tensor -> interpolate, twice) become fused on-device uint8 nearest resizes with identical
     rounding.  ``cls_list`` (one class name per clip, or a (C,384) tensor) selects the text-conditioned loop of
     prediction/predict_text.py:186-262 (same loop, `predict(model, X, cls_list)`); the names are encoded once.
+    ``latent_denoise``: the variant of evaluation/predict_fvd.py:160-178 — the predicted latent itself is resized (bilinear) to the
+    512-pixel latent grid and denoised, instead of being decoded, resized as an image and re-encoded first.
     ``cpu_noise``: the per-clip generators live on the host (bit-reproducible on a machine without the GPU: the committed
     oracle fixtures of tests/golden/sd_*.pt were drawn that way); default is the device generator, like the reference.
     Returns all_latents (C, 4+N, D_lat) f32 [and the decoded frames (C,4+N,F,F,3) uint8].
@@ -76,9 +78,12 @@ def sample_clips(model, sd_utils, clips_u8, pred_frames, denoise=False, start_st
         for _ in range(pred_frames):
             pred = predict(model, X, pe_row=pe0, cls_list=cls_list)                         # :144  (C, D)
             if denoise:
-                noisy_img = ctx.vae_decode(pred.reshape(C, 4, L, L))                        # :149-153 (uint8, on device)
-                e512 = clip_noise(gens, (4, res // 8, res // 8), dev)
-                resized = ctx.vae_encode(noisy_img, H=res, W=res, eps=e512)                 # :158 resize + :163-164
+                if latent_denoise:
+                    resized = ctx.resize_bilinear_f32(pred.reshape(C, 4, L, L), res // 8, res // 8)   # predict_fvd.py:163-165
+                else:
+                    noisy_img = ctx.vae_decode(pred.reshape(C, 4, L, L))                    # :149-153 (uint8, on device)
+                    e512 = clip_noise(gens, (4, res // 8, res // 8), dev)
+                    resized = ctx.vae_encode(noisy_img, H=res, W=res, eps=e512)             # :158 resize + :163-164
                 noise = clip_noise(gens, (4, res // 8, res // 8), dev) if 0 < start_step else None
                 den = ctx.ddim_loop(resized, emb, num_steps=num_inference_steps, start_step=start_step,
                                     guidance=guidance_scale, noise=noise)                   # :168-170

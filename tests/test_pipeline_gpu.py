@@ -32,13 +32,15 @@ def build(denoise, seed=3):
     return sdu, m, vsd, usd
 
 
-def clip_noise_cpu(seed, res, F, pred_frames, start_step):
-    """the per-clip draws of sample_clips, reproduced: a cuda generator seeded `seed`, in the documented order."""
+def clip_noise_cpu(seed, res, F, pred_frames, start_step, latent_denoise=False):
+    """the per-clip draws of sample_clips, reproduced: a cuda generator seeded `seed`, in the documented order
+    (the latent-space denoise variant has no VAE sample at 512)."""
     g = torch.Generator(device="cuda").manual_seed(seed)
     L = F // 8
     n = {"cond": torch.randn((5, 4, L, L), generator=g, device="cuda").cpu(), "e512": [], "add": [], "eF": []}
     for _ in range(pred_frames):
-        n["e512"].append(torch.randn((4, res // 8, res // 8), generator=g, device="cuda").cpu())
+        if not latent_denoise:
+            n["e512"].append(torch.randn((4, res // 8, res // 8), generator=g, device="cuda").cpu())
         if start_step > 0:
             n["add"].append(torch.randn((4, res // 8, res // 8), generator=g, device="cuda").cpu())
         n["eF"].append(torch.randn((4, L, L), generator=g, device="cuda").cpu())
@@ -103,6 +105,30 @@ def test_loop_denoise_matches_oracle(ctx):
                                       text_emb=emb.cpu(), vae_cfg=VCFG, unet_cfg=UCFG, res=128)
         # three uint8 round trips per frame sit between the networks: a 1-LSB pixel difference re-enters the encoder
         margin("test_loop_denoise_matches_oracle: lat[c:c + 1].cpu()", rel_l2(lat[c:c + 1].cpu(), ref), 2e-2)       # measured 6.6e-3
+
+
+def test_latent_space_denoise_variant(ctx):
+    """evaluation/predict_fvd.py:160-178: the predicted latent is resized bilinearly to the denoise grid (no decode / re-encode in
+    front of the DDIM loop); the bilinear resize itself against torch's F.interpolate."""
+    from sd_video_gen_amd.predict import sample_clips, bouncing_ball_clips
+    g = torch.Generator().manual_seed(2)
+    for (h, w, oh, ow) in ((8, 8, 64, 64), (16, 16, 64, 64), (8, 8, 16, 16), (5, 7, 13, 9), (16, 16, 8, 8)):
+        x = torch.randn(3, 4, h, w, generator=g)
+        got = ctx.resize_bilinear_f32(x.cuda(), oh, ow).cpu()
+        want = torch.nn.functional.interpolate(x, (oh, ow), mode="bilinear")
+        assert float((got - want).abs().max()) < 2e-6, (h, w, oh, ow)
+    sdu, m, vsd, usd = build(True)
+    clips = bouncing_ball_clips(2, 64, 5, seed=9)
+    seeds = [31, 32]
+    emb = sdu.encode_text([""])
+    S = 47
+    lat = sample_clips(m, sdu, clips.cuda(), 2, denoise=True, start_step=S, seeds=seeds, text_embeddings=emb, res=128, latent_denoise=True)
+    xsd = {k: v.cpu() for k, v in m.state_dict().items()}
+    for c in range(2):
+        noise = clip_noise_cpu(seeds[c], 128, 64, 2, S, latent_denoise=True)
+        ref = loop_oracle.sample_clip(xsd, 4, vsd, clips[c], 2, noise, denoise=True, start_step=S, unet_sd=usd, text_emb=emb.cpu(),
+                                      vae_cfg=VCFG, unet_cfg=UCFG, res=128, latent_denoise=True)
+        margin("latent-space denoise loop (predict_fvd.py variant), clip %d" % c, rel_l2(lat[c:c + 1].cpu(), ref), 1.6e-2)
 
 
 def test_sdutils_reference_surface(ctx):
