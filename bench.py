@@ -44,6 +44,9 @@ def parse():
     p.add_argument("--no-denoise", action="store_true")
     p.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16",
                    help="fp8 = BASELINE configs[4]: qualifying dense projections of the UNet in MX block-scaled fp8 (the rest stays bf16)")
+    p.add_argument("--train", action="store_true",
+                   help="SURVEY 8(f1): optimisation steps of the latent Transformer (trainers/trainer.py:141-165) instead of the sampling loop; "
+                        "one step = forward in train mode + criterion + backward + Adam on the config's own batch")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     return p.parse_args()
@@ -230,6 +233,98 @@ def roofline_pass(args, sd_utils, step, denoise, C):
     return out
 
 
+def train_bench(args, rank, local_rank, world, dist):
+    """Training-step line.  The reference's trainer is single-GPU (no DDP): with N ranks every rank trains its own replica
+    (DESIGN.md section 6 'replicas only'), value = iterations of all ranks / max-over-ranks time."""
+    import statistics
+    import torch
+    from sd_video_gen_amd import config as svg_config
+    from sd_video_gen_amd import _lib
+    from sd_video_gen_amd.transformer import Transformer
+    svg_config.set_args(["--dataset", "synthetic-ball", "--config", args.config])
+    cfg = svg_config.load_config(args.config)
+    dev = torch.device("cuda", local_rank)
+    first = lambda v: v[0] if isinstance(v, (list, tuple)) else v
+    torch.manual_seed(0)
+    model = Transformer(num_tokens=0, dim_model=first(cfg.DIM_MODEL), num_heads=first(cfg.NUM_HEADS), num_encoder_layers=first(cfg.NUM_ENCODER_LAYERS),
+                        num_decoder_layers=first(cfg.NUM_DECODER_LAYERS), dropout_p=first(cfg.DROPOUT_P)).train()
+    n_par = sum(p.numel() for p in model.parameters())
+    B, F = first(cfg.BATCH_SIZE), first(cfg.FRAMES_TO_PREDICT)
+    T = first(cfg.FRAMES_PER_CLIP) + F + 1
+    feat = cfg.FRAME_SIZE // 8
+    D = 4 * feat * feat
+    g = torch.Generator().manual_seed(1 + rank)
+    new_batch = torch.cat([2.0 * torch.ones(B, 1, D), 0.8 * torch.randn(B, T - 1, D, generator=g)], dim=1).to(dev)   # resident before timing
+    w = dict(w_mse=float(bool(first(getattr(cfg, "USE_MSE", False)))), w_l1=float(bool(first(getattr(cfg, "USE_L1", False)))),
+             w_gdl=float(bool(first(getattr(cfg, "USE_GDL", False)))) * float(first(getattr(cfg, "LAMBDA_GDL", 1))),
+             alpha=float(first(getattr(cfg, "ALPHA", 1))),
+             w_con=float(bool(first(getattr(cfg, "USE_CONTRASTIVE", False)))) * float(first(getattr(cfg, "LAMBDA_CONTRASTIVE", 0.0))))
+    tc = _lib.TrainCfg(frames_to_predict=F, feat_h=feat, feat_w=feat, w_mse=w["w_mse"], w_l1=w["w_l1"], w_gdl=w["w_gdl"], gdl_alpha=w["alpha"],
+                       w_contrastive=w["w_con"], temperature=0.07, dropout_p=float(first(cfg.DROPOUT_P)), seed=0)
+    lr = float(first(cfg.LR))
+
+    def step(i):
+        tc.seed = i + 1
+        terms = model.training_loss(tc, new_batch)          # reads the loss back like loss.item() in the reference's loop
+        model.adam_step(lr)
+        return terms
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    steps, warm = max(args.steps, 20) if args.steps == 2 else args.steps, max(args.warmup, 3)
+    for i in range(warm):
+        step(i)
+    sync()
+    per = []
+    t0 = time.perf_counter()
+    for i in range(steps):
+        t1 = time.perf_counter()
+        terms = step(warm + i)
+        torch.cuda.synchronize()
+        per.append(time.perf_counter() - t1)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert all(v == v for v in terms.values())
+    med = statistics.median(per)
+    step_bytes = 10.0 * n_par * 4          # W read by forward and by dX, dW written, Adam: p, g, m, v read and p, m, v written
+    rec = {"metric": "training iterations/sec, latent Transformer (forward + criterion + backward + Adam)", "value": world * steps / dt,
+           "unit": "iterations/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "%s training step: %d parameters, batch %d x %d tokens (5+%d frames + SOS), D_lat %d, dropout %.2f, loss %s"
+                                  % (args.config, n_par, B, T, F, D, float(first(cfg.DROPOUT_P)), {k: v for k, v in w.items() if v}),
+                      "parallelism": "replicas only (the reference trainer is single-GPU)", "weights": "seeded random init"},
+           "roofline": {"bound": "hbm", "kernel": "whole step: xf_gemm (forward) + xf_gemm_nn (dX) + xf_gemm_tn (dW, db) + adam_kernel",
+                        "achieved": step_bytes / med / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": step_bytes / med / PEAK_HBM, "traffic": None,
+                        "algorithmic_bytes_per_step": step_bytes, "median_ms_per_step": med * 1e3, "mean_ms_per_step": dt / steps * 1e3,
+                        "note": "median over per-step wall times (each step synchronises to read its loss); the mean includes this pool's "
+                                "periodic ~75 ms stalls of many-launch sequences (profiles/README.md)"}}
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import train_oracle as TR
+        torch.set_num_threads(host_cores())
+        sd = TR.leaf_state({k: v.detach().cpu() for k, v in model.state_dict().items()})
+        opt = torch.optim.Adam(TR.params_of(sd), lr=lr)
+        nb = new_batch.cpu()
+        t1 = time.perf_counter()
+        total, _ = TR.loss(sd, first(cfg.NUM_HEADS), nb, F, feat, w_mse=w["w_mse"], w_l1=w["w_l1"], w_gdl=w["w_gdl"], alpha=w["alpha"],
+                           w_contrastive=w["w_con"])
+        opt.zero_grad(); total.backward(); opt.step()
+        t_cpu = time.perf_counter() - t1
+        rec["cpu_baseline"] = {"value": 1.0 / t_cpu, "unit": "iterations/s", "cores": host_cores(), "kind": "port", "cpu": cpu_model(),
+                               "sample": "one full step of the training oracle (torch autograd over the explicit-op forward + torch.optim.Adam), no dropout"}
+    if rank == 0:
+        print(json.dumps(rec))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -262,6 +357,8 @@ def main():
     from sd_video_gen_amd.sd_utils import SDUtils
     from sd_video_gen_amd.transformer import Transformer
 
+    if args.train:
+        return train_bench(args, rank, local_rank, world, dist)
     denoise = not args.no_denoise
     argv = ["--dataset", "synthetic-ball", "--config", args.config, "--pred_frames", str(args.pred_frames),
             "--denoise_start_step", str(args.start_step)] + (["--denoise", "True"] if denoise else [])
