@@ -263,10 +263,13 @@ def train_bench(args, rank, local_rank, world, dist):
                        w_contrastive=w["w_con"], temperature=0.07, dropout_p=float(first(cfg.DROPOUT_P)), seed=0)
     lr = float(first(cfg.LR))
 
+    side = torch.cuda.Stream()        # a capturable stream: the library replays the step as one hipGraph there
+
     def step(i):
         tc.seed = i + 1
-        terms = model.training_loss(tc, new_batch)          # reads the loss back like loss.item() in the reference's loop
-        model.adam_step(lr)
+        with torch.cuda.stream(side):
+            terms = model.training_loss(tc, new_batch)      # reads the loss back like loss.item() in the reference's loop
+            model.adam_step(lr)
         return terms
 
     def sync():

@@ -108,6 +108,7 @@ struct svg_ctx {
   static constexpr int kCtxSlot = 4;                 // owned[] index of allocations that belong to the context itself
   std::vector<void*> owned[5];   // device allocations per model id (kCtxSlot = context) freed at reconfigure / destroy
   int cur_model = kCtxSlot;
+  uint64_t* seed_scratch = nullptr;   // device word for svg_op_dropout_mask
   void* dalloc(int64_t bytes);
   void ensure_arena(int64_t bytes);
 };

@@ -73,6 +73,7 @@ void gemm_pp_init_device();
 void conv_halo_init_device();
 void ff_fused_init_device();
 void gemm_fp8_init_device();
+void xf_train_init_device();
 
 // ---- MX block-scaled fp8 (OCP e4m3 elements, one E8M0 scale per 32 K elements): quantiser and GEMM (gemm_fp8.hip)
 void quant_mx_bf16(svg_ctx* ctx, const bf16* x, int ldx, uint8_t* q, uint8_t* sc, int64_t rows, int K, hipStream_t s);
@@ -193,8 +194,9 @@ void xf_add_ln(const float* x, const float* r, const float* g, const float* b, f
 void xf_embed_post(const float* emb, const float* pe, const int32_t* pe_row, const float* text, int d_txt, float* y, int B, int T,
                    int d, float scale, hipStream_t s);
 // ---- training step of the latent Transformer (xf_train.hip) --------------------------------------------------------------
-// dropout site: mask element i of site `site` is a pure function of (seed, site, i); p = 0 disables it
-struct XfDrop { uint64_t seed; uint32_t site; float p; };
+// dropout site: mask element i of site `site` is a pure function of (seed, site, i); p = 0 disables it.  The seed is read from
+// device memory, so a captured graph of the step replays with a new seed without new kernel arguments.
+struct XfDrop { const uint64_t* seed; uint32_t site; float p; };
 struct XfAdamTensor { float* p; const float* g; float* m; float* v; };
 struct XfAdamChunk { int32_t ten; int32_t n; int64_t off; };
 void xf_drop_mask(const XfDrop d, float* out, int64_t n, hipStream_t s);

@@ -166,7 +166,7 @@ int svg_create(int device_id, svg_ctx** out) {
   gemm_pp_init_device();
   conv_halo_init_device();
   ff_fused_init_device();
-  gemm_fp8_init_device();
+  gemm_fp8_init_device(); xf_train_init_device();
   ctx = new svg_ctx();
   ctx->device = device_id;
   ctx->prof_entries.resize(PK_COUNT);

@@ -19,7 +19,7 @@ namespace {
 
 // ---- dropout: counter-based, keyed by (seed, site, element index) so that backward regenerates the forward mask -------------
 __device__ __forceinline__ float drop_keep(const XfDrop d, uint64_t idx) {
-  uint64_t x = d.seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(d.site + 1));
+  uint64_t x = *d.seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(d.site + 1));
   x += idx * 0xD1B54A32D192ED03ull;
   x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
   x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
@@ -333,23 +333,34 @@ __global__ void embed_post_bwd_kernel(const float* __restrict__ dy, float* __res
 }
 
 // ---- attention, T <= 32: one workgroup per (batch row, head) -----------------------------------------------------------------
+// The head's q / k / v (and dO) rows are staged into LDS first with independent coalesced loads: read straight from global inside
+// the T x T loops every access is a dependent L2 round trip (36 / 49 us per launch for 11 x 11 tokens).
 constexpr int TMAX = 32;
 // P (B,H,Tq,Tk) = softmax(q k^T / sqrt(hd) + mask) is kept; o = dropout(P) v
 __global__ void __launch_bounds__(256) attn_train_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                                                               const float* __restrict__ v, int ldk, const float* __restrict__ mask,
                                                               float* __restrict__ o, float* __restrict__ P, int Tq, int Tk, int B, int heads,
                                                               int hd, const XfDrop dr) {
+  extern __shared__ float lds[];                  // sq[Tq][hd], sk[Tk][hd], sv[Tk][hd]
   __shared__ float sc[TMAX][TMAX + 1];
+  float* sq = lds;
+  float* sk = sq + Tq * hd;
+  float* sv = sk + Tk * hd;
   const int b = blockIdx.x, hh = blockIdx.y;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const float scale = rsqrtf((float)hd);
   const int d = heads * hd;
+  for (int idx = threadIdx.x; idx < Tq * hd; idx += 256) { const int i = idx / hd, c = idx - i * hd; sq[idx] = q[((int64_t)i * B + b) * ldq + hh * hd + c]; }
+  for (int idx = threadIdx.x; idx < Tk * hd; idx += 256) {
+    const int j = idx / hd, c = idx - j * hd;
+    sk[idx] = k[((int64_t)j * B + b) * ldk + hh * hd + c];
+    sv[idx] = v[((int64_t)j * B + b) * ldk + hh * hd + c];
+  }
+  __syncthreads();
   for (int p = wid; p < Tq * Tk; p += 4) {
     const int i = p / Tk, j = p - i * Tk;
-    const float* qr = q + ((int64_t)i * B + b) * ldq + hh * hd;
-    const float* kr = k + ((int64_t)j * B + b) * ldk + hh * hd;
     float s = 0.f;
-    for (int c = lane; c < hd; c += 64) s += qr[c] * kr[c];
+    for (int c = lane; c < hd; c += 64) s += sq[i * hd + c] * sk[j * hd + c];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0) sc[i][j] = s * scale + (mask ? mask[i * Tk + j] : 0.f);
   }
@@ -372,7 +383,7 @@ __global__ void __launch_bounds__(256) attn_train_fwd_kernel(const float* __rest
   for (int idx = threadIdx.x; idx < Tq * hd; idx += 256) {
     const int i = idx / hd, c = idx - i * hd;
     float acc = 0.f;
-    for (int j = 0; j < Tk; ++j) acc += sc[i][j] * v[((int64_t)j * B + b) * ldk + hh * hd + c];
+    for (int j = 0; j < Tk; ++j) acc += sc[i][j] * sv[j * hd + c];
     o[((int64_t)i * B + b) * d + hh * hd + c] = acc;
   }
 }
@@ -383,20 +394,34 @@ __global__ void __launch_bounds__(256) attn_train_bwd_kernel(const float* __rest
                                                               const float* __restrict__ P, float* __restrict__ dq, int lddq,
                                                               float* __restrict__ dk, float* __restrict__ dv, int lddk, int Tq, int Tk, int B,
                                                               int heads, int hd, const XfDrop dr) {
-  __shared__ float pd[TMAX][TMAX + 1];   // dropout(P)
-  __shared__ float ds[TMAX][TMAX + 1];   // dP, then dS
+  extern __shared__ float lds[];                  // sdo[Tq][hd], sq[Tq][hd], sk[Tk][hd], sv[Tk][hd]
+  __shared__ float pd[TMAX][TMAX + 1];            // dropout(P)
+  __shared__ float ds[TMAX][TMAX + 1];            // dP, then dS
+  float* sdo = lds;
+  float* sq = sdo + Tq * hd;
+  float* sk = sq + Tq * hd;
+  float* sv = sk + Tk * hd;
   const int b = blockIdx.x, hh = blockIdx.y;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const float scale = rsqrtf((float)hd);
   const int d = heads * hd;
   const int64_t pbase = ((int64_t)b * heads + hh) * Tq * Tk;
+  for (int idx = threadIdx.x; idx < Tq * hd; idx += 256) {
+    const int i = idx / hd, c = idx - i * hd;
+    sdo[idx] = dout[((int64_t)i * B + b) * d + hh * hd + c];
+    sq[idx] = q[((int64_t)i * B + b) * ldq + hh * hd + c];
+  }
+  for (int idx = threadIdx.x; idx < Tk * hd; idx += 256) {
+    const int j = idx / hd, c = idx - j * hd;
+    sk[idx] = k[((int64_t)j * B + b) * ldk + hh * hd + c];
+    sv[idx] = v[((int64_t)j * B + b) * ldk + hh * hd + c];
+  }
+  __syncthreads();
   // dPd[i][j] = <do_i, v_j>; dP = dPd * mask
   for (int p = wid; p < Tq * Tk; p += 4) {
     const int i = p / Tk, j = p - i * Tk;
-    const float* dor = dout + ((int64_t)i * B + b) * d + hh * hd;
-    const float* vr = v + ((int64_t)j * B + b) * ldk + hh * hd;
     float s = 0.f;
-    for (int c = lane; c < hd; c += 64) s += dor[c] * vr[c];
+    for (int c = lane; c < hd; c += 64) s += sdo[i * hd + c] * sv[j * hd + c];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0) {
       const float m = drop_apply(dr, (uint64_t)(pbase + p));
@@ -415,15 +440,15 @@ __global__ void __launch_bounds__(256) attn_train_bwd_kernel(const float* __rest
   for (int idx = threadIdx.x; idx < Tq * hd; idx += 256) {
     const int i = idx / hd, c = idx - i * hd;
     float acc = 0.f;
-    for (int j = 0; j < Tk; ++j) acc += ds[i][j] * k[((int64_t)j * B + b) * ldk + hh * hd + c];
+    for (int j = 0; j < Tk; ++j) acc += ds[i][j] * sk[j * hd + c];
     dq[((int64_t)i * B + b) * lddq + hh * hd + c] = acc;
   }
   for (int idx = threadIdx.x; idx < Tk * hd; idx += 256) {
     const int j = idx / hd, c = idx - j * hd;
     float ak = 0.f, av = 0.f;
     for (int i = 0; i < Tq; ++i) {
-      ak += ds[i][j] * q[((int64_t)i * B + b) * ldq + hh * hd + c];
-      av += pd[i][j] * dout[((int64_t)i * B + b) * d + hh * hd + c];
+      ak += ds[i][j] * sq[i * hd + c];
+      av += pd[i][j] * sdo[i * hd + c];
     }
     dk[((int64_t)j * B + b) * lddk + hh * hd + c] = ak;
     dv[((int64_t)j * B + b) * lddk + hh * hd + c] = av;
@@ -565,9 +590,16 @@ __global__ void __launch_bounds__(256) adam_kernel(const XfAdamTensor* __restric
   }
 }
 
+constexpr int kAttnTrainLds = 150 * 1024;   // + 2 x 4.3 KiB of static score tiles: under the 160 KiB of a CU
+
 int grid_for(int64_t n, int per_block) { return (int)std::min<int64_t>(4096, (n + per_block - 1) / per_block); }
 
 }  // namespace
+
+void xf_train_init_device() {
+  HIP_OK(hipFuncSetAttribute((const void*)attn_train_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kAttnTrainLds));
+  HIP_OK(hipFuncSetAttribute((const void*)attn_train_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kAttnTrainLds));
+}
 
 void xf_drop_mask(const XfDrop d, float* out, int64_t n, hipStream_t s) {
   hipLaunchKernelGGL(drop_mask_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d, out, n);
@@ -643,13 +675,17 @@ void xf_embed_post_bwd(const float* dy, float* de, int B, int T, int d, int d_im
 void xf_attention_train(const float* q, int ldq, const float* k, const float* v, int ldk, const float* mask, float* o, float* P, int Tq, int Tk,
                         int B, int heads, int hd, const XfDrop dr, hipStream_t s) {
   SVG_CHECK(Tq <= TMAX && Tk <= TMAX, "xf_attention_train: T %d/%d > %d", Tq, Tk, TMAX);
-  hipLaunchKernelGGL(attn_train_fwd_kernel, dim3(B, heads), dim3(256), 0, s, q, ldq, k, v, ldk, mask, o, P, Tq, Tk, B, heads, hd, dr);
+  const size_t lds = (size_t)(Tq + 2 * Tk) * hd * sizeof(float);
+  SVG_CHECK(lds <= kAttnTrainLds, "xf_attention_train: %d + 2 x %d tokens of head dim %d do not fit the LDS staging (%zu > %d bytes)", Tq, Tk, hd, lds, kAttnTrainLds);
+  hipLaunchKernelGGL(attn_train_fwd_kernel, dim3(B, heads), dim3(256), lds, s, q, ldq, k, v, ldk, mask, o, P, Tq, Tk, B, heads, hd, dr);
   check_launch("xf_attention_train");
 }
 void xf_attention_bwd(const float* dout, const float* q, int ldq, const float* k, const float* v, int ldk, const float* P, float* dq, int lddq,
                       float* dk, float* dv, int lddk, int Tq, int Tk, int B, int heads, int hd, const XfDrop dr, hipStream_t s) {
   SVG_CHECK(Tq <= TMAX && Tk <= TMAX, "xf_attention_bwd: T %d/%d > %d", Tq, Tk, TMAX);
-  hipLaunchKernelGGL(attn_train_bwd_kernel, dim3(B, heads), dim3(256), 0, s, dout, q, ldq, k, v, ldk, P, dq, lddq, dk, dv, lddk, Tq, Tk, B, heads,
+  const size_t lds = (size_t)(2 * Tq + 2 * Tk) * hd * sizeof(float);
+  SVG_CHECK(lds <= kAttnTrainLds, "xf_attention_bwd: 2 x %d + 2 x %d tokens of head dim %d do not fit the LDS staging (%zu > %d bytes)", Tq, Tk, hd, lds, kAttnTrainLds);
+  hipLaunchKernelGGL(attn_train_bwd_kernel, dim3(B, heads), dim3(256), lds, s, dout, q, ldq, k, v, ldk, P, dq, lddq, dk, dv, lddk, Tq, Tk, B, heads,
                      hd, dr);
   check_launch("xf_attention_bwd");
 }

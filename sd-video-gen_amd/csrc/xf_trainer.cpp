@@ -8,6 +8,7 @@
 #include "../../include/svg_hip.h"
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 
 struct XfTrain {
   struct Slot { float* g = nullptr; float* m = nullptr; float* v = nullptr; int64_t n = 0; };
@@ -18,7 +19,20 @@ struct XfTrain {
   int step = 0;
   float* d_losses = nullptr;     // [5]
   float* h_losses = nullptr;     // pinned mirror: a device-to-pageable copy goes through the runtime's staging path and its host thread
-  std::unordered_map<uint64_t, int64_t> plan;   // workspace high-water mark per call shape (saves the dry planning pass)
+  // One plan per call signature (shapes + every criterion / dropout parameter except the seed): the workspace high-water mark and,
+  // for the loss (+ backward) calls, the captured hipGraph of the whole step.  ~540 launches per step cost more host time than
+  // the GPU needs to run them (15.3 ms wall against 9.3 ms of kernels); the graph replays them from fixed staging buffers.
+  struct Plan {
+    svg_train_cfg cfg{}; int B = 0, Ts = 0, Tt = 0, backward = 0, mode = 0; bool has_mask = false, has_text = false;
+    int64_t high = 0;
+    hipGraphExec_t exec = nullptr;
+    char* arena_base = nullptr;
+    float *src = nullptr, *tgt = nullptr, *exp = nullptr, *text = nullptr, *mask = nullptr;
+  };
+  std::vector<Plan> plans;
+  uint64_t* d_seed = nullptr;     // device seed word read by every dropout site
+  uint64_t* h_seed = nullptr;     // pinned ring of 16 seeds (a call that does not synchronise must not race the next one's seed)
+  int seed_slot = 0;
   std::vector<void*> bufs;       // device allocations of the training state (freed with it)
   void* dalloc(int64_t bytes) {
     void* p = nullptr;
@@ -26,7 +40,12 @@ struct XfTrain {
     bufs.push_back(p);
     return p;
   }
-  ~XfTrain() { for (void* p : bufs) hipFree(p); if (h_losses) hipHostFree(h_losses); }
+  ~XfTrain() {
+    for (auto& pl : plans) if (pl.exec) hipGraphExecDestroy(pl.exec);
+    for (void* p : bufs) hipFree(p);
+    if (h_losses) hipHostFree(h_losses);
+    if (h_seed) hipHostFree(h_seed);
+  }
 };
 
 namespace {
@@ -34,21 +53,21 @@ namespace {
 constexpr int kAdamChunk = 1 << 16;
 
 struct LinTape { const float* x = nullptr; int M = 0, N = 0, K = 0; std::string w, b; int64_t woff = 0, boff = 0; };
-struct LnTape { float* xhat = nullptr; float* rstd = nullptr; std::string p; XfDrop dr{0, 0, 0.f}; int M = 0; };
+struct LnTape { float* xhat = nullptr; float* rstd = nullptr; std::string p; XfDrop dr{nullptr, 0, 0.f}; int M = 0; };
 struct MhaTape {
   LinTape in_q, in_kv, outp;   // self: in_q is the whole packed projection
   float *qkv = nullptr, *q = nullptr, *kv = nullptr, *P = nullptr;
   const float* mask = nullptr;
   int Tq = 0, Tk = 0;
   bool self = true;
-  XfDrop dr{0, 0, 0.f};
+  XfDrop dr{nullptr, 0, 0.f};
 };
 struct FfnTape { LinTape l1, l2; float* r = nullptr; float gate_scale = 1.f; };
 struct EncTape { MhaTape sa; LnTape n1; FfnTape ff; LnTape n2; };
 struct DecTape { MhaTape sa; LnTape n1; MhaTape ca; LnTape n2; FfnTape ff; LnTape n3; };
 
 struct Run {
-  svg_ctx* ctx; XfModel* m; XfTrain* tr; hipStream_t s; int B; uint64_t seed; float p; bool grads;
+  svg_ctx* ctx; XfModel* m; XfTrain* tr; hipStream_t s; int B; const uint64_t* seed; float p; bool grads;
   const float* text = nullptr;
   uint32_t site = 0;
   bool go() const { return SVG_LAUNCHING(ctx); }
@@ -78,7 +97,7 @@ struct Run {
   float* add_ln(LnTape& t, const float* x, const float* r, const std::string& p, int M, bool drop_r) {
     const int d = m->d_model;
     t.p = p; t.M = M;
-    t.dr = drop_r ? drop() : XfDrop{0, 0, 0.f};
+    t.dr = drop_r ? drop() : XfDrop{seed, 0, 0.f};
     t.xhat = get<float>((int64_t)M * d);
     t.rstd = get<float>(M);
     float* y = get<float>((int64_t)M * d);
@@ -195,6 +214,8 @@ void ensure_train(svg_ctx* ctx, XfModel* m) {
   tr->d_chunks = (XfAdamChunk*)tr->dalloc(chunks.size() * sizeof(XfAdamChunk));
   tr->d_losses = (float*)tr->dalloc(5 * sizeof(float));
   HIP_OK(hipHostMalloc((void**)&tr->h_losses, 5 * sizeof(float), hipHostMallocDefault));
+  tr->d_seed = (uint64_t*)tr->dalloc(sizeof(uint64_t));
+  HIP_OK(hipHostMalloc((void**)&tr->h_seed, 16 * sizeof(uint64_t), hipHostMallocDefault));
   HIP_OK(hipMemcpy(tr->d_tens, tens.data(), tens.size() * sizeof(XfAdamTensor), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(tr->d_chunks, chunks.data(), chunks.size() * sizeof(XfAdamChunk), hipMemcpyHostToDevice));
   tr->n_chunks = (int)chunks.size();
@@ -217,9 +238,8 @@ void loss_pass(svg_ctx* ctx, XfModel* m, const svg_train_cfg& cfg, const float* 
   ensure_train(ctx, m);
   XfTrain* tr = m->train;
   const int d = m->d_model, Ms = Ts * B, Mt = Tt * B;
-  const uint64_t shape_key = ((uint64_t)B << 40) | ((uint64_t)Ts << 24) | ((uint64_t)Tt << 8) | (uint64_t)(backward ? 1 : 0) | (expected ? 0u : 2u);
-  auto body = [&]() {
-    Run r{ctx, m, tr, s, B, cfg.seed, backward ? cfg.dropout_p : 0.f, backward != 0};
+  auto body = [&](const float* src, const float* tgt, const float* expected, const float* text, const float* mask) {
+    Run r{ctx, m, tr, s, B, tr->d_seed, backward ? cfg.dropout_p : 0.f, backward != 0};
     r.text = text;
     LinTape e_src, e_tgt, l_out;
     XfDrop d_src, d_tgt;
@@ -295,14 +315,66 @@ void loss_pass(svg_ctx* ctx, XfModel* m, const svg_train_cfg& cfg, const float* 
     r.embed_bwd(e_src, d_src, dxs, Ts, false);
     r.embed_bwd(e_tgt, d_tgt, dxt, Tt, true);                 // the embedding layer is shared: second contribution accumulates
   };
-  auto it = tr->plan.find(shape_key);
-  if (it == tr->plan.end()) {
-    run_planned(ctx, body);
-    tr->plan[shape_key] = ctx->arena.high;
-  } else {                                                    // same shapes as a planned call: the workspace need is known
-    ctx->ensure_arena(it->second);
+  // ---- the plan of this call signature ----------------------------------------------------------------------------------------
+  const int mode = expected ? 0 : 2;
+  XfTrain::Plan* pl = nullptr;
+  for (auto& c : tr->plans)
+    if (c.B == B && c.Ts == Ts && c.Tt == Tt && c.backward == backward && c.mode == mode && c.has_mask == (mask != nullptr) &&
+        c.has_text == (text != nullptr) && c.cfg.frames_to_predict == cfg.frames_to_predict && c.cfg.feat_h == cfg.feat_h &&
+        c.cfg.feat_w == cfg.feat_w && c.cfg.w_mse == cfg.w_mse && c.cfg.w_l1 == cfg.w_l1 && c.cfg.w_gdl == cfg.w_gdl &&
+        c.cfg.gdl_alpha == cfg.gdl_alpha && c.cfg.w_contrastive == cfg.w_contrastive && c.cfg.temperature == cfg.temperature &&
+        c.cfg.dropout_p == cfg.dropout_p) { pl = &c; break; }
+  if (!pl) {
+    tr->plans.emplace_back();
+    pl = &tr->plans.back();
+    pl->cfg = cfg; pl->B = B; pl->Ts = Ts; pl->Tt = Tt; pl->backward = backward; pl->mode = mode;
+    pl->has_mask = mask != nullptr; pl->has_text = text != nullptr;
+    ctx->arena.reset(); ctx->arena.dry = true; ctx->arena.high = 0;          // dry pass: the workspace this signature needs
+    try { body(src, tgt, expected, text, mask); } catch (...) { ctx->arena.dry = false; tr->plans.pop_back(); throw; }
+    ctx->arena.dry = false;
+    pl->high = ctx->arena.high;
+  }
+  ctx->ensure_arena(pl->high);
+  tr->seed_slot = (tr->seed_slot + 1) & 15;
+  tr->h_seed[tr->seed_slot] = cfg.seed;
+  HIP_OK(hipMemcpyAsync(tr->d_seed, tr->h_seed + tr->seed_slot, sizeof(uint64_t), hipMemcpyHostToDevice, s));
+  static const bool graph_env = !(getenv("SVG_TRAIN_GRAPH") && atoi(getenv("SVG_TRAIN_GRAPH")) == 0);
+  // hipGraph replay of the whole step: needs a capturable (non-null) stream; the inputs go through fixed staging buffers
+  if (graph_env && expected && s != nullptr && !ctx->prof) {
+    if (!pl->src) {
+      pl->src = (float*)tr->dalloc((int64_t)B * Ts * m->d_lat * sizeof(float));
+      pl->tgt = (float*)tr->dalloc((int64_t)B * Tt * m->d_lat * sizeof(float));
+      pl->exp = (float*)tr->dalloc((int64_t)B * Tt * m->d_lat * sizeof(float));
+      if (text) pl->text = (float*)tr->dalloc((int64_t)B * m->text_dim * sizeof(float));
+      if (mask) pl->mask = (float*)tr->dalloc((int64_t)Tt * Tt * sizeof(float));
+    }
+    HIP_OK(hipMemcpyAsync(pl->src, src, (size_t)B * Ts * m->d_lat * sizeof(float), hipMemcpyDefault, s));
+    HIP_OK(hipMemcpyAsync(pl->tgt, tgt, (size_t)B * Tt * m->d_lat * sizeof(float), hipMemcpyDefault, s));
+    HIP_OK(hipMemcpyAsync(pl->exp, expected, (size_t)B * Tt * m->d_lat * sizeof(float), hipMemcpyDefault, s));
+    if (text) HIP_OK(hipMemcpyAsync(pl->text, text, (size_t)B * m->text_dim * sizeof(float), hipMemcpyDefault, s));
+    if (mask) HIP_OK(hipMemcpyAsync(pl->mask, mask, (size_t)Tt * Tt * sizeof(float), hipMemcpyDefault, s));
+    if (!pl->exec || pl->arena_base != ctx->arena.base) {       // first use, or the workspace moved since the capture
+      if (pl->exec) { HIP_OK(hipGraphExecDestroy(pl->exec)); pl->exec = nullptr; }
+      hipGraph_t g = nullptr;
+      HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      try {
+        ctx->arena.reset();
+        body(pl->src, pl->tgt, pl->exp, pl->text, pl->mask);
+      } catch (...) {
+        hipStreamEndCapture(s, &g);
+        if (g) hipGraphDestroy(g);
+        throw;
+      }
+      HIP_OK(hipStreamEndCapture(s, &g));
+      const hipError_t e = hipGraphInstantiate(&pl->exec, g, nullptr, nullptr, 0);
+      hipGraphDestroy(g);
+      HIP_OK(e);
+      pl->arena_base = ctx->arena.base;
+    }
+    HIP_OK(hipGraphLaunch(pl->exec, s));
+  } else {
     ctx->arena.reset();
-    body();
+    body(src, tgt, expected, text, mask);
   }
   if (losses_host) {
     HIP_OK(hipMemcpyAsync(tr->h_losses, tr->d_losses, 5 * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -377,7 +449,10 @@ extern "C" int svg_transformer_tensor(svg_ctx* ctx, int kind, const char* name, 
 extern "C" int svg_op_dropout_mask(svg_ctx* ctx, uint64_t seed, int site, float p, float* out, int64_t n, void* stream) {
   try {
     SVG_CHECK(ctx && out && n >= 0 && p >= 0.f && p < 1.f && site >= 0, "svg_op_dropout_mask: bad argument");
-    xf_drop_mask(XfDrop{seed, (uint32_t)site, p}, out, n, (hipStream_t)stream);
+    if (!ctx->seed_scratch) ctx->seed_scratch = (uint64_t*)ctx->dalloc(sizeof(uint64_t));
+    HIP_OK(hipMemcpyAsync(ctx->seed_scratch, &seed, sizeof(uint64_t), hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));            // `seed` is a stack word
+    xf_drop_mask(XfDrop{ctx->seed_scratch, (uint32_t)site, p}, out, n, (hipStream_t)stream);
     return 0;
   } catch (const std::exception& e) { return svg_fail(ctx, e); }
 }

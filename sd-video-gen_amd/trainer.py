@@ -70,6 +70,7 @@ class Trainer:
         self.sd_utils = sd_utils
         self.SOS_token = torch.ones((1, 1, self.config.FRAME_SIZE ** 2 // 64 * 4), dtype=torch.float32, device=self.device) * 2
         self.seed = 0           # dropout: one fresh seed per training iteration
+        self._stream = torch.cuda.Stream() if torch.cuda.is_available() else None   # capturable: the library replays a step as one hipGraph
         self.log = lambda rec: print(json.dumps(rec), flush=True)
 
     def criterion(self, use_mse=True, use_L1=False, use_gdl=True, lambda_gdl=1, alpha=2, use_contrastive=True, temperature=0.07,
@@ -91,9 +92,12 @@ class Trainer:
             cfg = loss_fn.cfg(frames_to_predict, model.positional_encoder.dropout_p if train else 0.0, self.seed)
             if train:
                 opt.zero_grad()
-            terms = model.training_loss(cfg, new_batch, backward=train)                    # :141-145 (+ loss.backward(), :164)
-            if train:
-                opt.step()                                                                 # :165
+            torch.cuda.current_stream().synchronize()                                      # the encoded batch is ready
+            with torch.cuda.stream(self._stream):
+                terms = model.training_loss(cfg, new_batch, backward=train)                # :141-145 (+ loss.backward(), :164)
+                if train:
+                    opt.step()                                                             # :165
+            self._stream.synchronize()
             for k in sums:
                 sums[k] += terms[k]
             n += 1

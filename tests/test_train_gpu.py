@@ -295,3 +295,31 @@ def test_more_rows_than_one_weight_pass(ctx):
     got = m.training_loss(cfg_of(4, 8, w), nb.cuda())
     assert abs(got["total"] - total) <= 5e-6 * abs(total)
     check_grads(m, leaves, "400 rows")
+
+
+def test_graph_replay_equals_direct_launches(ctx):
+    """On a non-default stream the step is captured into a hipGraph once per call signature and replayed from staging buffers with
+    the seed in device memory: same bits as the direct launches (default stream), for new inputs and new seeds, through Adam steps."""
+    sd = torch.load(os.path.join(GOLD, "transformer_tiny.pt"))["state_dict"]
+    p = 0.2
+    w = dict(w_mse=1.0, w_gdl=0.5, alpha=2, w_contrastive=0.05, temperature=0.1)
+    ma = make_model("model_10_26", ctx, sd, dropout_p=p, dim_model=32, num_heads=4, num_encoder_layers=1, num_decoder_layers=2)
+    mb = make_model("model_10_26", _lib.Context(0), sd, dropout_p=p, dim_model=32, num_heads=4, num_encoder_layers=1, num_decoder_layers=2)
+    ma.train(); mb.train()
+    side = torch.cuda.Stream()
+    g = torch.Generator().manual_seed(40)
+    for it in range(4):
+        nb = torch.cat([2.0 * torch.ones(3, 1, 256), torch.randn(3, 6, 256, generator=g)], dim=1).cuda()
+        cfg = cfg_of(3, 8, w, dropout_p=p, seed=100 + it)
+        la = ma.training_loss(cfg, nb)                       # default stream: direct launches
+        ma.adam_step(1e-3)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):                        # side stream: captured at it == 0, replayed afterwards
+            lb = mb.training_loss(cfg, nb)
+            mb.adam_step(1e-3)
+        side.synchronize()
+        assert la == lb, (it, la, lb)
+        for k in ("embedding.weight", "transformer.decoder.layers.1.multihead_attn.in_proj_weight", "out.bias"):
+            assert torch.equal(ma.grad_of(k), mb.grad_of(k)), (it, k)
+    sa, sb = ma.state_dict(), mb.state_dict()
+    assert all(torch.equal(sa[k].cpu(), sb[k].cpu()) for k in sa)
