@@ -30,7 +30,7 @@ constexpr int F_LDS = F_OFF_S1 + 2 * 2 * FH * 4;
 struct FfArgs {
   const bf16* X; int ldx;               // pre-LayerNorm input rows
   const bf16* W1; const float* b1; const float* s1;   // packed GEGLU weights [2*FH][FC] (h / gate tiles of 16 rows alternate), folded bias, row sums
-  const float* rs; const float* rm;     // LayerNorm row statistics: rstd, rstd * mean
+  const float* rs; const float* rm;     // LayerNorm row statistics: rstd, rstd * mean; both null: computed here from the rows in registers
   const bf16* W2p; const float* b2;     // [FC][FH], k permuted inside 32-blocks (pack_ff2_perm)
   const bf16* residual; int ldr;
   bf16* out; int ldo;
@@ -90,7 +90,28 @@ __global__ void __launch_bounds__(512, 2) ff_fused_kernel(const FfArgs a) {
     if (m_ok) v = *(const uint4*)(a.X + (int64_t)m * a.ldx + ks * 32 + lq * 8);
     xf[ks] = *(bf16x8*)&v;
   }
-  const float rs = m_ok ? a.rs[m] : 0.f, rm = m_ok ? a.rm[m] : 0.f;
+  float rs, rm;
+  if (a.rs) {
+    rs = m_ok ? a.rs[m] : 0.f; rm = m_ok ? a.rm[m] : 0.f;
+  } else {
+    // the four lanes l15 + 16 * lq hold the whole row (80 values each): two-pass statistics like ln_stats_kernel (eps 1e-5), without
+    // the extra pass over the tensor
+    float sum = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < F_KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += (float)xf[ks][j];
+    sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.f / FC);
+    float sq = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < F_KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float dlt = (float)xf[ks][j] - mean; sq += dlt * dlt; }
+    sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
+    rs = m_ok ? rsqrtf(sq * (1.f / FC) + 1e-5f) : 0.f;
+    rm = rs * mean;
+  }
 
   f32x4 acc2[FC / 16];
 #pragma unroll

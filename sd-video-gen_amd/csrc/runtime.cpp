@@ -373,8 +373,10 @@ int svg_op_ff_fused(svg_ctx* ctx, const uint16_t* x, const float* ln_gamma, cons
       rowsum_bf16(w1p, s1, 2 * F, C, s);
       pack_ff2_perm(w2d, w2p, C, F, s);
     }
-    ln_stats(ctx, (const bf16*)x, rs, rm, M, C, 1e-5f, s);
-    ff_fused(ctx, (const bf16*)x, C, w1p, b1p, s1, rs, rm, w2p, b2d, (const bf16*)residual, C, (bf16*)out, C, M, s);
+    // the kernel derives the LayerNorm statistics from the rows it holds (the UNet's path); SVG_FF_LNSTATS=1 feeds it ln_stats' instead
+    static const bool ext = getenv("SVG_FF_LNSTATS") && atoi(getenv("SVG_FF_LNSTATS"));
+    if (ext) ln_stats(ctx, (const bf16*)x, rs, rm, M, C, 1e-5f, s);
+    ff_fused(ctx, (const bf16*)x, C, w1p, b1p, s1, ext ? rs : nullptr, ext ? rm : nullptr, w2p, b2d, (const bf16*)residual, C, (bf16*)out, C, M, s);
   });
   API_END(ctx)
 }

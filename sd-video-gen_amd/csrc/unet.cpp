@@ -418,14 +418,15 @@ struct UnetRun {
     bf16* h2 = ctx->arena.get<bf16>(P * C);
     linear(ctx, ao, C, b.o2, h2, C, M, ACT_NONE, h1, C, 0, s);
     // ---- GEGLU feed-forward
-    const bf16* a3 = norm(h2, b.ln3);
+    const bool ff_one = fold && b.ff2p && ff_fused_supported(C, M);
+    const bf16* a3 = ff_one ? h2 : norm(h2, b.ln3);     // the fused feed-forward takes its LayerNorm statistics from the rows it holds
     {
       // The GEGLU intermediate is M x 4C (293 MB at 28 clips x 64 x 64 x 1280): written by ff1 and read back by ff2.  Run
       // the pair over row chunks whose intermediate fits the 256 MiB Infinity Cache (with the other stream group's share):
       // the same chunk-sized buffer is rewritten per chunk, so ff2 reads it from the cache instead of HBM.
-      if (fold && b.ff2p && ff_fused_supported(C, M)) {
+      if (ff_one) {
         // ff1 -> GEGLU -> ff2 in one kernel: the M x 4C intermediate never leaves the CU (h is free again: reused as h3)
-        ff_fused(ctx, h2, C, b.ff1.w, b.ff1.b, b.ff1.ln_s, rs, rm, b.ff2p, b.ff2.b, h2, C, h, C, M, s);
+        ff_fused(ctx, h2, C, b.ff1.w, b.ff1.b, b.ff1.ln_s, nullptr, nullptr, b.ff2p, b.ff2.b, h2, C, h, C, M, s);
       } else {
       ctx->arena.push();
       const int rows = ff_chunk_rows(M, C);
