@@ -238,6 +238,7 @@ class Context:
     def transformer_tensor(self, name, like, kind=SVG_TENSOR_PARAM):
         """Copy of parameter `name` (or its gradient / Adam moment) shaped like `like`, on the CPU."""
         out = torch.empty(tuple(like.shape), dtype=torch.float32)
+        torch.cuda.synchronize()      # training steps may have run on another (non-blocking) stream than the current one
         self.check(self.lib.svg_transformer_tensor(self.h, kind, name.encode(), out.data_ptr(), out.numel(), _stream()),
                    "svg_transformer_tensor(%s)" % name)
         return out
