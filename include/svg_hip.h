@@ -185,6 +185,10 @@ int svg_op_conv3x3_gn(svg_ctx* ctx, const uint16_t* x, const float* w_oihw, cons
                       int groups, float eps, int silu, int* used_epilogue_stats, void* stream);
 /* C[M,N] = [A | A2] * W[N,K]^T + bias with the A operand given as two tensors (A: M x k_split, A2: M x (K - k_split)): the
  * torch.cat([hidden, skip], dim=1) in front of a resnet's 1x1 shortcut, never materialised.  k_split % 64 == 0. */
+/* C[batch*M,N] = A W^T + bias + residual, and the LayerNorm statistics of its rows (rs = rstd, rm = rstd * mean, eps 1e-5) as the
+ * transformer blocks of the UNet get them: from row partials the GEMM epilogue emits (*used = column tiles that emitted, 0 = fallback pass) */
+int svg_op_gemm_lnstats(svg_ctx* ctx, const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* residual, uint16_t* C, int M,
+                        int N, int K, int batch, float* rs, float* rm, int* used, void* stream);
 int svg_op_gemm_cat(svg_ctx* ctx, const uint16_t* A, const uint16_t* A2, const uint16_t* W, const float* bias, uint16_t* C,
                     int M, int N, int K, int k_split, void* stream);
 /* Fused GEGLU feed-forward of a BasicTransformerBlock (C = 320): out = ff.net.2(GEGLU(ff.net.0(LayerNorm(x)))) + residual in ONE

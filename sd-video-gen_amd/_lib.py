@@ -56,6 +56,7 @@ SIGNATURES = {
     "svg_op_gemm": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "svg_op_conv3x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "svg_op_conv3x3_gn": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, C.POINTER(_i), _vp],
+    "svg_op_gemm_lnstats": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, C.POINTER(_i), _vp],
     "svg_op_gemm_cat": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "svg_op_ff_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "svg_op_dropout_mask": [_vp, C.c_uint64, _i, _f, _vp, _i64, _vp],

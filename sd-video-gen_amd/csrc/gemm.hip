@@ -21,6 +21,7 @@ bool conv_halo_supported(const GemmArgs& g);
 int conv_halo_bn(const GemmArgs& g);
 void launch_conv_halo(const GemmArgs& g, dim3 grid, hipStream_t s);
 bool gemm_pp_supported(const GemmArgs& g);
+int gemm_pp_bn(const GemmArgs& g);
 void launch_gemm_pp(const GemmArgs& g, hipStream_t s);
 
 namespace {
@@ -272,7 +273,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const GemmArgs g) {
     return;
   }
   // (an LDS-staged, 16-byte coalesced store variant measured no faster: L2 merges the 8-byte pieces)
-  epi_tile<MT, NT>(g, z, m0 + wm * 64 + l15, 16, n0 + wn * (BN / 2) + lq * 4, acc, smem, 2, wm, wn, tm, n0);
+  epi_tile<MT, NT, AMODE == A_DENSE>(g, z, m0 + wm * 64 + l15, 16, n0 + wn * (BN / 2) + lq * 4, acc, smem, 2, wm, wn, tm, n0);
 }
 
 // sums the split-K slabs and applies the epilogue
@@ -405,6 +406,17 @@ int gemm_emits_gn(const GemmArgs& g0) {
   if (conv_halo_supported(g)) return 256;
   if (gemm_pp_supported(g)) return 256;
   return pick_bn(g) >= 32 ? BM : 0;
+}
+
+int gemm_ln_tiles(const GemmArgs& g0) {
+  GemmArgs g = g0;
+  if (g.n_valid <= 0) g.n_valid = g.N;
+  if (g.out_f32 || g.act == ACT_GEGLU || g.N > g.ldc || g.amode != A_DENSE || g.bias_row) return 0;
+  if (plan_splitk(g) > 1) return 0;
+  g.splitk = 1;
+  if (gemm_pp_supported(g)) return cdiv(g.N, gemm_pp_bn(g));
+  const int bn = pick_bn(g);
+  return bn >= 128 ? cdiv(g.N, bn) : 0;
 }
 
 void gemm_init_device() { attr_bn<32>(); attr_bn<64>(); attr_bn<128>(); attr_bn<160>(); }

@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs g) {
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------------------
-  epi_tile<MT, NT>(g, 0, m0 + wm * 64 + l15, 16, n0 + wn * (BN / 2) + lq * 4, acc, smem, 4, wm, wn, tm, n0);
+  epi_tile<MT, NT, true>(g, 0, m0 + wm * 64 + l15, 16, n0 + wn * (BN / 2) + lq * 4, acc, smem, 4, wm, wn, tm, n0);
 }
 
 template <int BN>

@@ -166,11 +166,13 @@ __device__ __forceinline__ void bar() {
 // 16-lane butterfly finishes the wave's rows, the waves of the tile meet in LDS (`lds`: the tile's staging memory, free after
 // the K loop) and the first BN_ threads add them in a fixed order.  WM_ = waves along M, wm / wn = this wave's position,
 // BNH_ = columns per wave, tile_m = row-tile index, n0 = first column of the tile.
-template <int MT_, int NT_>
+// LN_ (dense GEMMs only): additionally emit the LayerNorm row partials of the stored values (GemmArgs::ln_part).
+template <int MT_, int NT_, bool LN_ = false>
 __device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int mstep, int nc, f32x4 (&acc)[MT_][NT_],
                                          char* lds = nullptr, int WM_ = 0, int wm = 0, int wn = 0, int tile_m = 0, int n0 = 0) {
   const bool geglu = g.act == ACT_GEGLU;
   const bool emit_gn = g.gn_part != nullptr && lds != nullptr;
+  const bool emit_ln = LN_ && g.ln_part != nullptr && lds != nullptr;
   const float* const bias_z = g.bias ? g.bias + (int64_t)z * g.bias_zs : nullptr;
   float alpha = g.alpha;
   if (g.ln_rs) { ln_fold_tile<MT_, NT_>(g, z, mr, mstep, nc, alpha, acc); alpha = 1.f; }
@@ -266,7 +268,7 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int m
             *(bf16x4*)((bf16*)g.C + o) = w;
             // the accumulator is dead from here: keep what the consumer will read (the rounded values) in it for the
             // GroupNorm column sums below — no extra registers live across the stores
-            if (emit_gn) { acc[i][j][0] = (float)w[0]; acc[i][j][1] = (float)w[1]; acc[i][j][2] = (float)w[2]; acc[i][j][3] = (float)w[3]; }
+            if (emit_gn || emit_ln) { acc[i][j][0] = (float)w[0]; acc[i][j][1] = (float)w[1]; acc[i][j][2] = (float)w[2]; acc[i][j][3] = (float)w[3]; }
           }
         }
       }
@@ -306,6 +308,43 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int m
       float a = 0.f, b = 0.f;
       for (int w = 0; w < WM_; ++w) { a += sc[(w * ncols + col) * 2]; b += sc[(w * ncols + col) * 2 + 1]; }
       *(float2*)(g.gn_part + ((int64_t)tile_m * g.N + n) * 2) = make_float2(a, b);
+    }
+  }
+  if (emit_ln) {
+    // LayerNorm row partials of this tile's columns: the four lanes l15 + 16 * lq hold a row's columns of the wave tile; the
+    // waves along N meet in LDS and are added in order.  acc holds the stored (rounded) values (rows / columns past M / N: skipped).
+    const int lane = threadIdx.x & 63;
+    const int WN_ = (blockDim.x >> 6) / WM_;
+    const int trows = WM_ * MT_ * 16;
+    float* sc = (float*)lds;                                // [WN_][trows][2]
+    bar();
+#pragma unroll
+    for (int i = 0; i < MT_; ++i) {
+      const int m = mr + mstep * i;
+      float a = 0.f, b = 0.f;
+      if (m < g.M) {
+#pragma unroll
+        for (int j = 0; j < NT_; ++j)
+          if (nc + 16 * j < g.N) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float v = acc[i][j][e]; a += v; b += v * v; }
+          }
+      }
+      a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
+      a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
+      if ((lane >> 4) == 0) {
+        const int rl = m - tile_m * trows;
+        *(float2*)(sc + ((size_t)wn * trows + rl) * 2) = make_float2(a, b);
+      }
+    }
+    bar();
+    const int tile_n = n0 / (WN_ * NT_ * 16);
+    for (int rl = threadIdx.x; rl < trows; rl += blockDim.x) {
+      const int m = tile_m * trows + rl;
+      if (m >= g.M) continue;
+      float a = 0.f, b = 0.f;
+      for (int w = 0; w < WN_; ++w) { a += sc[((size_t)w * trows + rl) * 2]; b += sc[((size_t)w * trows + rl) * 2 + 1]; }
+      *(float2*)(g.ln_part + (((int64_t)z * g.M + m) * g.ln_tiles + tile_n) * 2) = make_float2(a, b);
     }
   }
 }

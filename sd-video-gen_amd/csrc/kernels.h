@@ -58,6 +58,10 @@ struct GemmArgs {
   // tile in a fixed order (deterministic).  Row tile = 128 rows (igemm), 256 rows (gemm_pp) or a 16 x 16 pixel block (halo conv);
   // only without split-K.  gemm_emits_gn() says whether a problem qualifies and how many rows a tile has.
   float* gn_part = nullptr;
+  // LayerNorm row sums of the stored (bf16-rounded) values, one partial per column tile: ln_part[(m * ln_tiles + tile_n) * 2 + {0,1}]
+  // = sum, sum of squares of row m over the tile's columns (the consumer's ln_finish turns them into rstd, rstd * mean)
+  float* ln_part = nullptr;
+  int ln_tiles = 0;
   int64_t bias_zs = 0;               // batched problems: element stride of `bias` per batch (0 = shared)
   int tn_major = 0;                  // tile order inside an XCD's run: 0 = tiles sharing the A rows adjacent, 1 = tiles sharing the weights adjacent
   int dbg = 0;                       // ablation switch (SVG_GEMM_DBG): 1 no stores, 2 no MFMA, 3 no DMA, 5 LDS-staged epilogue
@@ -103,6 +107,10 @@ void pack_geglu(const float* w, const float* b, bf16* wout, float* bout, int F, 
 // ------------------------------------------------------------------------------------------------
 // normalisation / softmax
 // ------------------------------------------------------------------------------------------------
+// column tiles a dense GEMM launch of g will use when it can emit LayerNorm row partials (0: it cannot — split-K, f32 / GEGLU output ...)
+int gemm_ln_tiles(const GemmArgs& g);
+// rs[m] = rstd, rm[m] = rstd * mean of row m from `tiles` partials per row (GemmArgs::ln_part)
+void ln_finish(svg_ctx* ctx, const float* part, int tiles, float* rs, float* rm, int M, int C, float eps, hipStream_t s);
 // per-row-tile column sums of a tensor, emitted by the epilogue that produced it (GemmArgs::gn_part)
 struct GnStats {
   const float* part = nullptr;   // [B * tiles_per_sample][C][2]

@@ -149,6 +149,12 @@ struct GnEmit {
   float* buf = nullptr;
   GnStats st;
 };
+// Request for the LayerNorm row partials of a linear()'s output (GemmArgs::ln_part): the caller provides `buf` (M * 16 floats covers
+// every tile width here); `tiles` > 0 afterwards when the launch emitted them (else the consumer runs ln_stats).
+struct LnEmit {
+  float* buf = nullptr;
+  int tiles = 0;
+};
 static inline int64_t gn_part_floats(int64_t B, int64_t HW, int64_t N) { return B * (HW / 128 + 1) * N * 2; }
 
 // shared graph pieces (sdnet.cpp)
@@ -168,4 +174,4 @@ void conv3x3(svg_ctx* ctx, const bf16* x, const ConvW& cw, void* out, int B, int
 // channel concat [A | A2] of two tensors (columns >= k_split come from A2, row stride lda2) without materialising it.
 void linear(svg_ctx* ctx, const bf16* A, int lda, const PackedLinear& pl, void* C, int ldc, int M, int act, const bf16* residual,
             int ldr, int out_f32, hipStream_t s, const float* ln_rs = nullptr, const float* ln_rm = nullptr, GnEmit* emit = nullptr,
-            int rows_per_sample = 0, const bf16* A2 = nullptr, int lda2 = 0, int k_split = 0);
+            int rows_per_sample = 0, const bf16* A2 = nullptr, int lda2 = 0, int k_split = 0, LnEmit* ln = nullptr);

@@ -345,6 +345,19 @@ __global__ void __launch_bounds__(256) ln_stats_kernel(const bf16* __restrict__ 
   if (lane == 0) { rs[row] = rstd; rm[row] = rstd * mean; }
 }
 
+// rs / rm from the row partials the producing GEMM's epilogue left (GemmArgs::ln_part): tiles are added in order; the variance is
+// E[x^2] - mean^2 of the bf16 values the consumer will read, in f32 (C <= 1280 terms of O(1..100) magnitude)
+__global__ void ln_finish_kernel(const float* __restrict__ part, int tiles, float* __restrict__ rs, float* __restrict__ rm, int M, int C, float eps) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  float a = 0.f, b = 0.f;
+  for (int t = 0; t < tiles; ++t) { const float2 p = *(const float2*)(part + ((int64_t)m * tiles + t) * 2); a += p.x; b += p.y; }
+  const float mean = a / (float)C;
+  const float var = fmaxf(b / (float)C - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + eps);
+  rs[m] = rstd; rm[m] = rstd * mean;
+}
+
 // ---- LayerNorm folding at load time --------------------------------------------------------------------------------
 // one block per output row: bias_out[n] = bias_in[n] + sum_k W[n][k] beta[k], then W[n][k] *= gamma[k]
 __global__ void __launch_bounds__(256) fold_ln_kernel(float* __restrict__ w, const float* __restrict__ bin, const float* __restrict__ gamma,
@@ -507,6 +520,15 @@ void ln_stats(svg_ctx* ctx, const bf16* x, float* rs, float* rm, int M, int C, f
   ProfScope ps(ctx, PK_LNORM, s, 0, 2.0 * M * C, tag);
   hipLaunchKernelGGL(ln_stats_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, x, rs, rm, M, C, eps);
   check_launch("ln_stats");
+}
+
+void ln_finish(svg_ctx* ctx, const float* part, int tiles, float* rs, float* rm, int M, int C, float eps, hipStream_t s) {
+  if (!SVG_LAUNCHING(ctx)) return;
+  char tag[64];
+  snprintf(tag, sizeof(tag), "finish_M%d_C%d_t%d", M, C, tiles);
+  ProfScope ps(ctx, PK_LNORM, s, 0, 8.0 * M * tiles, tag);
+  hipLaunchKernelGGL(ln_finish_kernel, dim3(cdiv(M, 256)), dim3(256), 0, s, part, tiles, rs, rm, M, C, eps);
+  check_launch("ln_finish");
 }
 
 void fold_ln_weights(float* w, const float* bias_in, const float* gamma, const float* beta, float* bias_out, int N, int K, hipStream_t s) {

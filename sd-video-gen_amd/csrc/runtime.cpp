@@ -339,6 +339,30 @@ int svg_op_gemm_cat(svg_ctx* ctx, const uint16_t* A, const uint16_t* A2, const u
   API_END(ctx)
 }
 
+// C = A W^T + bias + residual (bf16) with the LayerNorm row statistics of C taken from the epilogue's row partials (GemmArgs::ln_part
+// + ln_finish): rs[m] = rstd, rm[m] = rstd * mean over the N columns; *used = column tiles that emitted (0: the launch could not, rs / rm
+// then come from the ln_stats pass).  Test hook.
+int svg_op_gemm_lnstats(svg_ctx* ctx, const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* residual, uint16_t* C, int M,
+                        int N, int K, int batch, float* rs, float* rm, int* used, void* stream) {
+  API_BEGIN
+  int tiles = 0;
+  run_planned(ctx, [&]() {
+    GemmArgs g;
+    g.A = (const bf16*)A; g.lda = K; g.Wt = (const bf16*)W; g.ldb = K; g.M = M; g.N = N; g.K = K; g.n_valid = N; g.bias = bias;
+    g.residual = (const bf16*)residual; g.ldr = N; g.C = C; g.ldc = N;
+    if (batch > 1) { g.batch = batch; g.sA = (int64_t)M * K; g.sB = 0; g.sC = (int64_t)M * N; }
+    float* part = ctx->arena.get<float>((int64_t)batch * M * 16);
+    tiles = gemm_ln_tiles(g);
+    if (tiles > 8) tiles = 0;
+    if (tiles > 0) { g.ln_part = part; g.ln_tiles = tiles; }
+    gemm_auto(ctx, g, (hipStream_t)stream, PK_GEMM);
+    if (tiles > 0) ln_finish(ctx, part, tiles, rs, rm, batch * M, N, 1e-5f, (hipStream_t)stream);
+    else ln_stats(ctx, (const bf16*)C, rs, rm, batch * M, N, 1e-5f, (hipStream_t)stream);
+  });
+  if (used) *used = tiles;
+  API_END(ctx)
+}
+
 // fused GEGLU feed-forward of a transformer block at C = 320: out = ff2(GEGLU(ff1(LayerNorm(x)))) + residual.  Weights in the
 // state_dict layout (W1 [2*4C][C] = [h; gate], W2 [C][4C]); folding, packing and the row statistics happen here (test hook).
 int svg_op_ff_fused(svg_ctx* ctx, const uint16_t* x, const float* ln_gamma, const float* ln_beta, const float* w1, const float* b1,

@@ -135,7 +135,8 @@ void conv3x3(svg_ctx* ctx, const bf16* x, const ConvW& cw, void* out, int B, int
 
 void linear(svg_ctx* ctx, const bf16* A, int lda, const PackedLinear& pl, void* C, int ldc, int M, int act, const bf16* residual,
             int ldr, int out_f32, hipStream_t s, const float* ln_rs, const float* ln_rm, GnEmit* emit, int rows_per_sample,
-            const bf16* A2, int lda2, int k_split) {
+            const bf16* A2, int lda2, int k_split, LnEmit* ln) {
+  if (ln) ln->tiles = 0;
   SVG_CHECK((pl.ln_s != nullptr) == (ln_rs != nullptr), "linear: LayerNorm-folded weights need the row statistics (and only they)");
   {   // 32-bit operand offsets in the kernels: split very tall problems (1 x 1 convs on the 512 x 512 VAE levels) by rows
     const int64_t lim = chunk_limit();
@@ -169,5 +170,10 @@ void linear(svg_ctx* ctx, const bf16* A, int lda, const PackedLinear& pl, void* 
   g.bias = pl.b; g.act = act; g.residual = residual; g.ldr = ldr; g.C = C; g.ldc = ldc; g.out_f32 = out_f32;
   g.A2 = A2; g.lda2 = lda2; g.k_split = k_split;
   plan_gn_emit(g, emit, rows_per_sample);
+  if (ln && ln->buf) {
+    static const int use_ln = getenv("SVG_LN_EPI") ? atoi(getenv("SVG_LN_EPI")) : 1;    // 0: A/B switch, ln_stats pass as before
+    const int tiles = use_ln ? gemm_ln_tiles(g) : 0;
+    if (tiles > 0 && tiles <= 5) { g.ln_part = ln->buf; g.ln_tiles = tiles; ln->tiles = tiles; }   // C = 1280 (8 tiles): the finish costs what the 8 us pass did
+  }
   gemm_auto(ctx, g, s, PK_GEMM);
 }

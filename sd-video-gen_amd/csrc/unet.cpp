@@ -342,6 +342,11 @@ struct UnetRun {
     GnEmit eo = emit_for(HW, C);
     ctx->arena.push();
     bf16* h = ctx->arena.get<bf16>(P * C);
+    // LayerNorm row partials: the three LayerNorm inputs of the block (proj_in output, the two attention residual sums) are written by
+    // GEMM epilogues that leave per-tile row sums here; ln_finish replaces the statistics pass over the tensor (one buffer: a
+    // LayerNorm's partials are consumed before the next producer runs)
+    LnEmit le;
+    le.buf = ctx->arena.get<float>((int64_t)M * 16);
     static const int gn_fold = getenv("SVG_GN_FOLD") ? atoi(getenv("SVG_GN_FOLD")) : 1;
     if (gn_fold && xa.st.valid() && b.proj_in_f32) {
       // GroupNorm (no activation) -> proj_in: the normalisation is folded into per-sample weights, so the normalised tensor
@@ -359,12 +364,18 @@ struct UnetRun {
       g.A = x; g.lda = C; g.Wt = wb; g.ldb = C; g.M = HW; g.N = C; g.K = C; g.n_valid = C;
       g.batch = N; g.sA = (int64_t)HW * C; g.sB = (int64_t)C * C; g.sC = (int64_t)HW * C;
       g.bias = bb; g.bias_zs = C; g.C = h; g.ldc = C;
+      {
+        static const int use_ln = getenv("SVG_LN_EPI") ? atoi(getenv("SVG_LN_EPI")) : 1;
+        const int tiles = use_ln ? gemm_ln_tiles(g) : 0;
+        le.tiles = 0;
+        if (tiles > 0 && tiles <= 5) { g.ln_part = le.buf; g.ln_tiles = tiles; le.tiles = tiles; }
+      }
       gemm_auto(ctx, g, s, PK_GEMM);
       ctx->arena.pop();
     } else {
       bf16* n0 = ctx->arena.get<bf16>(P * C);
       groupnorm(ctx, x, C, nullptr, 0, b.gn.g, b.gn.b, n0, N, HW, m->groups, 1e-6f, 0, s, &xa.st, nullptr);
-      linear(ctx, n0, C, b.proj_in, h, C, M, ACT_NONE, nullptr, 0, 0, s);
+      linear(ctx, n0, C, b.proj_in, h, C, M, ACT_NONE, nullptr, 0, 0, s, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, &le);
     }
     // LayerNorms: folded into the consuming projections (row statistics only) unless SVG_LN_FOLD=0
     const bool fold = b.qk1.ln_s != nullptr;
@@ -372,7 +383,12 @@ struct UnetRun {
     float* rs = fold ? ctx->arena.get<float>(M + 8) : nullptr;
     float* rm = fold ? ctx->arena.get<float>(M + 8) : nullptr;
     auto norm = [&](const bf16* src, const NormW& n) -> const bf16* {
-      if (fold) { ln_stats(ctx, src, rs, rm, M, C, 1e-5f, s); return src; }
+      if (fold) {
+        if (le.tiles > 0) ln_finish(ctx, le.buf, le.tiles, rs, rm, M, C, 1e-5f, s);   // src's producer left its row partials
+        else ln_stats(ctx, src, rs, rm, M, C, 1e-5f, s);
+        le.tiles = 0;
+        return src;
+      }
       layernorm(ctx, src, n.g, n.b, ln, M, C, 1e-5f, s);
       return ln;
     };
@@ -389,7 +405,7 @@ struct UnetRun {
       ctx->arena.pop();
     }
     bf16* h1 = ctx->arena.get<bf16>(P * C);
-    linear(ctx, ao, C, b.o1, h1, C, M, ACT_NONE, h, C, 0, s);
+    linear(ctx, ao, C, b.o1, h1, C, M, ACT_NONE, h, C, 0, s, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, &le);
     // ---- cross-attention
     const bf16* a2 = norm(h1, b.ln2);
     {
@@ -416,7 +432,7 @@ struct UnetRun {
       ctx->arena.pop();
     }
     bf16* h2 = ctx->arena.get<bf16>(P * C);
-    linear(ctx, ao, C, b.o2, h2, C, M, ACT_NONE, h1, C, 0, s);
+    linear(ctx, ao, C, b.o2, h2, C, M, ACT_NONE, h1, C, 0, s, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, &le);
     // ---- GEGLU feed-forward
     const bool ff_one = fold && b.ff2p && ff_fused_supported(C, M);
     const bf16* a3 = ff_one ? h2 : norm(h2, b.ln3);     // the fused feed-forward takes its LayerNorm statistics from the rows it holds

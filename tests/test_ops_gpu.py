@@ -419,3 +419,33 @@ def test_resize_nearest_u8(ctx):
     odd = ctx.resize_nearest_u8(img, 100, 37)
     ref = F.interpolate(img.permute(0, 3, 1, 2).float(), (100, 37)).permute(0, 2, 3, 1).to(torch.uint8)
     assert torch.equal(odd, ref)
+
+
+@pytest.mark.parametrize("M,N,K,batch,res", [(4096, 320, 320, 1, True), (1000, 640, 640, 1, True), (512, 1280, 1280, 1, True), (4096, 320, 320, 3, False),
+                                            (28672, 640, 640, 1, True), (7168, 1280, 1280, 1, True), (25000, 640, 640, 1, False),
+                                            (256, 1280, 320, 2, False), (64, 1280, 1280, 2, False), (300, 64, 64, 1, False)])
+def test_gemm_epilogue_layernorm_statistics(ctx, M, N, K, batch, res):
+    """The transformer blocks take the LayerNorm row statistics of a GEMM's output from row partials its epilogue emits (sum and sum of
+    squares of the bf16 values it stores, per column tile) instead of a pass over the tensor: against statistics of the stored output."""
+    import ctypes as C
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + batch)
+    A = bf(torch.randn(batch * M, K, device="cuda", generator=g))
+    W = bf(torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K))
+    bias = torch.randn(N, device="cuda", generator=g) * 3.0            # a row mean away from zero
+    R = bf(torch.randn(batch * M, N, device="cuda", generator=g)) if res else None
+    out = torch.empty(batch * M, N, device="cuda", dtype=torch.bfloat16)
+    rs = torch.empty(batch * M, device="cuda")
+    rm = torch.empty(batch * M, device="cuda")
+    used = C.c_int(-1)
+    ctx.check(ctx.lib.svg_op_gemm_lnstats(ctx.h, u16(A), u16(W), bias.data_ptr(), u16(R) if res else None, out.data_ptr(), M, N, K, batch,
+                                          rs.data_ptr(), rm.data_ptr(), C.byref(used), stream()), "gemm_lnstats")
+    ref = A.float() @ W.float().t() + bias + (R.float() if res else 0.0)
+    assert rel_l2(out.float(), ref) < 4e-3
+    x = out.float()
+    mean, var = x.mean(dim=1), x.var(dim=1, unbiased=False)
+    rstd = torch.rsqrt(var + 1e-5)
+    if M >= 4096:                                        # enough tiles for a launch without split-K: the epilogue must have emitted
+        assert used.value in (-(-N // 128), -(-N // 160)), used.value
+    else:
+        assert used.value >= 0                           # small problems may take split-K (no emission): the statistics pass fills rs / rm
+    assert rel_l2(rs, rstd) < 2e-5 and rel_l2(rm, rstd * mean) < 2e-5, (used.value, rel_l2(rs, rstd), rel_l2(rm, rstd * mean))
