@@ -215,8 +215,11 @@ def roofline_pass(args, sd_utils, step, denoise, C):
         if e["bound"] == "mfma":      # the other ceiling, for the short-K shapes whose operands bound them before the matrix pipe does
             e["algorithmic_gb_per_s"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9
             e["frac_of_hbm_peak"] = e["algorithmic_gb_per_s"] / (PEAK_HBM / 1e9)
-        if pmc and k in pmc[1]["families"] and pmc[1]["families"][k]["launches"] == v["calls"]:
-            e["traffic"] = pmc[1]["families"][k]["hbm_bytes_per_launch"]
+        if pmc and k in pmc[1]["families"]:
+            # per launch in the sense of `achieved`: one bracketed call (a GEMM and its split-K reduce are two kernels, one launch here)
+            pf = pmc[1]["families"][k]
+            e["traffic"] = (pf["fetch_bytes"] + pf["write_bytes"]) / v["calls"]
+            e["traffic_kernels"] = pf["launches"]
             e["traffic_source"] = "profiles/%s (%s)" % (pmc[0], pmc[1].get("note", ""))
         by_family[k] = e
     dom_name = max((k for k in by_family if by_family[k]["bound"] == "mfma"), key=lambda k: by_family[k]["ms"])
