@@ -156,7 +156,7 @@ HBM_FAMILIES = {"groupnorm": "gn_stats / gn_apply / gn_small", "layernorm": "ln_
                 "eltwise": "layout / DDIM step / image pre-post kernels", "softmax": "VAE mid-block row softmax"}
 
 
-def roofline_pass(args, sd_utils, step, denoise, C):
+def roofline_pass(args, sd_utils, step, denoise, C, model=None):
     """Instrumented pass on rank 0: ONE stream group's clips alone, hipEvent brackets recorded by the library on the launch
     stream around every launch of each kernel family (svg_prof_*).  `roofline` is the family that takes the most time;
     `roofline.by_family` lists every family against its own bound."""
@@ -187,6 +187,25 @@ def roofline_pass(args, sd_utils, step, denoise, C):
                            "rows_per_forward": n_grp * 6,
                            "f32_mfma_tflops": dom["flops"] / (dom["ms"] * 1e-3) / 1e12,
                            "note": "f32 MFMA peaks at 157 TFLOP/s: above ~50 rows (2*M/4 FLOP/B against 157e12/6.3e12) the stream is MFMA-bound, not HBM-bound"}
+        if model is not None:
+            # the HBM-bound regime proper: 8 clips x 6 tokens = 48 rows per forward (wall time of back-to-back forwards, torch events)
+            n_par = sum(p.numel() for p in model.parameters())
+            D = model.d_lat
+            X = torch.randn(8, 6, D, device="cuda")
+            mask = model.get_tgt_mask(6).cuda()
+            pe0 = torch.zeros(8, dtype=torch.int32, device="cuda")
+            with torch.no_grad():
+                for _ in range(3):
+                    model(X, X, mask, pe_row=pe0)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    model(X, X, mask, pe_row=pe0)
+                e1.record()
+                torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 20
+            out["roofline"]["small_batch_forward"] = {"rows": 48, "ms": ms, "gb_per_s": n_par * 4 / (ms * 1e-3) / 1e9,
+                                                      "frac_of_6.3_TB_per_s": n_par * 4 / (ms * 1e-3) / 6.3e12}
         out["families"] = fam
         return out
     pmc = None
@@ -442,7 +461,7 @@ def main():
                        "weights": "seeded random init (SD v1.4 architecture, %s)" % args.config}}
 
     if rank == 0 and not args.no_roofline:
-        line.update(roofline_pass(args, sd_utils, step, denoise, C))
+        line.update(roofline_pass(args, sd_utils, step, denoise, C, model))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.config, args.start_step, denoise)
     if rank == 0:
