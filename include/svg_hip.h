@@ -37,8 +37,10 @@
  *     no entry point synchronises the device except svg_load_weight/svg_finalize/svg_prof_*.
  *   - one context per (process, GPU); calls on a context are serialised by the caller.
  *   - boundary dtypes: f32 latents / embeddings / masks / noise, u8 images (NHWC).
- *     Internal compute dtype of the SD networks is bf16 with f32 accumulation; the latent
- *     Transformer computes in f32 (f32-input MFMA).
+ *     Storage type of the SD networks (activations + packed weights, f32 accumulation everywhere): bf16 by default,
+ *     IEEE fp16 when the model is configured with f16=1 — the reference runs the UNet under fp16 autocast
+ *     (utils/sd_utils.py:246); both sets of kernels are in the library (same sources compiled per type).
+ *     The latent Transformer and the CLIP text tower compute in f32 (f32-input MFMA).
  */
 #ifndef SVG_HIP_H
 #define SVG_HIP_H
@@ -64,11 +66,12 @@ const char* svg_version(void);
 /* `kv`: "key=v[,v...];key=v" e.g. "block_out=320,640,1280,1280;layers=2;heads=8;ctx_dim=768".
  * Transformer keys: d_lat, d_model, heads, enc_layers, dec_layers, ffn (default 2048), text_dim (0; 384 for the
  *   text-conditioned variant, whose first layer is named project_image_embedding instead of embedding).
- * VAE keys: block_out (128,256,512,512), layers (2), groups (32), latent (4).
+ * VAE keys: block_out (128,256,512,512), layers (2), groups (32), latent (4), f16 (0; 1 = fp16 storage instead of bf16).
  * UNet keys: block_out (320,640,1280,1280), layers (2), heads (8), ctx_dim (768), groups (32),
  *            in_ch (4), out_ch (4), attn (1,1,1,0: cross-attention per down block), fp8 (0; 1 = BASELINE configs[4]: the
  *            dense projections with K % 128 == 0 that carry no folded LayerNorm / GEGLU run in MX block-scaled fp8 —
- *            OCP e4m3 + E8M0 per 32 — with activations quantised on the way in; everything else stays bf16).
+ *            OCP e4m3 + E8M0 per 32 — with activations quantised on the way in; everything else stays 16-bit),
+ *            f16 (0; 1 = fp16 storage instead of bf16: utils/sd_utils.py:246 autocast).
  * CLIP text keys: vocab (49408), d_model (768), heads (12), layers (12), ffn (3072), max_pos (77); tensors by their
  *   transformers names without the "text_model." prefix (embeddings.token_embedding.weight, encoder.layers.N.*, ...). */
 int svg_model_configure(svg_ctx* ctx, int model, const char* kv);
@@ -78,6 +81,8 @@ int svg_load_weight(svg_ctx* ctx, int model, const char* name, const float* data
 /* packs fused layouts, checks that every expected tensor arrived (error names the first
  * missing key), returns the model's parameter count through *n_params if non-NULL. */
 int svg_finalize(svg_ctx* ctx, int model, int64_t* n_params);
+/* storage type of a configured model: "bf16" / "fp16" (SVG_VAE, SVG_UNET), "f32" (SVG_TRANSFORMER, SVG_CLIP_TEXT); NULL if absent */
+const char* svg_model_dtype(svg_ctx* ctx, int model);
 
 /* ---- latent Transformer -------------------------------------------------------------------- */
 /* src (B,Ts,D_lat), tgt (B,Tt,D_lat) batch-first f32; mask (Tt,Tt) additive f32 or NULL;
@@ -166,7 +171,9 @@ int svg_resize_nearest_u8(svg_ctx* ctx, const uint8_t* src, int N, int sh, int s
 int svg_resize_bilinear_f32(svg_ctx* ctx, const float* src, int planes, int h, int w, float* dst, int oh, int ow, void* stream);
 
 /* ---- operator level (the kernels the graphs are made of; used by the parity tests) ---------- */
-/* bf16 buffers are passed as uint16_t bit patterns. NHWC activations, weights [N][K] K-contiguous. */
+/* 16-bit buffers are passed as uint16_t bit patterns: bf16 for svg_op_<name>, IEEE fp16 for the svg_op_<name>_f16 twin
+ * declared at the end of this section (same arguments, the fp16 build of the same kernel).  NHWC activations, weights
+ * [N][K] K-contiguous. */
 /* C[M,N] = act(A[M,K] * W[N,K]^T + bias[N] + residual[M,N]);  out_f32: C is f32 instead of bf16.
  * act: 0 none, 1 SiLU, 2 GELU(erf), 3 GEGLU (W rows = [h;gate] halves of 2*N_out, C is [M,N/2]). */
 int svg_op_gemm(svg_ctx* ctx, const uint16_t* A, const uint16_t* W, const float* bias,
@@ -221,6 +228,31 @@ int svg_op_attention(svg_ctx* ctx, const uint16_t* q, const uint16_t* k, const u
                      uint16_t* out, int B, int heads, int Sq, int Skv, int d, int ldq, int ldk,
                      int ldvt, int ldo, int64_t q_bstride, int64_t k_bstride, int64_t vt_bstride,
                      int64_t o_bstride, float scale, void* stream);
+/* fp16-storage twins of the hooks above (identical contracts; 16-bit buffers hold IEEE half) */
+int svg_op_gemm_f16(svg_ctx* ctx, const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* residual, void* C, int M,
+                    int N, int K, int act, int out_f32, void* stream);
+int svg_op_conv3x3_f16(svg_ctx* ctx, const uint16_t* x, const float* w_oihw, const float* bias, uint16_t* out, int B, int H, int W,
+                       int Cin, int Cout, int mode, void* stream);
+int svg_op_conv3x3_gn_f16(svg_ctx* ctx, const uint16_t* x, const float* w_oihw, const float* bias, const float* gamma,
+                          const float* beta, uint16_t* conv_out, uint16_t* gn_out, int B, int H, int W, int Cin, int Cout,
+                          int groups, float eps, int silu, int* used_epilogue_stats, void* stream);
+int svg_op_gemm_lnstats_f16(svg_ctx* ctx, const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* residual,
+                            uint16_t* C, int M, int N, int K, int batch, float* rs, float* rm, int* used, void* stream);
+int svg_op_gemm_cat_f16(svg_ctx* ctx, const uint16_t* A, const uint16_t* A2, const uint16_t* W, const float* bias, uint16_t* C,
+                        int M, int N, int K, int k_split, void* stream);
+int svg_op_ff_fused_f16(svg_ctx* ctx, const uint16_t* x, const float* ln_gamma, const float* ln_beta, const float* w1,
+                        const float* b1, const float* w2, const float* b2, const uint16_t* residual, uint16_t* out, int M, int C,
+                        void* stream);
+int svg_op_quant_mx_f16(svg_ctx* ctx, const uint16_t* x, uint8_t* q, uint8_t* scales, int64_t rows, int K, void* stream);
+int svg_op_gemm_fp8_f16(svg_ctx* ctx, const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* residual, void* C,
+                        int M, int N, int K, int act, int out_f32, void* stream);
+int svg_op_groupnorm_f16(svg_ctx* ctx, const uint16_t* x, const float* gamma, const float* beta, uint16_t* out, int B, int HW,
+                         int C, int groups, float eps, int silu, void* stream);
+int svg_op_layernorm_f16(svg_ctx* ctx, const uint16_t* x, const float* gamma, const float* beta, uint16_t* out, int M, int C,
+                         float eps, void* stream);
+int svg_op_attention_f16(svg_ctx* ctx, const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* out, int B, int heads,
+                         int Sq, int Skv, int d, int ldq, int ldk, int ldvt, int ldo, int64_t q_bstride, int64_t k_bstride,
+                         int64_t vt_bstride, int64_t o_bstride, float scale, void* stream);
 /* f32 skinny GEMM of the latent Transformer: Y[M,N] = X[M,K] * W[N,K]^T + bias (relu_in: X:=max(X,0)). */
 int svg_op_xf_gemm(svg_ctx* ctx, const float* X, const float* W, const float* bias, float* Y,
                    int M, int N, int K, int relu_in, void* stream);

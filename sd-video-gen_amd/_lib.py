@@ -71,7 +71,12 @@ SIGNATURES = {
     "svg_prof_report": [_vp, C.c_char_p, _i],
     "svg_workspace_bytes": [_vp],
 }
-_RESTYPES = {"svg_destroy": None, "svg_last_error": C.c_char_p, "svg_version": C.c_char_p,
+# fp16-storage twins of the 16-bit operator hooks (svg_op_<name>_f16: same arguments)
+for _n in ("gemm", "conv3x3", "conv3x3_gn", "gemm_lnstats", "gemm_cat", "ff_fused", "quant_mx", "gemm_fp8", "groupnorm", "layernorm",
+           "attention"):
+    SIGNATURES["svg_op_%s_f16" % _n] = SIGNATURES["svg_op_" + _n]
+SIGNATURES["svg_model_dtype"] = [_vp, _i]
+_RESTYPES = {"svg_destroy": None, "svg_model_dtype": C.c_char_p, "svg_last_error": C.c_char_p, "svg_version": C.c_char_p,
              "svg_workspace_bytes": _i64}
 
 
@@ -176,6 +181,11 @@ class Context:
             shape = (_i64 * max(t.dim(), 1))(*(list(t.shape) if t.dim() else [1]))
             self.check(self.lib.svg_load_weight(self.h, model, name.encode(), t.data_ptr(), shape, max(t.dim(), 1)),
                        "svg_load_weight(%s)" % name)
+
+    def model_dtype(self, model):
+        """'bf16' / 'fp16' for the SD networks, 'f32' for the Transformer / CLIP, None when the slot is empty"""
+        r = self.lib.svg_model_dtype(self.h, model)
+        return r.decode() if r else None
 
     def finalize(self, model):
         n = _i64(0)

@@ -19,8 +19,8 @@
 #include "igemm_epi.h"
 #include <cstdlib>
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+namespace SDNS {
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
@@ -84,14 +84,14 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
   }
   const int q0 = qt * (128 * QB) + wid * (32 * QB);
 
-  const bf16* __restrict__ Q = a.q + (int64_t)b * a.qb + head * D;
-  const bf16* __restrict__ Kp = a.k + (int64_t)b * a.kb + head * D;
-  const bf16* __restrict__ Vt = a.vt + (int64_t)b * a.vtb + (int64_t)head * D * a.ldvt;
+  const h16* __restrict__ Q = a.q + (int64_t)b * a.qb + head * D;
+  const h16* __restrict__ Kp = a.k + (int64_t)b * a.kb + head * D;
+  const h16* __restrict__ Vt = a.vt + (int64_t)b * a.vtb + (int64_t)head * D * a.ldvt;
 
   // ---- Q^T fragments (B operand): lane (r,h) holds Q[q0+r][16ks + 8h .. +7] -------------------
   static_assert(!BC || (DK - D >= 3 && (D % 16) == 8), "bias-column form needs the pad columns in lane-half 1 of the last k-step");
   const float c = a.scale * 1.4426950408889634f;   // exp(x*scale) = exp2(x*c)
-  bf16x8 qf[QB][KS];
+  h16x8 qf[QB][KS];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int q = q0 + 32 * qb + r;
@@ -100,10 +100,10 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
       const int col = ks * 16 + h * 8;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (q < a.Sq && col < D) v = *(const uint4*)(Q + (int64_t)q * a.ldq + col);
-      qf[qb][ks] = *(bf16x8*)&v;
+      qf[qb][ks] = *(h16x8*)&v;
       if (BC) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qf[qb][ks][j] = (bf16)((float)qf[qb][ks][j] * c);
+        for (int j = 0; j < 8; ++j) qf[qb][ks][j] = (h16)((float)qf[qb][ks][j] * c);
       }
     }
   }
@@ -124,8 +124,8 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
     char* const sK = smem + st * STAGE;
     char* const sV = sK + K_BYTES;
     if (CPR * 8 < DK && tid < KVT)   // BC: columns d, d+1, d+2 = 1.0 (they multiply the three pieces of -m in Q)
-      *(uint4*)(sK + tid * KROW + CPR * 16) = BC ? make_uint4(0x3F803F80u, 0x00003F80u, 0, 0) : make_uint4(0, 0, 0, 0);
-    if (ONES && tid < 16) *(uint2*)(sV + D * VROW + tid * 8) = make_uint2(0x3F803F80u, 0x3F803F80u);
+      *(uint4*)(sK + tid * KROW + CPR * 16) = BC ? make_uint4(H16_ONE2, H16_ONE1, 0, 0) : make_uint4(0, 0, 0, 0);
+    if (ONES && tid < 16) *(uint2*)(sV + D * VROW + tid * 8) = make_uint2(H16_ONE2, H16_ONE2);
   }
 
   uint4 rk[NLD], rv[NLD];
@@ -186,12 +186,12 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
       for (int j = 0; j < 16; ++j) { S0[qb][j] = 0.f; S1[qb][j] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8 a0 = *(const bf16x8*)(sK + r * KROW + (ks * 2 + h) * 16);
-      const bf16x8 a1 = *(const bf16x8*)(sK + (32 + r) * KROW + (ks * 2 + h) * 16);
+      const h16x8 a0 = *(const h16x8*)(sK + r * KROW + (ks * 2 + h) * 16);
+      const h16x8 a1 = *(const h16x8*)(sK + (32 + r) * KROW + (ks * 2 + h) * 16);
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
-        S0[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[qb][ks], S0[qb], 0, 0, 0);
-        S1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[qb][ks], S1[qb], 0, 0, 0);
+        S0[qb] = MFMA_32x32x16(a0, qf[qb][ks], S0[qb]);
+        S1[qb] = MFMA_32x32x16(a1, qf[qb][ks], S1[qb]);
       }
     }
     // ---- HV: the V^T fragments of this tile do not depend on the softmax — issue their LDS reads now, so that the
@@ -248,10 +248,10 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
           for (int j = 0; j < 16; ++j) { S0[qb][j] -= delta; S1[qb][j] -= delta; }
           // -m as three bf16 pieces in Q columns d, d+1, d+2 (held by lane-half 1 of the last k-step)
           const float v0 = -m_run[qb];
-          const bf16 p1 = (bf16)v0;
+          const h16 p1 = (h16)v0;
           const float r1 = v0 - (float)p1;
-          const bf16 p2 = (bf16)r1;
-          const bf16 p3 = (bf16)(r1 - (float)p2);
+          const h16 p2 = (h16)r1;
+          const h16 p3 = (h16)(r1 - (float)p2);
           if (h == 1) { qf[qb][KS - 1][0] = p1; qf[qb][KS - 1][1] = p2; qf[qb][KS - 1][2] = p3; }
         }
 #pragma unroll
@@ -302,11 +302,11 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
     for (int st = 0; st < 2; ++st) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        bf16x8 pf[QB];
+        h16x8 pf[QB];
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) pf[qb][j] = (bf16)(st == 0 ? S0[qb][8 * s2 + j] : S1[qb][8 * s2 + j]);
+          for (int j = 0; j < 8; ++j) pf[qb][j] = (h16)(st == 0 ? S0[qb][8 * s2 + j] : S1[qb][8 * s2 + j]);
         const int kvoff = (32 * st + 16 * s2 + 4 * h) * 2;   // bytes
 #pragma unroll
         for (int dt = 0; dt < DVT; ++dt) {
@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
           }
 #pragma unroll
           for (int qb = 0; qb < QB; ++qb)
-            O[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8*)&v, pf[qb], O[qb][dt], 0, 0, 0);
+            O[qb][dt] = MFMA_32x32x16(*(h16x8*)&v, pf[qb], O[qb][dt]);
         }
       }
     }
@@ -342,19 +342,19 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
     const float inv = 1.f / l_tot;
     const int q = q0 + 32 * qb + r;
     if (q < a.Sq) {
-      bf16* orow = a.out + (int64_t)b * a.ob + (int64_t)q * a.ldo + head * D;
+      h16* orow = a.out + (int64_t)b * a.ob + (int64_t)q * a.ldo + head * D;
 #pragma unroll
       for (int dt = 0; dt < DVT; ++dt) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int dd = 32 * dt + 8 * g + 4 * h;
           if (dd < D) {
-            bf16x4 w;
-            w[0] = (bf16)(O[qb][dt][4 * g + 0] * inv);
-            w[1] = (bf16)(O[qb][dt][4 * g + 1] * inv);
-            w[2] = (bf16)(O[qb][dt][4 * g + 2] * inv);
-            w[3] = (bf16)(O[qb][dt][4 * g + 3] * inv);
-            *(bf16x4*)(orow + dd) = w;
+            h16x4 w;
+            w[0] = (h16)(O[qb][dt][4 * g + 0] * inv);
+            w[1] = (h16)(O[qb][dt][4 * g + 1] * inv);
+            w[2] = (h16)(O[qb][dt][4 * g + 2] * inv);
+            w[3] = (h16)(O[qb][dt][4 * g + 3] * inv);
+            *(h16x4*)(orow + dd) = w;
           }
         }
       }
@@ -410,9 +410,9 @@ __global__ void __launch_bounds__(256) attn_dma40_kernel(const AttnArgs a) {
     b = bh / a.heads;
   }
   const int q0 = qt * 256 + wid * 64;
-  const bf16* __restrict__ Q = a.q + (int64_t)b * a.qb + head * D;
-  const bf16* __restrict__ Kp = a.k + (int64_t)b * a.kb + head * D;
-  const bf16* __restrict__ Vt = a.vt + (int64_t)b * a.vtb + (int64_t)head * D * a.ldvt;
+  const h16* __restrict__ Q = a.q + (int64_t)b * a.qb + head * D;
+  const h16* __restrict__ Kp = a.k + (int64_t)b * a.kb + head * D;
+  const h16* __restrict__ Vt = a.vt + (int64_t)b * a.vtb + (int64_t)head * D * a.ldvt;
   const uint64_t pk = (uint64_t)Kp, pv = (uint64_t)Vt;
   const unsigned k_bytes = (unsigned)(((int64_t)a.Skv - 1) * a.ldk * 2 + D * 2);
   const unsigned v_bytes = (unsigned)(((int64_t)D - 1) * a.ldvt * 2 + ((a.Skv + 7) / 8 * 8) * 2);
@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(256) attn_dma40_kernel(const AttnArgs a) {
 
   // ---- Q^T fragments, pre-multiplied by scale * log2(e) ----------------------------------------------------------------------
   const float c = a.scale * 1.4426950408889634f;
-  bf16x8 qf[QB][KS];
+  h16x8 qf[QB][KS];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int q = q0 + 32 * qb + r;
@@ -476,9 +476,9 @@ __global__ void __launch_bounds__(256) attn_dma40_kernel(const AttnArgs a) {
       const int col = ks * 16 + h * 8;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (q < a.Sq && col < D) v = *(const uint4*)(Q + (int64_t)q * a.ldq + col);
-      qf[qb][ks] = *(bf16x8*)&v;
+      qf[qb][ks] = *(h16x8*)&v;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) qf[qb][ks][j] = (bf16)((float)qf[qb][ks][j] * c);
+      for (int j = 0; j < 8; ++j) qf[qb][ks][j] = (h16)((float)qf[qb][ks][j] * c);
     }
   }
   // ---- once per stage: K bias columns (1, 1, 1, 0...) and the spare chunk; V^T ones row 40 and zero rows 41..63 --------------
@@ -487,12 +487,12 @@ __global__ void __launch_bounds__(256) attn_dma40_kernel(const AttnArgs a) {
     char* const sK = smem + st * STAGE;
     char* const sV = sK + K_BYTES;
     if (tid < KVT) {
-      *(uint4*)(sK + tid * KROW + 80) = make_uint4(0x3F803F80u, 0x00003F80u, 0, 0);
+      *(uint4*)(sK + tid * KROW + 80) = make_uint4(H16_ONE2, H16_ONE1, 0, 0);
       *(uint4*)(sK + tid * KROW + 96) = make_uint4(0, 0, 0, 0);
     }
     for (int i = tid; i < 24 * 8; i += 256) {
       const int row = 40 + i / 8, pos = i & 7;
-      *(uint4*)(sV + row * 128 + pos * 16) = row == 40 ? make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u) : make_uint4(0, 0, 0, 0);
+      *(uint4*)(sV + row * 128 + pos * 16) = row == 40 ? make_uint4(H16_ONE2, H16_ONE2, H16_ONE2, H16_ONE2) : make_uint4(0, 0, 0, 0);
     }
   }
   __syncthreads();   // the constants are in place before any DMA lands next to them (and LDS-DMA writes are not ordered with ds_writes)
@@ -526,12 +526,12 @@ __global__ void __launch_bounds__(256) attn_dma40_kernel(const AttnArgs a) {
       for (int j = 0; j < 16; ++j) { S0[qb][j] = 0.f; S1[qb][j] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8 a0 = *(const bf16x8*)(sK + r * KROW + (ks * 2 + h) * 16);
-      const bf16x8 a1 = *(const bf16x8*)(sK + (32 + r) * KROW + (ks * 2 + h) * 16);
+      const h16x8 a0 = *(const h16x8*)(sK + r * KROW + (ks * 2 + h) * 16);
+      const h16x8 a1 = *(const h16x8*)(sK + (32 + r) * KROW + (ks * 2 + h) * 16);
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
-        S0[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[qb][ks], S0[qb], 0, 0, 0);
-        S1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[qb][ks], S1[qb], 0, 0, 0);
+        S0[qb] = MFMA_32x32x16(a0, qf[qb][ks], S0[qb]);
+        S1[qb] = MFMA_32x32x16(a1, qf[qb][ks], S1[qb]);
       }
     }
     // V^T fragments of this tile: one 16-byte read each, issued now so that their latency runs under the softmax
@@ -576,10 +576,10 @@ __global__ void __launch_bounds__(256) attn_dma40_kernel(const AttnArgs a) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) { S0[qb][j] -= delta; S1[qb][j] -= delta; }
         const float v0 = -m_run[qb];
-        const bf16 p1 = (bf16)v0;
+        const h16 p1 = (h16)v0;
         const float r1 = v0 - (float)p1;
-        const bf16 p2 = (bf16)r1;
-        const bf16 p3 = (bf16)(r1 - (float)p2);
+        const h16 p2 = (h16)r1;
+        const h16 p3 = (h16)(r1 - (float)p2);
         if (h == 1) { qf[qb][KS - 1][0] = p1; qf[qb][KS - 1][1] = p2; qf[qb][KS - 1][2] = p3; }
       }
 #pragma unroll
@@ -592,17 +592,17 @@ __global__ void __launch_bounds__(256) attn_dma40_kernel(const AttnArgs a) {
     for (int st = 0; st < 2; ++st)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        bf16x8 pf[QB];
+        h16x8 pf[QB];
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) pf[qb][j] = (bf16)(st == 0 ? S0[qb][8 * s2 + j] : S1[qb][8 * s2 + j]);
+          for (int j = 0; j < 8; ++j) pf[qb][j] = (h16)(st == 0 ? S0[qb][8 * s2 + j] : S1[qb][8 * s2 + j]);
 #pragma unroll
         for (int dt = 0; dt < DVT; ++dt) {
           const uint4 v = vfr[(2 * st + s2) * DVT + dt];
 #pragma unroll
           for (int qb = 0; qb < QB; ++qb)
-            O[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&v, pf[qb], O[qb][dt], 0, 0, 0);
+            O[qb][dt] = MFMA_32x32x16(*(const h16x8*)&v, pf[qb], O[qb][dt]);
         }
       }
   }
@@ -613,19 +613,19 @@ __global__ void __launch_bounds__(256) attn_dma40_kernel(const AttnArgs a) {
     const float inv = 1.f / l_tot;
     const int q = q0 + 32 * qb + r;
     if (q < a.Sq) {
-      bf16* orow = a.out + (int64_t)b * a.ob + (int64_t)q * a.ldo + head * D;
+      h16* orow = a.out + (int64_t)b * a.ob + (int64_t)q * a.ldo + head * D;
 #pragma unroll
       for (int dt = 0; dt < DVT; ++dt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int dd = 32 * dt + 8 * g + 4 * h;
           if (dd < D) {
-            bf16x4 w;
-            w[0] = (bf16)(O[qb][dt][4 * g + 0] * inv);
-            w[1] = (bf16)(O[qb][dt][4 * g + 1] * inv);
-            w[2] = (bf16)(O[qb][dt][4 * g + 2] * inv);
-            w[3] = (bf16)(O[qb][dt][4 * g + 3] * inv);
-            *(bf16x4*)(orow + dd) = w;
+            h16x4 w;
+            w[0] = (h16)(O[qb][dt][4 * g + 0] * inv);
+            w[1] = (h16)(O[qb][dt][4 * g + 1] * inv);
+            w[2] = (h16)(O[qb][dt][4 * g + 2] * inv);
+            w[3] = (h16)(O[qb][dt][4 * g + 3] * inv);
+            *(h16x4*)(orow + dd) = w;
           }
         }
     }
@@ -687,3 +687,5 @@ void attention(svg_ctx* ctx, const AttnArgs& a, hipStream_t s) {
   }
   check_launch("attention");
 }
+
+}  // namespace SDNS

@@ -10,7 +10,29 @@
 #include <cstring>
 #include <cmath>
 
-typedef __bf16 bf16;
+// Storage type of the Stable-Diffusion side (activations and packed weights; accumulation is always f32).  Every SD source is
+// compiled twice into libsvg_hip.so: once with h16 = bf16 (namespace sd_bf16, the default) and once with -DSVG_F16, h16 = IEEE
+// half (namespace sd_f16: the reference's autocast arithmetic, utils/sd_utils.py:246).  A model picks its namespace when it is
+// configured (kv key f16=1); files compiled once see the bf16 namespace.
+#ifdef SVG_F16
+typedef _Float16 h16;
+#define SDNS sd_f16
+#define SD_F16 1
+#define H16_ONE1 0x00003C00u          /* 1.0 as one 16-bit pattern / as a pair */
+#define H16_ONE2 0x3C003C00u
+#define MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#else
+typedef __bf16 h16;
+#define SDNS sd_bf16
+#define SD_F16 0
+#define H16_ONE1 0x00003F80u
+#define H16_ONE2 0x3F803F80u
+#define MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
+typedef h16 h16x8 __attribute__((ext_vector_type(8)));
+typedef h16 h16x4 __attribute__((ext_vector_type(4)));
 typedef uint16_t u16;
 
 // SvgError: the caller handed over something the library cannot take (shape, size, missing weight, call order): the
@@ -102,8 +124,8 @@ struct svg_ctx {
   size_t ev_used = 0;
   // models (opaque here; defined in their own translation units)
   struct XfModel* xf = nullptr;
-  struct VaeModel* vae = nullptr;
-  struct UnetModel* unet = nullptr;
+  struct VaeIface* vae = nullptr;     // sd_bf16::VaeModel or sd_f16::VaeModel (configure key f16=1)
+  struct UnetIface* unet = nullptr;
   struct ClipTextModel* clip = nullptr;
   static constexpr int kCtxSlot = 4;                 // owned[] index of allocations that belong to the context itself
   std::vector<void*> owned[5];   // device allocations per model id (kCtxSlot = context) freed at reconfigure / destroy

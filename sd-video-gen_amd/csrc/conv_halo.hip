@@ -14,6 +14,8 @@
 #include "igemm_epi.h"
 #include <cstdlib>
 
+namespace SDNS {
+
 namespace {
 
 // compile-time ablation switch for tools/abl_halo.sh (-DHALO_ABL=n): 1 no stores, 2 no MFMA, 3 no DMA, 4 no fragment reads, 6 no barrier
@@ -170,12 +172,12 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
     const char* sb = sB + stage * B_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 xf[MT], wf[NT];
+      h16x8 xf[MT], wf[NT];
       if (ABL != 4) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i) xf[i] = *(const bf16x8*)(sp + lds_off7(pp0[i] + toff, kk * 4 + lq));
+      for (int i = 0; i < MT; ++i) xf[i] = *(const h16x8*)(sp + lds_off7(pp0[i] + toff, kk * 4 + lq));
 #pragma unroll
-      for (int j = 0; j < NT; ++j) wf[j] = *(const bf16x8*)(sb + lds_off7(wn * (BN / 2) + j * 16 + l15, kk * 4 + lq));
+      for (int j = 0; j < NT; ++j) wf[j] = *(const h16x8*)(sb + lds_off7(wn * (BN / 2) + j * 16 + l15, kk * 4 + lq));
       } else {
 #pragma unroll
       for (int i = 0; i < MT; ++i) asm volatile("" : "=v"(xf[i]));
@@ -193,12 +195,12 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = MFMA_16x16x32(wf[j], xf[i], acc[i][j]);
     }
   };
 
   // the operands were read a phase ago (the compiler's own counted lgkmcnt covers them, not the reads just issued)
-  auto mma_phase = [&](const bf16x8 (&xf)[MT], const bf16x8 (&wf)[NT]) {
+  auto mma_phase = [&](const h16x8 (&xf)[MT], const h16x8 (&wf)[NT]) {
     __builtin_amdgcn_sched_barrier(0);
     if (ABL == 2) {
 #pragma unroll
@@ -212,7 +214,7 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = MFMA_16x16x32(wf[j], xf[i], acc[i][j]);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -255,18 +257,18 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
     int waddr[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) waddr[kk] = OFF_B + (wn * (BN / 2) + l15) * 128 + (((kk * 4 + lq) ^ (l15 & 7)) << 4);
-    auto rd_x = [&](int tap, int kk, bf16x8 (&xf)[MT]) {
+    auto rd_x = [&](int tap, int kk, h16x8 (&xf)[MT]) {
       const int toff = (tap / 3) * PW + (tap % 3);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int rel = i * PW + toff;
-        if (ABL != 4) xf[i] = *(const bf16x8*)(smem + xaddr[rel & 7][kk] + rel * 128);
+        if (ABL != 4) xf[i] = *(const h16x8*)(smem + xaddr[rel & 7][kk] + rel * 128);
       }
     };
-    auto rd_w = [&](int stage, int kk, bf16x8 (&wf)[NT]) {
+    auto rd_w = [&](int stage, int kk, h16x8 (&wf)[NT]) {
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        if (ABL != 4) wf[j] = *(const bf16x8*)(smem + waddr[kk] + stage * B_BYTES + j * 2048);
+        if (ABL != 4) wf[j] = *(const h16x8*)(smem + waddr[kk] + stage * B_BYTES + j * 2048);
     };
     auto dma_w_part = [&](int cc, int tap, int stage, int i0, int i1) {     // instructions [i0, i1) of a slab's NW
       const unsigned dst = lds0 + OFF_B + stage * B_BYTES + wave_u * 1024;
@@ -278,7 +280,7 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
       }
     };
 
-    bf16x8 xa[MT], wa[NT], xb[MT], wb[NT];
+    h16x8 xa[MT], wa[NT], xb[MT], wb[NT];
     rd_x(0, 0, xa);
     rd_w(0, 0, wa);
     for (int cc = cc_begin; cc < cc_end; ++cc) {
@@ -416,3 +418,5 @@ void launch_conv_halo(const GemmArgs& g, dim3 grid, hipStream_t s) {
   if (pp) { if (w160) launch_halo<160, true>(g, grid, s); else launch_halo<128, true>(g, grid, s); }
   else    { if (w160) launch_halo<160, false>(g, grid, s); else launch_halo<128, false>(g, grid, s); }
 }
+
+}  // namespace SDNS

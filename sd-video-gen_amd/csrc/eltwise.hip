@@ -1,7 +1,8 @@
 // Element-wise and layout kernels of the sampling path (HBM-bound, vectorised where the layout allows).
 #include "kernels.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+namespace SDNS {
+
 
 namespace {
 
@@ -17,7 +18,7 @@ __device__ __forceinline__ int nearest_src(int d, int in, int out) {
 }
 
 // sd_utils.py:135-138: x/255 -> 2*(x-0.5); channels padded 3 -> 8 with zeros
-__global__ void img_to_act_kernel(const uint8_t* __restrict__ img, bf16* __restrict__ out, int N, int sh, int sw, int H, int W) {
+__global__ void img_to_act_kernel(const uint8_t* __restrict__ img, h16* __restrict__ out, int N, int sh, int sw, int H, int W) {
   const int64_t total = (int64_t)N * H * W;
   GRID_STRIDE(idx, total) {
     const int x = (int)(idx % W);
@@ -26,15 +27,15 @@ __global__ void img_to_act_kernel(const uint8_t* __restrict__ img, bf16* __restr
     const int sy = (sh == H) ? y : nearest_src(y, sh, H);
     const int sx = (sw == W) ? x : nearest_src(x, sw, W);
     const uint8_t* p = img + (((int64_t)n * sh + sy) * sw + sx) * 3;
-    bf16x8 o;
+    h16x8 o;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       float f = (float)p[c] / 255.0f;
-      o[c] = (bf16)(2.f * (f - 0.5f));
+      o[c] = (h16)(2.f * (f - 0.5f));
     }
 #pragma unroll
-    for (int c = 3; c < 8; ++c) o[c] = (bf16)0.f;
-    *(bf16x8*)(out + idx * 8) = o;
+    for (int c = 3; c < 8; ++c) o[c] = (h16)0.f;
+    *(h16x8*)(out + idx * 8) = o;
   }
 }
 
@@ -70,13 +71,13 @@ __global__ void act_to_img_kernel(const float* __restrict__ x, int ldc, uint8_t*
   }
 }
 
-__global__ void nchw_to_act_kernel(const float* __restrict__ x, bf16* __restrict__ out, int N, int C, int hw, int Cpad, float scale) {
+__global__ void nchw_to_act_kernel(const float* __restrict__ x, h16* __restrict__ out, int N, int C, int hw, int Cpad, float scale) {
   const int64_t total = (int64_t)N * hw;
   GRID_STRIDE(idx, total) {
     const int px = (int)(idx % hw);
     const int n = (int)(idx / hw);
     for (int c = 0; c < Cpad; ++c)
-      out[idx * Cpad + c] = (bf16)((c < C) ? x[((int64_t)n * C + c) * hw + px] * scale : 0.f);
+      out[idx * Cpad + c] = (h16)((c < C) ? x[((int64_t)n * C + c) * hw + px] * scale : 0.f);
   }
 }
 
@@ -88,9 +89,9 @@ __global__ void nchw_to_actf32_kernel(const float* __restrict__ x, float* __rest
     for (int c = 0; c < C; ++c) out[idx * C + c] = x[((int64_t)n * C + c) * hw + px] * scale;
   }
 }
-__global__ void actf32_pad_bf16_kernel(const float* __restrict__ x, int C, bf16* __restrict__ out, int Cpad, int64_t P) {
+__global__ void actf32_pad_h16_kernel(const float* __restrict__ x, int C, h16* __restrict__ out, int Cpad, int64_t P) {
   GRID_STRIDE(idx, P) {
-    for (int c = 0; c < Cpad; ++c) out[idx * Cpad + c] = (bf16)((c < C) ? x[idx * C + c] : 0.f);
+    for (int c = 0; c < Cpad; ++c) out[idx * Cpad + c] = (h16)((c < C) ? x[idx * C + c] : 0.f);
   }
 }
 
@@ -141,15 +142,15 @@ __global__ void vae_sample_kernel(const float* __restrict__ mom, int ldm, const 
   }
 }
 
-__global__ void concat_kernel(const bf16* __restrict__ a, int Ca, const bf16* __restrict__ b, int Cb, bf16* __restrict__ out, int64_t P) {
+__global__ void concat_kernel(const h16* __restrict__ a, int Ca, const h16* __restrict__ b, int Cb, h16* __restrict__ out, int64_t P) {
   const int CV = (Ca + Cb) / 8;
   const int64_t total = P * CV;
   GRID_STRIDE(idx, total) {
     const int cv = (int)(idx % CV);
     const int64_t p = idx / CV;
     const int c0 = cv * 8;
-    bf16x8 v = (c0 < Ca) ? *(const bf16x8*)(a + p * Ca + c0) : *(const bf16x8*)(b + p * Cb + (c0 - Ca));
-    *(bf16x8*)(out + p * (Ca + Cb) + c0) = v;
+    h16x8 v = (c0 < Ca) ? *(const h16x8*)(a + p * Ca + c0) : *(const h16x8*)(b + p * Cb + (c0 - Ca));
+    *(h16x8*)(out + p * (Ca + Cb) + c0) = v;
   }
 }
 
@@ -164,18 +165,18 @@ __global__ void resize_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __res
   }
 }
 
-__global__ void f32_to_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, int64_t n) {
-  GRID_STRIDE(i, n) y[i] = (bf16)x[i];
+__global__ void f32_to_h16_kernel(const float* __restrict__ x, h16* __restrict__ y, int64_t n) {
+  GRID_STRIDE(i, n) y[i] = (h16)x[i];
 }
-__global__ void bf16_to_f32_kernel(const bf16* __restrict__ x, float* __restrict__ y, int64_t n) {
+__global__ void h16_to_f32_kernel(const h16* __restrict__ x, float* __restrict__ y, int64_t n) {
   GRID_STRIDE(i, n) y[i] = (float)x[i];
 }
-__global__ void silu_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int64_t n) {
-  GRID_STRIDE(i, n) { float f = (float)x[i]; y[i] = (bf16)(f / (1.f + __expf(-f))); }
+__global__ void silu_kernel(const h16* __restrict__ x, h16* __restrict__ y, int64_t n) {
+  GRID_STRIDE(i, n) { float f = (float)x[i]; y[i] = (h16)(f / (1.f + __expf(-f))); }
 }
 
 // diffusers get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin]
-__global__ void timestep_embed_kernel(const float* __restrict__ t, bf16* __restrict__ out, int N, int dim) {
+__global__ void timestep_embed_kernel(const float* __restrict__ t, h16* __restrict__ out, int N, int dim) {
   const int half = dim / 2;
   const int64_t total = (int64_t)N * half;
   GRID_STRIDE(idx, total) {
@@ -183,8 +184,8 @@ __global__ void timestep_embed_kernel(const float* __restrict__ t, bf16* __restr
     const int n = (int)(idx / half);
     const float freq = expf(-logf(10000.f) * (float)i / (float)half);
     const float a = t[n] * freq;
-    out[(int64_t)n * dim + i] = (bf16)cosf(a);
-    out[(int64_t)n * dim + half + i] = (bf16)sinf(a);
+    out[(int64_t)n * dim + i] = (h16)cosf(a);
+    out[(int64_t)n * dim + half + i] = (h16)sinf(a);
   }
 }
 
@@ -206,7 +207,7 @@ __global__ void add_noise_kernel(const float* __restrict__ x0, const float* __re
 
 }  // namespace
 
-void img_to_act(const uint8_t* img, bf16* out, int N, int sh, int sw, int H, int W, hipStream_t s) {
+void img_to_act(const uint8_t* img, h16* out, int N, int sh, int sw, int H, int W, hipStream_t s) {
   hipLaunchKernelGGL(img_to_act_kernel, grid_for((int64_t)N * H * W), dim3(256), 0, s, img, out, N, sh, sw, H, W);
   check_launch("img_to_act");
 }
@@ -214,7 +215,7 @@ void act_to_img(const float* x, int ldc, uint8_t* img, float* fout, int N, int h
   hipLaunchKernelGGL(act_to_img_kernel, grid_for((int64_t)N * std::max(h * w, oh * ow)), dim3(256), 0, s, x, ldc, img, fout, N, h, w, oh, ow);
   check_launch("act_to_img");
 }
-void nchw_to_act(const float* x, bf16* out, int N, int C, int h, int w, int Cpad, float scale, hipStream_t s) {
+void nchw_to_act(const float* x, h16* out, int N, int C, int h, int w, int Cpad, float scale, hipStream_t s) {
   hipLaunchKernelGGL(nchw_to_act_kernel, grid_for((int64_t)N * h * w), dim3(256), 0, s, x, out, N, C, h * w, Cpad, scale);
   check_launch("nchw_to_act");
 }
@@ -222,9 +223,9 @@ void nchw_to_actf32(const float* x, float* out, int N, int C, int h, int w, floa
   hipLaunchKernelGGL(nchw_to_actf32_kernel, grid_for((int64_t)N * h * w), dim3(256), 0, s, x, out, N, C, h * w, scale);
   check_launch("nchw_to_actf32");
 }
-void actf32_pad_bf16(const float* x, int C, bf16* out, int Cpad, int64_t P, hipStream_t s) {
-  hipLaunchKernelGGL(actf32_pad_bf16_kernel, grid_for(P), dim3(256), 0, s, x, C, out, Cpad, P);
-  check_launch("actf32_pad_bf16");
+void actf32_pad_h16(const float* x, int C, h16* out, int Cpad, int64_t P, hipStream_t s) {
+  hipLaunchKernelGGL(actf32_pad_h16_kernel, grid_for(P), dim3(256), 0, s, x, C, out, Cpad, P);
+  check_launch("actf32_pad_h16");
 }
 void actf32_to_nchw(const float* x, int ld, float* out, int N, int C, int h, int w, hipStream_t s) {
   hipLaunchKernelGGL(actf32_to_nchw_kernel, grid_for((int64_t)N * h * w), dim3(256), 0, s, x, ld, out, N, C, h * w);
@@ -239,7 +240,7 @@ void vae_sample(const float* mom, int ldm, const float* eps, float* z, float* mo
   hipLaunchKernelGGL(vae_sample_kernel, grid_for((int64_t)N * h * w), dim3(256), 0, s, mom, ldm, eps, z, mom_nchw, N, h * w);
   check_launch("vae_sample");
 }
-void concat_channels(const bf16* a, int Ca, const bf16* b, int Cb, bf16* out, int64_t P, hipStream_t s) {
+void concat_channels(const h16* a, int Ca, const h16* b, int Cb, h16* out, int64_t P, hipStream_t s) {
   SVG_CHECK(Ca % 8 == 0 && Cb % 8 == 0, "concat: channels must be multiples of 8");
   hipLaunchKernelGGL(concat_kernel, grid_for(P * ((Ca + Cb) / 8)), dim3(256), 0, s, a, Ca, b, Cb, out, P);
   check_launch("concat");
@@ -273,19 +274,19 @@ void resize_nearest_u8(const uint8_t* src, uint8_t* dst, int N, int sh, int sw, 
   hipLaunchKernelGGL(resize_u8_kernel, grid_for((int64_t)N * dh * dw), dim3(256), 0, s, src, dst, N, sh, sw, C, dh, dw);
   check_launch("resize_u8");
 }
-void f32_to_bf16(const float* x, bf16* y, int64_t n, hipStream_t s) {
-  hipLaunchKernelGGL(f32_to_bf16_kernel, grid_for(n), dim3(256), 0, s, x, y, n);
-  check_launch("f32_to_bf16");
+void f32_to_h16(const float* x, h16* y, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(f32_to_h16_kernel, grid_for(n), dim3(256), 0, s, x, y, n);
+  check_launch("f32_to_h16");
 }
-void bf16_to_f32(const bf16* x, float* y, int64_t n, hipStream_t s) {
-  hipLaunchKernelGGL(bf16_to_f32_kernel, grid_for(n), dim3(256), 0, s, x, y, n);
-  check_launch("bf16_to_f32");
+void h16_to_f32(const h16* x, float* y, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(h16_to_f32_kernel, grid_for(n), dim3(256), 0, s, x, y, n);
+  check_launch("h16_to_f32");
 }
-void silu_bf16(const bf16* x, bf16* y, int64_t n, hipStream_t s) {
+void silu_h16(const h16* x, h16* y, int64_t n, hipStream_t s) {
   hipLaunchKernelGGL(silu_kernel, grid_for(n), dim3(256), 0, s, x, y, n);
   check_launch("silu");
 }
-void timestep_embed(const float* t, bf16* out, int N, int dim, hipStream_t s) {
+void timestep_embed(const float* t, h16* out, int N, int dim, hipStream_t s) {
   hipLaunchKernelGGL(timestep_embed_kernel, grid_for((int64_t)N * dim / 2), dim3(256), 0, s, t, out, N, dim);
   check_launch("timestep_embed");
 }
@@ -307,3 +308,5 @@ void add_noise(const float* x0, const float* nz, float* out, int64_t n, float sa
   hipLaunchKernelGGL(add_noise_kernel, grid_for(n), dim3(256), 0, s, x0, nz, out, n, sa, s1a);
   check_launch("add_noise");
 }
+
+}  // namespace SDNS

@@ -14,6 +14,8 @@
 #include "igemm_epi.h"
 #include <cstdlib>
 
+namespace SDNS {
+
 namespace {
 
 constexpr int FC = 320;                 // channels
@@ -28,12 +30,12 @@ constexpr int F_OFF_S1 = F_RING * F_SLAB;              // s1 (2560 f32) then b1 
 constexpr int F_LDS = F_OFF_S1 + 2 * 2 * FH * 4;
 
 struct FfArgs {
-  const bf16* X; int ldx;               // pre-LayerNorm input rows
-  const bf16* W1; const float* b1; const float* s1;   // packed GEGLU weights [2*FH][FC] (h / gate tiles of 16 rows alternate), folded bias, row sums
+  const h16* X; int ldx;               // pre-LayerNorm input rows
+  const h16* W1; const float* b1; const float* s1;   // packed GEGLU weights [2*FH][FC] (h / gate tiles of 16 rows alternate), folded bias, row sums
   const float* rs; const float* rm;     // LayerNorm row statistics: rstd, rstd * mean; both null: computed here from the rows in registers
-  const bf16* W2p; const float* b2;     // [FC][FH], k permuted inside 32-blocks (pack_ff2_perm)
-  const bf16* residual; int ldr;
-  bf16* out; int ldo;
+  const h16* W2p; const float* b2;     // [FC][FH], k permuted inside 32-blocks (pack_ff2_perm)
+  const h16* residual; int ldr;
+  h16* out; int ldo;
   int M;
 };
 
@@ -83,12 +85,12 @@ __global__ void __launch_bounds__(512, 2) ff_fused_kernel(const FfArgs a) {
   }
   const int m = m0 + wave_u * 16 + l15;
   const bool m_ok = m < a.M;
-  bf16x8 xf[F_KS];
+  h16x8 xf[F_KS];
 #pragma unroll
   for (int ks = 0; ks < F_KS; ++ks) {
     uint4 v = make_uint4(0, 0, 0, 0);
     if (m_ok) v = *(const uint4*)(a.X + (int64_t)m * a.ldx + ks * 32 + lq * 8);
-    xf[ks] = *(bf16x8*)&v;
+    xf[ks] = *(h16x8*)&v;
   }
   float rs, rm;
   if (a.rs) {
@@ -152,16 +154,16 @@ __global__ void __launch_bounds__(512, 2) ff_fused_kernel(const FfArgs a) {
       const char* sl = smem + (q & (F_RING - 1)) * F_SLAB;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        bf16x8 wf[8];
+        h16x8 wf[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) wf[t] = *(const bf16x8*)(sl + t * 2048 + fsw[kk]);
+        for (int t = 0; t < 8; ++t) wf[t] = *(const h16x8*)(sl + t * 2048 + fsw[kk]);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf[s * 2 + kk], acc1[t], 0, 0, 0);
+        for (int t = 0; t < 8; ++t) acc1[t] = MFMA_16x16x32(wf[t], xf[s * 2 + kk], acc1[t]);
       }
       ++q;
     }
     // ---- folded LayerNorm + bias, GEGLU: p = h * gelu(gate) -> the B operand of GEMM2
-    bf16x8 pf[2];
+    h16x8 pf[2];
 #pragma unroll
     for (int pr = 0; pr < 4; ++pr) {
       const int n = 128 * c + 32 * pr + 4 * lq;            // packed column of the h tile; the gate tile follows 16 later
@@ -170,7 +172,7 @@ __global__ void __launch_bounds__(512, 2) ff_fused_kernel(const FfArgs a) {
       const f32x4 h = acc1[2 * pr] * rs - sh * rm + bh;
       const f32x4 gt = acc1[2 * pr + 1] * rs - sg * rm + bg;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) pf[pr >> 1][(pr & 1) * 4 + e] = (bf16)(h[e] * gelu_erf(gt[e]));
+      for (int e = 0; e < 4; ++e) pf[pr >> 1][(pr & 1) * 4 + e] = (h16)(h[e] * gelu_erf(gt[e]));
     }
     // ---- GEMM2: acc2[320 columns] += P (16 x 64) W2p[:, chunk]^T, 3 slabs of 128 W2 rows
 #pragma unroll
@@ -182,8 +184,8 @@ __global__ void __launch_bounds__(512, 2) ff_fused_kernel(const FfArgs a) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           if (s * 8 + t < FC / 16) {
-            const bf16x8 wf = *(const bf16x8*)(sl + t * 2048 + fsw[kk]);
-            acc2[s * 8 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, pf[kk], acc2[s * 8 + t], 0, 0, 0);
+            const h16x8 wf = *(const h16x8*)(sl + t * 2048 + fsw[kk]);
+            acc2[s * 8 + t] = MFMA_16x16x32(wf, pf[kk], acc2[s * 8 + t]);
           }
         }
       }
@@ -191,28 +193,28 @@ __global__ void __launch_bounds__(512, 2) ff_fused_kernel(const FfArgs a) {
     }
   }
 
-  // ---- epilogue: + b2 + residual, bf16 store (4 consecutive columns per lane)
+  // ---- epilogue: + b2 + residual, h16 store (4 consecutive columns per lane)
   if (m_ok) {
 #pragma unroll
     for (int t = 0; t < FC / 16; ++t) {
       const int n = t * 16 + lq * 4;
       f32x4 v = acc2[t] + *(const f32x4*)(a.b2 + n);
       if (a.residual) {
-        const bf16x4 r = *(const bf16x4*)(a.residual + (int64_t)m * a.ldr + n);
+        const h16x4 r = *(const h16x4*)(a.residual + (int64_t)m * a.ldr + n);
         v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
       }
-      *(bf16x4*)(a.out + (int64_t)m * a.ldo + n) = to_bf16x4(v);
+      *(h16x4*)(a.out + (int64_t)m * a.ldo + n) = to_h16x4(v);
     }
   }
 }
 
 // W2p[n][32 b + 8 lq + j] = W2[n][32 b + 16 (j >> 2) + 4 lq + (j & 3)]: the k order in which the GEGLU registers of a lane line up
-__global__ void pack_ff2_perm_kernel(const float* __restrict__ w, bf16* __restrict__ out, int N, int K) {
+__global__ void pack_ff2_perm_kernel(const float* __restrict__ w, h16* __restrict__ out, int N, int K) {
   const int64_t total = (int64_t)N * K;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int n = (int)(idx / K), k = (int)(idx - (int64_t)n * K);
     const int b = k >> 5, p = k & 31, lq = p >> 3, j = p & 7;
-    out[idx] = (bf16)w[(int64_t)n * K + 32 * b + 16 * (j >> 2) + 4 * lq + (j & 3)];
+    out[idx] = (h16)w[(int64_t)n * K + 32 * b + 16 * (j >> 2) + 4 * lq + (j & 3)];
   }
 }
 
@@ -227,14 +229,14 @@ bool ff_fused_supported(int C, int M) {
   return on && C == FC && M >= 128 * 192;     // enough 128-row tiles to give every CU a workgroup
 }
 
-void pack_ff2_perm(const float* w, bf16* out, int N, int K, hipStream_t s) {
+void pack_ff2_perm(const float* w, h16* out, int N, int K, hipStream_t s) {
   const int64_t total = (int64_t)N * K;
   hipLaunchKernelGGL(pack_ff2_perm_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, w, out, N, K);
   check_launch("pack_ff2_perm");
 }
 
-void ff_fused(svg_ctx* ctx, const bf16* X, int ldx, const bf16* W1, const float* b1, const float* s1, const float* rs, const float* rm,
-              const bf16* W2p, const float* b2, const bf16* residual, int ldr, bf16* out, int ldo, int M, hipStream_t s) {
+void ff_fused(svg_ctx* ctx, const h16* X, int ldx, const h16* W1, const float* b1, const float* s1, const float* rs, const float* rm,
+              const h16* W2p, const float* b2, const h16* residual, int ldr, h16* out, int ldo, int M, hipStream_t s) {
   SVG_CHECK(ldx % 8 == 0 && ldr % 4 == 0 && ldo % 4 == 0 && (int64_t)M * ldx < (1LL << 31), "ff_fused: strides / size unsupported");
   if (!SVG_LAUNCHING(ctx)) return;
   char tag[64];
@@ -245,3 +247,5 @@ void ff_fused(svg_ctx* ctx, const bf16* X, int ldx, const bf16* W1, const float*
   hipLaunchKernelGGL(ff_fused_kernel, dim3(cdiv(M, 128)), dim3(512), F_LDS, s, a);
   check_launch("ff_fused");
 }
+
+}  // namespace SDNS

@@ -6,7 +6,7 @@
 // buffer loads (no VGPR round trip): the DMA of K-step t+1 is issued before the MFMAs of K-step t.
 // (A 256 x 320 tile — 4 waves x 512 registers, half the L2 traffic per FLOP — was tried: hipcc cannot allocate its
 //  320 accumulator registers without hundreds of AGPR<->VGPR copies and scratch spills in the loop; it needs hand asm.)
-// LDS rows are 128 B (64 bf16); 16-B chunk c of row r is stored at chunk c ^ ((r>>1)&7) so the
+// LDS rows are 128 B (64 h16); 16-B chunk c of row r is stored at chunk c ^ ((r>>1)&7) so the
 // ds_read_b128 fragment reads (16 rows x 2 k-chunks per lane group) are bank-conflict free.
 // The MFMA is issued with the WEIGHT fragment as the A operand and the activation fragment as
 // the B operand, so D[i][j] has i = output column n (4 consecutive n per lane in registers) and
@@ -15,6 +15,8 @@
 #include <cstdlib>
 
 #include "igemm_epi.h"
+
+namespace SDNS {
 
 // conv_halo.hip
 bool conv_halo_supported(const GemmArgs& g);
@@ -29,7 +31,7 @@ namespace {
 // GEGLU: h and gate are 4 consecutive packed columns nh.. / nh+16..; output column oc..oc+3
 __device__ __forceinline__ void epi_store_geglu(const GemmArgs& g, int z, int m, int nh, int oc, f32x4 h, f32x4 gt) {
   int64_t o = (int64_t)z * g.sC + (int64_t)m * g.ldc + oc;
-  *(bf16x4*)((bf16*)g.C + o) = to_bf16x4(geglu_value(g, m, nh, h, gt));
+  *(h16x4*)((h16*)g.C + o) = to_h16x4(geglu_value(g, m, nh, h, gt));
 }
 
 template <int BN, int AMODE>
@@ -68,8 +70,8 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const GemmArgs g) {
   const int kt_begin = ks * kt_per;
   const int kt_end = min(KT, kt_begin + kt_per);
 
-  const bf16* __restrict__ Ap = g.A + (int64_t)z * g.sA;
-  const bf16* __restrict__ Bp = g.Wt + (int64_t)z * g.sB;
+  const h16* __restrict__ Ap = g.A + (int64_t)z * g.sA;
+  const h16* __restrict__ Bp = g.Wt + (int64_t)z * g.sB;
 
   // ---- loader state ---------------------------------------------------------------------------
   // Global -> register staging uses buffer loads: per-lane byte offset in voffset, the K-slab offset (uniform)
@@ -224,16 +226,16 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const GemmArgs g) {
     const char* sb = sa + A_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[MT], bfr[NT];
+      h16x8 af[MT], bfr[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(sa + lds_off(wm * 64 + i * 16 + l15, kk * 4 + lq));
+      for (int i = 0; i < MT; ++i) af[i] = *(const h16x8*)(sa + lds_off(wm * 64 + i * 16 + l15, kk * 4 + lq));
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(sb + lds_off(wn * (BN / 2) + j * 16 + l15, kk * 4 + lq));
+      for (int j = 0; j < NT; ++j) bfr[j] = *(const h16x8*)(sb + lds_off(wn * (BN / 2) + j * 16 + l15, kk * 4 + lq));
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = MFMA_16x16x32(bfr[j], af[i], acc[i][j]);
     }
   };
 
@@ -309,24 +311,24 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmArgs g) {
 }
 
 // ---- packing -------------------------------------------------------------------------------------
-__global__ void pack_conv3x3_kernel(const float* __restrict__ w, bf16* __restrict__ out, int O, int I, int Opad, int Ipad) {
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, h16* __restrict__ out, int O, int I, int Opad, int Ipad) {
   int64_t total = (int64_t)Opad * 9 * Ipad;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     int ci = (int)(idx % Ipad);
     int t = (int)((idx / Ipad) % 9);
     int o = (int)(idx / ((int64_t)Ipad * 9));
     float v = (o < O && ci < I) ? w[((int64_t)o * I + ci) * 9 + t] : 0.f;
-    out[idx] = (bf16)v;
+    out[idx] = (h16)v;
   }
 }
-__global__ void pack_linear_kernel(const float* __restrict__ w, bf16* __restrict__ out, int N, int K, int Npad) {
+__global__ void pack_linear_kernel(const float* __restrict__ w, h16* __restrict__ out, int N, int K, int Npad) {
   int64_t total = (int64_t)Npad * K;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     int n = (int)(idx / K);
-    out[idx] = (bf16)((n < N) ? w[idx] : 0.f);
+    out[idx] = (h16)((n < N) ? w[idx] : 0.f);
   }
 }
-__global__ void pack_geglu_kernel(const float* __restrict__ w, const float* __restrict__ b, bf16* __restrict__ wout,
+__global__ void pack_geglu_kernel(const float* __restrict__ w, const float* __restrict__ b, h16* __restrict__ wout,
                                   float* __restrict__ bout, int F, int K) {
   // packed row p: tile = p/16; pair = tile/2; which = tile&1 (0 h, 1 gate); src row = which*F + pair*16 + p%16
   int64_t total = (int64_t)2 * F * K;
@@ -334,7 +336,7 @@ __global__ void pack_geglu_kernel(const float* __restrict__ w, const float* __re
     int p = (int)(idx / K), k = (int)(idx - (int64_t)p * K);
     int tile = p >> 4, pair = tile >> 1, which = tile & 1;
     int src = which * F + pair * 16 + (p & 15);
-    wout[idx] = (bf16)w[(int64_t)src * K + k];
+    wout[idx] = (h16)w[(int64_t)src * K + k];
     if (k == 0 && b) bout[p] = b[src];
   }
 }
@@ -529,18 +531,20 @@ void gemm_auto(svg_ctx* ctx, GemmArgs g, hipStream_t s, int prof_kind) {
   }
 }
 
-void pack_conv3x3(const float* w, bf16* out, int O, int I, int Opad, int Ipad, hipStream_t s) {
+void pack_conv3x3(const float* w, h16* out, int O, int I, int Opad, int Ipad, hipStream_t s) {
   int64_t total = (int64_t)Opad * 9 * Ipad;
   hipLaunchKernelGGL(pack_conv3x3_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, w, out, O, I, Opad, Ipad);
   check_launch("pack_conv3x3");
 }
-void pack_linear(const float* w, bf16* out, int N, int K, int Npad, hipStream_t s) {
+void pack_linear(const float* w, h16* out, int N, int K, int Npad, hipStream_t s) {
   int64_t total = (int64_t)Npad * K;
   hipLaunchKernelGGL(pack_linear_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, w, out, N, K, Npad);
   check_launch("pack_linear");
 }
-void pack_geglu(const float* w, const float* b, bf16* wout, float* bout, int F, int K, hipStream_t s) {
+void pack_geglu(const float* w, const float* b, h16* wout, float* bout, int F, int K, hipStream_t s) {
   int64_t total = (int64_t)2 * F * K;
   hipLaunchKernelGGL(pack_geglu_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, w, b, wout, bout, F, K);
   check_launch("pack_geglu");
 }
+
+}  // namespace SDNS

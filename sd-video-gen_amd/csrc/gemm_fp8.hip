@@ -12,10 +12,12 @@
 //
 // Kernel: gemm.hip's structure at K step 128: tile 128 x BN x 128 per 256-thread workgroup (2 x 2 waves, each 64 x BN/2), two LDS
 // stages filled by LDS-direct buffer loads, the same XOR swizzle (rows are 128 B here too), weight fragment as the A operand so
-// that a lane owns 4 consecutive output columns, shared tile epilogue (bias / residual / activation, bf16 or f32 out).
+// that a lane owns 4 consecutive output columns, shared tile epilogue (bias / residual / activation, h16 or f32 out).
 // The scales ([rows][K/32] bytes) ride in registers: one byte load per fragment row and K step.
 #include "igemm_epi.h"
 #include <cstdlib>
+
+namespace SDNS {
 
 namespace {
 
@@ -169,14 +171,14 @@ void gemm_fp8_init_device() {
   HIP_OK(hipFuncSetAttribute((const void*)gemm_fp8_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM * 128 + 64 * 128)));
 }
 
-void quant_mx_bf16(svg_ctx* ctx, const bf16* x, int ldx, uint8_t* q, uint8_t* sc, int64_t rows, int K, hipStream_t s) {
+void quant_mx_h16(svg_ctx* ctx, const h16* x, int ldx, uint8_t* q, uint8_t* sc, int64_t rows, int K, hipStream_t s) {
   SVG_CHECK(K % 32 == 0 && ldx % 2 == 0, "quant_mx: K=%d must be a multiple of 32", K);
   if (!SVG_LAUNCHING(ctx)) return;
   char tag[64];
   snprintf(tag, sizeof(tag), "quant_mx_rows%lld_K%d", (long long)rows, K);
   ProfScope ps(ctx, PK_ELT, s, 0, 3.0 * rows * K, tag);
   const int64_t nblk = rows * (K / 32);
-  hipLaunchKernelGGL((quant_mx_kernel<bf16>), dim3((unsigned)std::min<int64_t>((nblk + 15) / 16, 16384)), dim3(256), 0, s, x, ldx, q, sc, rows, K);
+  hipLaunchKernelGGL((quant_mx_kernel<h16>), dim3((unsigned)std::min<int64_t>((nblk + 15) / 16, 16384)), dim3(256), 0, s, x, ldx, q, sc, rows, K);
   check_launch("quant_mx");
 }
 void quant_mx_f32(const float* x, int ldx, uint8_t* q, uint8_t* sc, int64_t rows, int K, hipStream_t s) {
@@ -200,3 +202,5 @@ void gemm_fp8(svg_ctx* ctx, const uint8_t* A, const uint8_t* As, const uint8_t* 
   if (g.N <= 64) launch_fp8<64>(a, s); else launch_fp8<128>(a, s);
   check_launch("gemm_fp8");
 }
+
+}  // namespace SDNS

@@ -12,6 +12,8 @@
 #include "igemm_epi.h"
 #include <cstdlib>
 
+namespace SDNS {
+
 namespace {
 
 template <int BN>
@@ -88,13 +90,13 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs g) {
     xaddr[kk] = (wm * 64 + l15) * 128 + sw;
     waddr[kk] = A_BYTES + (wn * (BN / 2) + l15) * 128 + sw;
   }
-  auto rd = [&](int stage, int kk, bf16x8 (&xf)[MT], bf16x8 (&wf)[NT]) {
+  auto rd = [&](int stage, int kk, h16x8 (&xf)[MT], h16x8 (&wf)[NT]) {
     const char* sx = smem + stage * STAGE + xaddr[kk];
     const char* sw = smem + stage * STAGE + waddr[kk];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) xf[i] = *(const bf16x8*)(sx + i * 2048);
+    for (int i = 0; i < MT; ++i) xf[i] = *(const h16x8*)(sx + i * 2048);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) wf[j] = *(const bf16x8*)(sw + j * 2048);
+    for (int j = 0; j < NT; ++j) wf[j] = *(const h16x8*)(sw + j * 2048);
   };
 
   f32x4 acc[MT][NT];
@@ -102,14 +104,14 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs g) {
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto mma_phase = [&](const bf16x8 (&xf)[MT], const bf16x8 (&wf)[NT]) {
+  auto mma_phase = [&](const h16x8 (&xf)[MT], const h16x8 (&wf)[NT]) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = MFMA_16x16x32(wf[j], xf[i], acc[i][j]);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -125,7 +127,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs g) {
     wait_vm(NW);                              // NW <= 7: slab 0 landed, slab 1 may be in flight
     bar();
     if (grp == 1) bar();
-    bf16x8 xa[MT], wa[NT], xb[MT], wb[NT];
+    h16x8 xa[MT], wa[NT], xb[MT], wb[NT];
     rd(0, 0, xa, wa);
     int st = 0;                               // stage of slab s
     for (int s = 0; s < KT; ++s) {
@@ -193,3 +195,5 @@ void launch_gemm_pp(const GemmArgs& g, hipStream_t s) {
   if (gemm_pp_bn(g) == 160) launch_pp<160>(g, s);
   else launch_pp<128>(g, s);
 }
+
+}  // namespace SDNS

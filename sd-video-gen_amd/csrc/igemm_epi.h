@@ -3,8 +3,8 @@
 #pragma once
 #include "kernels.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+namespace SDNS {
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -109,7 +109,7 @@ __device__ __forceinline__ f32x4 epi_value(const GemmArgs& g, int z, int m, int 
     v += b;
   }
   if (g.residual) {
-    bf16x4 r = *(const bf16x4*)(g.residual + (int64_t)z * g.sC + (int64_t)m * g.ldr + n);
+    h16x4 r = *(const h16x4*)(g.residual + (int64_t)z * g.sC + (int64_t)m * g.ldr + n);
     v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
   }
   if (g.act == ACT_SILU) {
@@ -119,16 +119,16 @@ __device__ __forceinline__ f32x4 epi_value(const GemmArgs& g, int z, int m, int 
   }
   return v;
 }
-__device__ __forceinline__ bf16x4 to_bf16x4(f32x4 v) {
-  bf16x4 w;
-  w[0] = (bf16)v[0]; w[1] = (bf16)v[1]; w[2] = (bf16)v[2]; w[3] = (bf16)v[3];
+__device__ __forceinline__ h16x4 to_h16x4(f32x4 v) {
+  h16x4 w;
+  w[0] = (h16)v[0]; w[1] = (h16)v[1]; w[2] = (h16)v[2]; w[3] = (h16)v[3];
   return w;
 }
 __device__ __forceinline__ void epi_store(const GemmArgs& g, int z, int m, int n, f32x4 v) {
   v = epi_value(g, z, m, n, v);
   int64_t o = (int64_t)z * g.sC + (int64_t)m * g.ldc + n;
   if (g.out_f32) *(f32x4*)((float*)g.C + o) = v;
-  else *(bf16x4*)((bf16*)g.C + o) = to_bf16x4(v);
+  else *(h16x4*)((h16*)g.C + o) = to_h16x4(v);
 }
 __device__ __forceinline__ f32x4 geglu_value(const GemmArgs& g, int m, int nh, f32x4 h, f32x4 gt) {
   if (g.bias) {
@@ -220,7 +220,7 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int m
         for (int j = 0; j < NT_; ++j) {
           const int n = nc + 16 * j;
           if (i0 + ii < MT_ && m < g.M && n < g.N) {
-            const bf16x4 r = *(const bf16x4*)(g.residual + (int64_t)z * g.sC + (int64_t)m * g.ldr + n);
+            const h16x4 r = *(const h16x4*)(g.residual + (int64_t)z * g.sC + (int64_t)m * g.ldr + n);
             ex[ii][j][0] += (float)r[0]; ex[ii][j][1] += (float)r[1]; ex[ii][j][2] += (float)r[2]; ex[ii][j][3] += (float)r[3];
           }
         }
@@ -244,7 +244,7 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int m
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = h[e] * gelu_erf(gt[e]);
             const int oc = (nh >> 5) * 16 + (nh & 15);
-            *(bf16x4*)((bf16*)g.C + (int64_t)z * g.sC + (int64_t)m * g.ldc + oc) = to_bf16x4(v);
+            *(h16x4*)((h16*)g.C + (int64_t)z * g.sC + (int64_t)m * g.ldc + oc) = to_h16x4(v);
           }
         }
       } else {
@@ -264,8 +264,8 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int m
           const int64_t o = (int64_t)z * g.sC + (int64_t)m * g.ldc + n;
           if (g.out_f32) *(f32x4*)((float*)g.C + o) = v;
           else {
-            const bf16x4 w = to_bf16x4(v);
-            *(bf16x4*)((bf16*)g.C + o) = w;
+            const h16x4 w = to_h16x4(v);
+            *(h16x4*)((h16*)g.C + o) = w;
             // the accumulator is dead from here: keep what the consumer will read (the rounded values) in it for the
             // GroupNorm column sums below — no extra registers live across the stores
             if (emit_gn || emit_ln) { acc[i][j][0] = (float)w[0]; acc[i][j][1] = (float)w[1]; acc[i][j][2] = (float)w[2]; acc[i][j][3] = (float)w[3]; }
@@ -385,3 +385,5 @@ __device__ __forceinline__ void wait_vm(int n) {
 }
 
 }  // namespace
+
+}  // namespace SDNS

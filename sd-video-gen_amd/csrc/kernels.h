@@ -2,6 +2,10 @@
 #pragma once
 #include "common.h"
 
+// Everything down to the latent-Transformer section belongs to the Stable-Diffusion side and lives in namespace SDNS
+// (sd_bf16 or sd_f16, see common.h): these sources are compiled once per storage type.
+namespace SDNS {
+
 // ------------------------------------------------------------------------------------------------
 // MFMA implicit GEMM:  C[M,N] = epi( A[M,K] * Wt[N,K]^T )
 //   A is either a dense row-major bf16 matrix or a gathered 3x3-conv window of an NHWC tensor.
@@ -11,17 +15,17 @@ enum Act { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2, ACT_GEGLU = 3 };
 
 struct GemmArgs {
   // A operand
-  const bf16* A = nullptr;
+  const h16* A = nullptr;
   int amode = A_DENSE;
   int lda = 0;                   // dense: row stride (elements)
   // dense, two-source A = channel concat [A | A2] (torch.cat([hidden, skip], dim=1) feeding a 1x1 shortcut): K columns
   // >= k_split (a multiple of 64) come from A2 (row stride lda2); igemm only
-  const bf16* A2 = nullptr;
+  const h16* A2 = nullptr;
   int lda2 = 0, k_split = 0;
   int H = 0, W = 0, Cin = 0;     // conv: input dims (NHWC)
   int Ho = 0, Wo = 0;            // conv: output dims
   // B operand (weights [N][K], K contiguous)
-  const bf16* Wt = nullptr;
+  const h16* Wt = nullptr;
   int ldb = 0;
   int n_valid = 0;               // rows of Wt that exist (<= N); rows beyond read as zero
   // C
@@ -38,7 +42,7 @@ struct GemmArgs {
   const float* bias_bn = nullptr;    // [M/rows_per_batch][N] per-sample column bias (time embedding)
   int rows_per_batch = 1;
   int bias_bn_ld = 0;                // row stride of bias_bn (0 = N)
-  const bf16* residual = nullptr;    // [M][ldr]
+  const h16* residual = nullptr;    // [M][ldr]
   int ldr = 0;
   int act = ACT_NONE;
   int out_f32 = 0;
@@ -77,32 +81,31 @@ void gemm_pp_init_device();
 void conv_halo_init_device();
 void ff_fused_init_device();
 void gemm_fp8_init_device();
-void xf_train_init_device();
 
 // ---- MX block-scaled fp8 (OCP e4m3 elements, one E8M0 scale per 32 K elements): quantiser and GEMM (gemm_fp8.hip)
-void quant_mx_bf16(svg_ctx* ctx, const bf16* x, int ldx, uint8_t* q, uint8_t* sc, int64_t rows, int K, hipStream_t s);
+void quant_mx_h16(svg_ctx* ctx, const h16* x, int ldx, uint8_t* q, uint8_t* sc, int64_t rows, int K, hipStream_t s);
 void quant_mx_f32(const float* x, int ldx, uint8_t* q, uint8_t* sc, int64_t rows, int K, hipStream_t s);
 bool gemm_fp8_supported(int M, int N, int K);
 void gemm_fp8(svg_ctx* ctx, const uint8_t* A, const uint8_t* As, const uint8_t* W, const uint8_t* Ws, const GemmArgs& g, hipStream_t s);
 
 // fused GEGLU feed-forward (C = 320): out = (GEGLU(LN(x) W1^T + b1)) W2^T + b2 + residual; the M x 4C intermediate stays on chip
 bool ff_fused_supported(int C, int M);
-void pack_ff2_perm(const float* w, bf16* out, int N, int K, hipStream_t s);
-void ff_fused(svg_ctx* ctx, const bf16* X, int ldx, const bf16* W1, const float* b1, const float* s1, const float* rs, const float* rm,
-              const bf16* W2p, const float* b2, const bf16* residual, int ldr, bf16* out, int ldo, int M, hipStream_t s);
+void pack_ff2_perm(const float* w, h16* out, int N, int K, hipStream_t s);
+void ff_fused(svg_ctx* ctx, const h16* X, int ldx, const h16* W1, const float* b1, const float* s1, const float* rs, const float* rm,
+              const h16* W2p, const float* b2, const h16* residual, int ldr, h16* out, int ldo, int M, hipStream_t s);
 // picks split-K from the shape, allocates slabs from the arena, launches
 void gemm_auto(svg_ctx* ctx, GemmArgs g, hipStream_t s, int prof_kind);
 
 // weight packing (device): f32 OIHW -> bf16 [Opad][ky][kx][Ipad]; f32 [N][K] -> bf16 [Npad][K]
-void pack_conv3x3(const float* w_oihw, bf16* out, int O, int I, int Opad, int Ipad, hipStream_t s);
-void pack_linear(const float* w, bf16* out, int N, int K, int Npad, hipStream_t s);
+void pack_conv3x3(const float* w_oihw, h16* out, int O, int I, int Opad, int Ipad, hipStream_t s);
+void pack_linear(const float* w, h16* out, int N, int K, int Npad, hipStream_t s);
 // LayerNorm folding (load time): bias_out[n] = bias_in[n] + sum_k W[n][k] beta[k]; then W[n][k] *= gamma[k] in place
 void fold_ln_weights(float* w, const float* bias_in, const float* gamma, const float* beta, float* bias_out, int N, int K, hipStream_t s);
-void rowsum_bf16(const bf16* w, float* out, int N, int K, hipStream_t s);
+void rowsum_h16(const h16* w, float* out, int N, int K, hipStream_t s);
 // per-row LayerNorm statistics of x[M][C]: rs = rstd, rm = rstd * mean
-void ln_stats(svg_ctx* ctx, const bf16* x, float* rs, float* rm, int M, int C, float eps, hipStream_t s);
+void ln_stats(svg_ctx* ctx, const h16* x, float* rs, float* rm, int M, int C, float eps, hipStream_t s);
 // GEGLU: rows [h(0..F-1); gate(0..F-1)] -> 16-row tiles alternating h / gate; bias likewise
-void pack_geglu(const float* w, const float* b, bf16* wout, float* bout, int F, int K, hipStream_t s);
+void pack_geglu(const float* w, const float* b, h16* wout, float* bout, int F, int K, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // normalisation / softmax
@@ -119,28 +122,28 @@ struct GnStats {
 };
 // x (B,HW,C) bf16 NHWC; optional second source for channel concat [x | x2] (C = C1 + C2).  With the producers' column sums
 // (st1 for x, st2 for x2) the statistics pass over the tensor is skipped: a small kernel finishes (mean, rstd) per (sample, group).
-void groupnorm(svg_ctx* ctx, const bf16* x, int C1, const bf16* x2, int C2, const float* gamma,
-               const float* beta, bf16* out, int B, int HW, int groups, float eps, int silu,
+void groupnorm(svg_ctx* ctx, const h16* x, int C1, const h16* x2, int C2, const float* gamma,
+               const float* beta, h16* out, int B, int HW, int groups, float eps, int silu,
                hipStream_t s, const GnStats* st1 = nullptr, const GnStats* st2 = nullptr);
 // (mean, rstd) per (sample, group) from producer column sums -> stats[B][groups][2]
 void gn_finish(svg_ctx* ctx, const GnStats& st1, int C1, const GnStats* st2, int C2, float* stats, int B, int HW, int groups, float eps,
                hipStream_t s);
 // GroupNorm folded into a following 1x1 projection (no activation in between): per-sample weights
 // Wb[b][n][c] = bf16(W[n][c] gamma[c] rstd[b][g(c)]) and bias bb[b][n] = bias[n] + sum_c W[n][c] (beta[c] - mean rstd gamma[c])
-void gn_fold_weights(const float* W, const float* bias, const float* gamma, const float* beta, const float* stats, bf16* Wb,
+void gn_fold_weights(const float* W, const float* bias, const float* gamma, const float* beta, const float* stats, h16* Wb,
                      float* bb, int B, int N, int C, int groups, hipStream_t s);
-void layernorm(svg_ctx* ctx, const bf16* x, const float* gamma, const float* beta, bf16* out, int M,
+void layernorm(svg_ctx* ctx, const h16* x, const float* gamma, const float* beta, h16* out, int M,
                int C, float eps, hipStream_t s);
 // rows of f32 scores -> bf16 probabilities; cols valid < n_valid, row stride ld (elements)
-void softmax_rows(svg_ctx* ctx, const float* s_in, bf16* p_out, int64_t rows, int cols, int ld_in,
+void softmax_rows(svg_ctx* ctx, const float* s_in, h16* p_out, int64_t rows, int cols, int ld_in,
                   int ld_out, float scale, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // fused attention
 // ------------------------------------------------------------------------------------------------
 struct AttnArgs {
-  const bf16 *q, *k, *vt;
-  bf16* out;
+  const h16 *q, *k, *vt;
+  h16* out;
   int B, heads, Sq, Skv, d;
   int ldq, ldk, ldvt, ldo;
   int64_t qb, kb, vtb, ob;       // batch strides (elements)
@@ -152,16 +155,16 @@ void attention(svg_ctx* ctx, const AttnArgs& a, hipStream_t s);
 // element-wise / layout
 // ------------------------------------------------------------------------------------------------
 // u8 NHWC (N,sh,sw,3) -> bf16 NHWC (N,H,W,8) with nearest resize, x/255*2-1, channels 3..7 zero
-void img_to_act(const uint8_t* img, bf16* out, int N, int sh, int sw, int H, int W, hipStream_t s);
+void img_to_act(const uint8_t* img, h16* out, int N, int sh, int sw, int H, int W, hipStream_t s);
 // f32 NHWC (N,h,w,ldc) first 3 channels -> optional f32 NCHW + u8 NHWC (N,oh,ow,3) nearest resized:
 // (x/2+.5).clamp(0,1)*255 round-half-even
 void act_to_img(const float* x, int ldc, uint8_t* img, float* fout, int N, int h, int w, int oh, int ow,
                 hipStream_t s);
 // f32 NCHW (N,C,h,w) * scale -> bf16 NHWC (N,h,w,Cpad)
-void nchw_to_act(const float* x, bf16* out, int N, int C, int h, int w, int Cpad, float scale, hipStream_t s);
+void nchw_to_act(const float* x, h16* out, int N, int C, int h, int w, int Cpad, float scale, hipStream_t s);
 // f32 NCHW -> f32 NHWC (scaled); f32 NHWC (P,C) -> bf16 (P,Cpad) zero padded
 void nchw_to_actf32(const float* x, float* out, int N, int C, int h, int w, float scale, hipStream_t s);
-void actf32_pad_bf16(const float* x, int C, bf16* out, int Cpad, int64_t P, hipStream_t s);
+void actf32_pad_h16(const float* x, int C, h16* out, int Cpad, int64_t P, hipStream_t s);
 // f32 NHWC-ish source (N,h,w,ld) f32 -> f32 NCHW (N,C,h,w)
 void actf32_to_nchw(const float* x, int ld, float* out, int N, int C, int h, int w, hipStream_t s);
 // per-pixel 1x1 conv with tiny channel counts, f32: y[p][o] = sum_i w[o][i] x[p][i] + b[o]
@@ -170,20 +173,24 @@ void pixel_linear_f32(const float* x, int ldx, const float* w, const float* b, f
 // VAE posterior sample: moments f32 (P,8) [mean(4); logvar(4)] -> z NCHW f32 = (mean + exp(.5*clamp(lv))*eps)*0.18215
 void vae_sample(const float* mom, int ldm, const float* eps_nchw, float* z_nchw, float* mom_nchw, int N,
                 int h, int w, hipStream_t s);
-void concat_channels(const bf16* a, int Ca, const bf16* b, int Cb, bf16* out, int64_t P, hipStream_t s);
+void concat_channels(const h16* a, int Ca, const h16* b, int Cb, h16* out, int64_t P, hipStream_t s);
 void resize_bilinear_f32(const float* src, float* dst, int P, int h, int w, int oh, int ow, hipStream_t s);
 void resize_nearest_u8(const uint8_t* src, uint8_t* dst, int N, int sh, int sw, int C, int dh, int dw,
                        hipStream_t s);
-void f32_to_bf16(const float* x, bf16* y, int64_t n, hipStream_t s);
-void bf16_to_f32(const bf16* x, float* y, int64_t n, hipStream_t s);
+void f32_to_h16(const float* x, h16* y, int64_t n, hipStream_t s);
+void h16_to_f32(const h16* x, float* y, int64_t n, hipStream_t s);
 // timestep sinusoid (flip_sin_to_cos, shift 0): t f32[N] -> bf16 (N,dim) = [cos | sin]
-void timestep_embed(const float* t, bf16* out, int N, int dim, hipStream_t s);
-void silu_bf16(const bf16* x, bf16* y, int64_t n, hipStream_t s);
+void timestep_embed(const float* t, h16* out, int N, int dim, hipStream_t s);
+void silu_h16(const h16* x, h16* y, int64_t n, hipStream_t s);
 // DDIM: z <- step(z, eps) with clip_sample; coefficients from the device table `coef` row `*step_idx`
 void ddim_step(const float* z, const float* eps_u, const float* eps_c, float guidance, float* z_out,
                int64_t n, float sqrt_at, float sqrt_1mat, float sqrt_ap, float sqrt_1map, hipStream_t s);
 void add_noise(const float* x0, const float* noise, float* out, int64_t n, float sa, float s1a, hipStream_t s);
 void fill_f32(float* p, int64_t n, float v, hipStream_t s);
+
+}  // namespace SDNS
+
+void xf_train_init_device();
 
 // ------------------------------------------------------------------------------------------------
 // latent Transformer (f32, f32-input MFMA)

@@ -30,18 +30,6 @@ inline void run_planned(svg_ctx* ctx, F&& body) {
   body();
 }
 
-// packed bf16 weight matrix [N][K] (+ f32 bias)
-struct PackedLinear {
-  // MX fp8 copy of w (gemm_fp8.hip): e4m3 elements + one E8M0 scale per 32 K elements; present when the owning model was
-  // configured with fp8=1 and the layer qualifies (K % 128 == 0, no folded LayerNorm, no GEGLU)
-  uint8_t* w8 = nullptr;
-  uint8_t* w8s = nullptr;
-  bf16* w = nullptr;
-  float* b = nullptr;
-  float* ln_s = nullptr;     // row sums of w when a LayerNorm (gamma, beta) has been folded into w / b at load
-  int N = 0, K = 0, n_valid = 0;
-};
-
 // ---- latent Transformer ------------------------------------------------------------------------------
 struct XfModel {
   WeightStore ws;
@@ -56,74 +44,6 @@ struct XfModel {
   void finalize(svg_ctx* ctx, int64_t* n_params);
   void forward(svg_ctx* ctx, const float* src, const float* tgt, int B, int Ts, int Tt, const float* mask,
                const int32_t* pe_row, float* out, hipStream_t s, const float* text = nullptr);
-};
-
-// ---- SD VAE -------------------------------------------------------------------------------------------
-struct ConvW { bf16* w = nullptr; float* b = nullptr; int Cin = 0, Cout = 0, Opad = 0; };
-struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
-struct ResW { NormW n1, n2; ConvW c1, c2; PackedLinear sc; bool has_sc = false; int temb_off = -1; };
-struct VaeAttnW { NormW gn; PackedLinear qk, v, proj; int C = 0; };
-
-struct VaeModel {
-  WeightStore ws;
-  std::vector<int> block_out{128, 256, 512, 512};
-  int layers = 2, groups = 32, latent = 4;
-  bool ready = false;
-  // encoder
-  ConvW e_conv_in, e_conv_out;
-  std::vector<std::vector<ResW>> e_down; std::vector<ConvW> e_downs;
-  ResW e_mid0, e_mid1; VaeAttnW e_attn; NormW e_norm_out;
-  float *quant_w = nullptr, *quant_b = nullptr, *pquant_w = nullptr, *pquant_b = nullptr;
-  // decoder
-  ConvW d_conv_in, d_conv_out;
-  std::vector<std::vector<ResW>> d_up; std::vector<ConvW> d_ups;
-  ResW d_mid0, d_mid1; VaeAttnW d_attn; NormW d_norm_out;
-  void configure(const char* kv);
-  void finalize(svg_ctx* ctx, int64_t* n_params);
-  void encode(svg_ctx* ctx, const uint8_t* img, int N, int srcH, int srcW, int H, int W, const float* eps, float* z_out,
-              float* moments_out, hipStream_t s);
-  void decode(svg_ctx* ctx, const float* z, int N, int h, int w, uint8_t* img_out, int outH, int outW, float* float_out,
-              hipStream_t s);
-};
-
-// ---- SD UNet --------------------------------------------------------------------------------------------
-struct XfBlockW {   // SpatialTransformer with one BasicTransformerBlock
-  NormW gn, ln1, ln2, ln3;
-  PackedLinear proj_in, proj_out, qk1, v1, o1, q2, k2, v2, o2, ff1, ff2;
-  float* proj_in_f32 = nullptr;   // [C][C] f32: source of the per-sample GroupNorm-folded weights
-  bf16* ff2p = nullptr;           // ff.net.2 weights with the k order of the fused GEGLU feed-forward (ff_fused.hip), C = 320 only
-  int C = 0;
-};
-// cross-attention K / V^T of a constant context, computed on the first DDIM step and reused by the others
-struct KvCache {
-  std::vector<bf16*> k, vt;
-  std::vector<int64_t> k_cap, vt_cap;
-  bool valid = false;
-};
-
-struct UnetModel {
-  WeightStore ws;
-  KvCache kv;
-  std::vector<int> block_out{320, 640, 1280, 1280};
-  std::vector<int> attn{1, 1, 1, 0};
-  int layers = 2, heads = 8, ctx_dim = 768, groups = 32, in_ch = 4, out_ch = 4;
-  int fp8 = 0;                       // configure key fp8=1: qualifying dense projections run in MX block-scaled fp8
-  bool ready = false;
-  int temb_dim = 0;
-  PackedLinear time1, time2, temb_all;     // temb_all: every resnet's time_emb_proj stacked [sum Cout][temb_dim]
-  ConvW conv_in, conv_out; NormW norm_out;
-  std::vector<std::vector<ResW>> down_res; std::vector<std::vector<XfBlockW>> down_attn; std::vector<ConvW> down_s;
-  ResW mid0, mid1; XfBlockW mid_attn;
-  std::vector<std::vector<ResW>> up_res; std::vector<std::vector<XfBlockW>> up_attn; std::vector<ConvW> up_s;
-  // DDIM tables (scaled_linear 0.00085..0.012, 1000 train steps)
-  std::vector<float> alphas_cumprod;
-  void configure(const char* kv);
-  void finalize(svg_ctx* ctx, int64_t* n_params);
-  void forward(svg_ctx* ctx, const float* x, int N, int h, int w, const float* timesteps, const float* ctx_emb, int ctx_len,
-               float* eps_out, hipStream_t s, KvCache* cache = nullptr);
-  void ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const float* text_emb, int ctx_len, int num_steps,
-                 int start_step, float guidance, const float* noise, float* hist, hipStream_t s);
-  void ddim_coefs(int t, int t_prev, float* sa, float* s1a, float* sap, float* s1ap) const;
 };
 
 // ---- CLIP text tower (transformers CLIPTextModel; reference call site utils/sd_utils.py:60,84,91) ---------------------
@@ -141,6 +61,122 @@ struct ClipTextModel {
 
 void xf_train_free(XfModel* m);
 void destroy_models(svg_ctx* ctx);
+
+// ---- Stable-Diffusion networks: one implementation per storage type (namespace sd_bf16 / sd_f16), chosen at configure time ----
+struct VaeIface {
+  WeightStore ws;
+  bool ready = false;
+  virtual ~VaeIface() {}
+  virtual const char* dtype() const = 0;
+  virtual void configure(const char* kv) = 0;
+  virtual void finalize(svg_ctx* ctx, int64_t* n_params) = 0;
+  virtual void encode(svg_ctx* ctx, const uint8_t* img, int N, int srcH, int srcW, int H, int W, const float* eps, float* z_out,
+                      float* moments_out, hipStream_t s) = 0;
+  virtual void decode(svg_ctx* ctx, const float* z, int N, int h, int w, uint8_t* img_out, int outH, int outW, float* float_out,
+                      hipStream_t s) = 0;
+};
+struct UnetIface {
+  WeightStore ws;
+  bool ready = false;
+  virtual ~UnetIface() {}
+  virtual const char* dtype() const = 0;
+  virtual void configure(const char* kv) = 0;
+  virtual void finalize(svg_ctx* ctx, int64_t* n_params) = 0;
+  virtual void forward(svg_ctx* ctx, const float* x, int N, int h, int w, const float* timesteps, const float* ctx_emb, int ctx_len,
+                       float* eps_out, hipStream_t s) = 0;
+  virtual void ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const float* text_emb, int ctx_len, int num_steps,
+                         int start_step, float guidance, const float* noise, float* hist, hipStream_t s) = 0;
+  virtual void ddim_coefs(int t, int t_prev, float* sa, float* s1a, float* sap, float* s1ap) const = 0;
+};
+VaeIface* new_vae_bf16();
+VaeIface* new_vae_f16();
+UnetIface* new_unet_bf16();
+UnetIface* new_unet_f16();
+namespace sd_bf16 { void sd_init_device(); }
+namespace sd_f16 { void sd_init_device(); }
+
+namespace SDNS {
+
+// packed h16 weight matrix [N][K] (+ f32 bias)
+struct PackedLinear {
+  // MX fp8 copy of w (gemm_fp8.hip): e4m3 elements + one E8M0 scale per 32 K elements; present when the owning model was
+  // configured with fp8=1 and the layer qualifies (K % 128 == 0, no folded LayerNorm, no GEGLU)
+  uint8_t* w8 = nullptr;
+  uint8_t* w8s = nullptr;
+  h16* w = nullptr;
+  float* b = nullptr;
+  float* ln_s = nullptr;     // row sums of w when a LayerNorm (gamma, beta) has been folded into w / b at load
+  int N = 0, K = 0, n_valid = 0;
+};
+
+// ---- SD VAE -------------------------------------------------------------------------------------------
+struct ConvW { h16* w = nullptr; float* b = nullptr; int Cin = 0, Cout = 0, Opad = 0; };
+struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
+struct ResW { NormW n1, n2; ConvW c1, c2; PackedLinear sc; bool has_sc = false; int temb_off = -1; };
+struct VaeAttnW { NormW gn; PackedLinear qk, v, proj; int C = 0; };
+
+struct VaeModel : VaeIface {
+  std::vector<int> block_out{128, 256, 512, 512};
+  int layers = 2, groups = 32, latent = 4;
+  const char* dtype() const override { return SD_F16 ? "fp16" : "bf16"; }
+  // encoder
+  ConvW e_conv_in, e_conv_out;
+  std::vector<std::vector<ResW>> e_down; std::vector<ConvW> e_downs;
+  ResW e_mid0, e_mid1; VaeAttnW e_attn; NormW e_norm_out;
+  float *quant_w = nullptr, *quant_b = nullptr, *pquant_w = nullptr, *pquant_b = nullptr;
+  // decoder
+  ConvW d_conv_in, d_conv_out;
+  std::vector<std::vector<ResW>> d_up; std::vector<ConvW> d_ups;
+  ResW d_mid0, d_mid1; VaeAttnW d_attn; NormW d_norm_out;
+  void configure(const char* kv) override;
+  void finalize(svg_ctx* ctx, int64_t* n_params) override;
+  void encode(svg_ctx* ctx, const uint8_t* img, int N, int srcH, int srcW, int H, int W, const float* eps, float* z_out,
+              float* moments_out, hipStream_t s) override;
+  void decode(svg_ctx* ctx, const float* z, int N, int h, int w, uint8_t* img_out, int outH, int outW, float* float_out,
+              hipStream_t s) override;
+};
+
+// ---- SD UNet --------------------------------------------------------------------------------------------
+struct XfBlockW {   // SpatialTransformer with one BasicTransformerBlock
+  NormW gn, ln1, ln2, ln3;
+  PackedLinear proj_in, proj_out, qk1, v1, o1, q2, k2, v2, o2, ff1, ff2;
+  float* proj_in_f32 = nullptr;   // [C][C] f32: source of the per-sample GroupNorm-folded weights
+  h16* ff2p = nullptr;           // ff.net.2 weights with the k order of the fused GEGLU feed-forward (ff_fused.hip), C = 320 only
+  int C = 0;
+};
+// cross-attention K / V^T of a constant context, computed on the first DDIM step and reused by the others
+struct KvCache {
+  std::vector<h16*> k, vt;
+  std::vector<int64_t> k_cap, vt_cap;
+  bool valid = false;
+};
+
+struct UnetModel : UnetIface {
+  KvCache kv;
+  std::vector<int> block_out{320, 640, 1280, 1280};
+  std::vector<int> attn{1, 1, 1, 0};
+  int layers = 2, heads = 8, ctx_dim = 768, groups = 32, in_ch = 4, out_ch = 4;
+  int fp8 = 0;                       // configure key fp8=1: qualifying dense projections run in MX block-scaled fp8
+  const char* dtype() const override { return SD_F16 ? "fp16" : "bf16"; }
+  int temb_dim = 0;
+  PackedLinear time1, time2, temb_all;     // temb_all: every resnet's time_emb_proj stacked [sum Cout][temb_dim]
+  ConvW conv_in, conv_out; NormW norm_out;
+  std::vector<std::vector<ResW>> down_res; std::vector<std::vector<XfBlockW>> down_attn; std::vector<ConvW> down_s;
+  ResW mid0, mid1; XfBlockW mid_attn;
+  std::vector<std::vector<ResW>> up_res; std::vector<std::vector<XfBlockW>> up_attn; std::vector<ConvW> up_s;
+  // DDIM tables (scaled_linear 0.00085..0.012, 1000 train steps)
+  std::vector<float> alphas_cumprod;
+  void configure(const char* kv) override;
+  void finalize(svg_ctx* ctx, int64_t* n_params) override;
+  // one UNet call (planned by the caller); cache: cross-attention K / V^T reuse across the steps of a DDIM loop
+  void run(svg_ctx* ctx, const float* x, int N, int h, int w, const float* timesteps, const float* ctx_emb, int ctx_len,
+           float* eps_out, hipStream_t s, KvCache* cache = nullptr);
+  void forward(svg_ctx* ctx, const float* x, int N, int h, int w, const float* timesteps, const float* ctx_emb, int ctx_len,
+               float* eps_out, hipStream_t s) override;
+  void ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const float* text_emb, int ctx_len, int num_steps,
+                 int start_step, float guidance, const float* noise, float* hist, hipStream_t s) override;
+  void ddim_coefs(int t, int t_prev, float* sa, float* s1a, float* sap, float* s1ap) const override;
+};
 
 // Request for the GroupNorm column sums of an output (GemmArgs::gn_part): the caller provides `buf` (gn_part_floats() floats, at
 // the arena scope of the output tensor); the wrapper fills `st` when the launch it chose can emit them (else st stays invalid
@@ -167,11 +203,13 @@ NormW load_norm(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int C)
 void add_fp8_copy(svg_ctx* ctx, PackedLinear& pl, hipStream_t s);
 float* keep_f32(svg_ctx* ctx, WeightStore& ws, const std::string& name, int64_t numel);
 // out (B,Ho,Wo,Cout) = conv3x3(x) + bias [+ per-sample bias] [+ residual]
-void conv3x3(svg_ctx* ctx, const bf16* x, const ConvW& cw, void* out, int B, int H, int W, int amode, const float* bias_bn,
-             int bias_bn_ld, const bf16* residual, int out_f32, hipStream_t s, GnEmit* emit = nullptr);
+void conv3x3(svg_ctx* ctx, const h16* x, const ConvW& cw, void* out, int B, int H, int W, int amode, const float* bias_bn,
+             int bias_bn_ld, const h16* residual, int out_f32, hipStream_t s, GnEmit* emit = nullptr);
 // C[M,N] = act(A[M,K] W^T + b) [+ residual]
 // emit / rows_per_sample: GroupNorm column sums of the output (M = samples x rows_per_sample).  A2 / k_split: the A operand is the
 // channel concat [A | A2] of two tensors (columns >= k_split come from A2, row stride lda2) without materialising it.
-void linear(svg_ctx* ctx, const bf16* A, int lda, const PackedLinear& pl, void* C, int ldc, int M, int act, const bf16* residual,
+void linear(svg_ctx* ctx, const h16* A, int lda, const PackedLinear& pl, void* C, int ldc, int M, int act, const h16* residual,
             int ldr, int out_f32, hipStream_t s, const float* ln_rs = nullptr, const float* ln_rm = nullptr, GnEmit* emit = nullptr,
-            int rows_per_sample = 0, const bf16* A2 = nullptr, int lda2 = 0, int k_split = 0, LnEmit* ln = nullptr);
+            int rows_per_sample = 0, const h16* A2 = nullptr, int lda2 = 0, int k_split = 0, LnEmit* ln = nullptr);
+
+}  // namespace SDNS

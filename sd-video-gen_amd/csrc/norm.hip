@@ -3,7 +3,8 @@
 #include "kernels.h"
 #include <cstdlib>
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+namespace SDNS {
+
 
 namespace {
 
@@ -21,7 +22,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // ---- GroupNorm stage 1: per (sample, pixel-chunk) partial sums per channel-group ----------------
 // grid (nchunk, B); block = CV*PL threads where CV = C/8 channel vectors, PL pixel lanes.
 // partial[b][chunk][group][2]
-__global__ void gn_stats_kernel(const bf16* __restrict__ x, int C1, const bf16* __restrict__ x2, int C2,
+__global__ void gn_stats_kernel(const h16* __restrict__ x, int C1, const h16* __restrict__ x2, int C2,
                                 float* __restrict__ partial, int HW, int groups, int nchunk, int CV, int PL) {
   extern __shared__ float sh[];   // [PL][C][2] then reused
   const int C = C1 + C2;
@@ -37,15 +38,15 @@ __global__ void gn_stats_kernel(const bf16* __restrict__ x, int C1, const bf16* 
   if (tid < nthr) {
     const int cv = tid % CV, pl = tid / CV;
     const int c0 = cv * 8;
-    const bf16* src; int ld, coff;
+    const h16* src; int ld, coff;
     if (c0 < C1) { src = x; ld = C1; coff = c0; } else { src = x2; ld = C2; coff = c0 - C1; }
     // four pixels per trip: four independent 16-byte loads in flight per thread (a one-load-per-trip loop is a chain of
     // exposed memory latencies: ~10 trips x ~1 us)
-    const bf16* sp = src + ((int64_t)b * HW + p_begin + pl) * ld + coff;
+    const h16* sp = src + ((int64_t)b * HW + p_begin + pl) * ld + coff;
     const int64_t st = (int64_t)PL * ld;
     int p = p_begin + pl;
     for (; p + 3 * PL < p_end; p += 4 * PL, sp += 4 * st) {
-      const bf16x8 v0 = *(const bf16x8*)sp, v1 = *(const bf16x8*)(sp + st), v2 = *(const bf16x8*)(sp + 2 * st), v3 = *(const bf16x8*)(sp + 3 * st);
+      const h16x8 v0 = *(const h16x8*)sp, v1 = *(const h16x8*)(sp + st), v2 = *(const h16x8*)(sp + 2 * st), v3 = *(const h16x8*)(sp + 3 * st);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float f0 = (float)v0[j], f1 = (float)v1[j], f2 = (float)v2[j], f3 = (float)v3[j];
@@ -54,7 +55,7 @@ __global__ void gn_stats_kernel(const bf16* __restrict__ x, int C1, const bf16* 
       }
     }
     for (; p < p_end; p += PL, sp += st) {
-      const bf16x8 v = *(const bf16x8*)sp;
+      const h16x8 v = *(const h16x8*)sp;
 #pragma unroll
       for (int j = 0; j < 8; ++j) { float f = (float)v[j]; s[j] += f; q[j] += f * f; }
     }
@@ -81,9 +82,9 @@ __global__ void gn_stats_kernel(const bf16* __restrict__ x, int C1, const bf16* 
 // grid (nblk, B); block = CV*PL threads like stage 1.  Each thread owns one 8-channel vector: it folds
 // (mean, rstd, gamma, beta) into 8 (scale, shift) pairs once, then streams its pixels with 16-B loads/stores
 // and 8 FMAs per vector — no divisions or table lookups in the loop.
-__global__ void gn_apply_kernel(const bf16* __restrict__ x, int C1, const bf16* __restrict__ x2, int C2,
+__global__ void gn_apply_kernel(const h16* __restrict__ x, int C1, const h16* __restrict__ x2, int C2,
                                 const float* __restrict__ partial, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, bf16* __restrict__ out, int HW, int groups,
+                                const float* __restrict__ beta, h16* __restrict__ out, int HW, int groups,
                                 int nchunk, float eps, int silu, int CV, int PL) {
   __shared__ float mean_s[64], rstd_s[64];
   const int C = C1 + C2;
@@ -123,34 +124,34 @@ __global__ void gn_apply_kernel(const bf16* __restrict__ x, int C1, const bf16* 
       sh[j] = beta[c0 + j] - mean_s[g] * a;
     }
   }
-  const bf16* src; int ld, coff;
+  const h16* src; int ld, coff;
   if (c0 < C1) { src = x; ld = C1; coff = c0; } else { src = x2; ld = C2; coff = c0 - C1; }
   const int per_blk = (HW + gridDim.x - 1) / gridDim.x;
   const int p_begin = blockIdx.x * per_blk;
   const int p_end = min(HW, p_begin + per_blk);
-  const bf16* sp = src + ((int64_t)b * HW + p_begin + pl) * ld + coff;
-  bf16* dp = out + ((int64_t)b * HW + p_begin + pl) * C + c0;
+  const h16* sp = src + ((int64_t)b * HW + p_begin + pl) * ld + coff;
+  h16* dp = out + ((int64_t)b * HW + p_begin + pl) * C + c0;
   const int64_t sstep = (int64_t)PL * ld, dstep = (int64_t)PL * C;
-  auto apply = [&](const bf16x8& v) -> bf16x8 {
-    bf16x8 o;
+  auto apply = [&](const h16x8& v) -> h16x8 {
+    h16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float f = fmaf((float)v[j], sc[j], sh[j]);
       if (silu) f = f * __builtin_amdgcn_rcpf(1.f + __expf(-f));
-      o[j] = (bf16)f;
+      o[j] = (h16)f;
     }
     return o;
   };
   int p = p_begin + pl;
   // four pixels per trip: the four loads are issued together (see gn_stats_kernel)
   for (; p + 3 * PL < p_end; p += 4 * PL, sp += 4 * sstep, dp += 4 * dstep) {
-    const bf16x8 v0 = *(const bf16x8*)sp, v1 = *(const bf16x8*)(sp + sstep), v2 = *(const bf16x8*)(sp + 2 * sstep), v3 = *(const bf16x8*)(sp + 3 * sstep);
-    *(bf16x8*)dp = apply(v0);
-    *(bf16x8*)(dp + dstep) = apply(v1);
-    *(bf16x8*)(dp + 2 * dstep) = apply(v2);
-    *(bf16x8*)(dp + 3 * dstep) = apply(v3);
+    const h16x8 v0 = *(const h16x8*)sp, v1 = *(const h16x8*)(sp + sstep), v2 = *(const h16x8*)(sp + 2 * sstep), v3 = *(const h16x8*)(sp + 3 * sstep);
+    *(h16x8*)dp = apply(v0);
+    *(h16x8*)(dp + dstep) = apply(v1);
+    *(h16x8*)(dp + 2 * dstep) = apply(v2);
+    *(h16x8*)(dp + 3 * dstep) = apply(v3);
   }
-  for (; p < p_end; p += PL, sp += sstep, dp += dstep) *(bf16x8*)dp = apply(*(const bf16x8*)sp);
+  for (; p < p_end; p += PL, sp += sstep, dp += dstep) *(h16x8*)dp = apply(*(const h16x8*)sp);
 }
 
 // ---- GroupNorm statistics from the producers' column sums (GemmArgs::gn_part): one workgroup per (group, sample) adds the
@@ -192,19 +193,19 @@ __global__ void __launch_bounds__(256) gn_finish_kernel(const float* __restrict_
 // one workgroup per (output row n, sample b)
 __global__ void __launch_bounds__(256) gn_fold_weights_kernel(const float* __restrict__ W, const float* __restrict__ bias,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               const float* __restrict__ stats, bf16* __restrict__ Wb, float* __restrict__ bb,
+                                                               const float* __restrict__ stats, h16* __restrict__ Wb, float* __restrict__ bb,
                                                                int N, int C, int groups) {
   __shared__ float red[4];
   const int n = blockIdx.x, b = blockIdx.y, cpg = C / groups;
   const float* wr = W + (int64_t)n * C;
-  bf16* o = Wb + ((int64_t)b * N + n) * C;
+  h16* o = Wb + ((int64_t)b * N + n) * C;
   const float* st = stats + (int64_t)b * groups * 2;
   float acc = 0.f;
   for (int c = threadIdx.x; c < C; c += 256) {
     const int g = c / cpg;
     const float mean = st[2 * g], rstd = st[2 * g + 1];
     const float w = wr[c], a = gamma[c] * rstd;
-    o[c] = (bf16)(w * a);
+    o[c] = (h16)(w * a);
     acc += w * (beta[c] - mean * a);
   }
   acc = wave_sum(acc);
@@ -217,23 +218,23 @@ __global__ void __launch_bounds__(256) gn_fold_weights_kernel(const float* __res
 // fit its registers (<= 256 x 80 here: the 16 x 16 and 8 x 8 UNet levels, where the two-stage pair above is all launch
 // latency: 22-27 us for 2.6-10 MB).  Values are fetched as 8-byte (4-channel) pieces, so a group may straddle the two
 // sources of a virtual concat.  Deterministic: fixed per-thread order, shuffle + LDS tree.
-typedef __bf16 bf16x4n __attribute__((ext_vector_type(4)));
+typedef h16 h16x4n __attribute__((ext_vector_type(4)));
 template <int MAXCH>
-__global__ void __launch_bounds__(256) gn_small_kernel(const bf16* __restrict__ x, int C1, const bf16* __restrict__ x2, int C2,
+__global__ void __launch_bounds__(256) gn_small_kernel(const h16* __restrict__ x, int C1, const h16* __restrict__ x2, int C2,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       bf16* __restrict__ out, int HW, int groups, float eps, int silu) {
+                                                       h16* __restrict__ out, int HW, int groups, float eps, int silu) {
   __shared__ float red[8];
   const int C = C1 + C2, cpg = C / groups, nch = cpg >> 2, total = HW * nch;
   const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  bf16x4n v[MAXCH];
+  h16x4n v[MAXCH];
   float s = 0.f, q = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXCH; ++i) {
     const int id = tid + 256 * i;
     if (id < total) {
       const int p = id / nch, c = g * cpg + ((id - p * nch) << 2);
-      const bf16* src = (c < C1) ? x + ((int64_t)b * HW + p) * C1 + c : x2 + ((int64_t)b * HW + p) * C2 + (c - C1);
-      v[i] = *(const bf16x4n*)src;
+      const h16* src = (c < C1) ? x + ((int64_t)b * HW + p) * C1 + c : x2 + ((int64_t)b * HW + p) * C2 + (c - C1);
+      v[i] = *(const h16x4n*)src;
 #pragma unroll
       for (int j = 0; j < 4; ++j) { const float f = (float)v[i][j]; s += f; q += f * f; }
     }
@@ -253,35 +254,35 @@ __global__ void __launch_bounds__(256) gn_small_kernel(const bf16* __restrict__ 
       const int p = id / nch, c = g * cpg + ((id - p * nch) << 2);
       const float4 ga = *(const float4*)(gamma + c), be = *(const float4*)(beta + c);
       const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
-      bf16x4n o;
+      h16x4n o;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float a = rstd * gg[j];
         float f = fmaf((float)v[i][j], a, bb[j] - mean * a);
         if (silu) f = f * __builtin_amdgcn_rcpf(1.f + __expf(-f));
-        o[j] = (bf16)f;
+        o[j] = (h16)f;
       }
-      *(bf16x4n*)(out + ((int64_t)b * HW + p) * C + c) = o;
+      *(h16x4n*)(out + ((int64_t)b * HW + p) * C + c) = o;
     }
   }
 }
 
 // ---- LayerNorm: one wave per row -------------------------------------------------------------------
-__global__ void __launch_bounds__(256) layernorm_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
-                                 const float* __restrict__ beta, bf16* __restrict__ out, int M, int C, float eps) {
+__global__ void __launch_bounds__(256) layernorm_kernel(const h16* __restrict__ x, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, h16* __restrict__ out, int M, int C, float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int CV = C / 8;
-  const bf16* xr = x + (int64_t)row * C;
+  const h16* xr = x + (int64_t)row * C;
   // C <= 8*64*4 = 2048: up to 4 vectors per lane
-  bf16x8 v[4];
+  h16x8 v[4];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int cv = lane + 64 * i;
     if (cv < CV) {
-      v[i] = *(const bf16x8*)(xr + cv * 8);
+      v[i] = *(const h16x8*)(xr + cv * 8);
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += (float)v[i][j];
     }
@@ -301,32 +302,32 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const bf16* __restrict__
   for (int i = 0; i < 4; ++i) {
     const int cv = lane + 64 * i;
     if (cv < CV) {
-      bf16x8 o;
+      h16x8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int cc = cv * 8 + j;
-        o[j] = (bf16)(((float)v[i][j] - mean) * rstd * gamma[cc] + beta[cc]);
+        o[j] = (h16)(((float)v[i][j] - mean) * rstd * gamma[cc] + beta[cc]);
       }
-      *(bf16x8*)(out + (int64_t)row * C + cv * 8) = o;
+      *(h16x8*)(out + (int64_t)row * C + cv * 8) = o;
     }
   }
 }
 
 // ---- LayerNorm statistics only (the normalisation itself is folded into the consuming GEMM) ---------------------------
-__global__ void __launch_bounds__(256) ln_stats_kernel(const bf16* __restrict__ x, float* __restrict__ rs, float* __restrict__ rm,
+__global__ void __launch_bounds__(256) ln_stats_kernel(const h16* __restrict__ x, float* __restrict__ rs, float* __restrict__ rm,
                                                        int M, int C, float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int CV = C / 8;
-  const bf16* xr = x + (int64_t)row * C;
-  bf16x8 v[4];
+  const h16* xr = x + (int64_t)row * C;
+  h16x8 v[4];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int cv = lane + 64 * i;
     if (cv < CV) {
-      v[i] = *(const bf16x8*)(xr + cv * 8);
+      v[i] = *(const h16x8*)(xr + cv * 8);
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += (float)v[i][j];
     }
@@ -376,10 +377,10 @@ __global__ void __launch_bounds__(256) fold_ln_kernel(float* __restrict__ w, con
   __syncthreads();
   if (threadIdx.x == 0) bout[n] = (bin ? bin[n] : 0.f) + ((red[0] + red[1]) + (red[2] + red[3]));
 }
-__global__ void __launch_bounds__(256) rowsum_bf16_kernel(const bf16* __restrict__ w, float* __restrict__ out, int K) {
+__global__ void __launch_bounds__(256) rowsum_h16_kernel(const h16* __restrict__ w, float* __restrict__ out, int K) {
   __shared__ float red[4];
   const int n = blockIdx.x;
-  const bf16* wr = w + (int64_t)n * K;
+  const h16* wr = w + (int64_t)n * K;
   float acc = 0.f;
   for (int k = threadIdx.x; k < K; k += 256) acc += (float)wr[k];
   acc = wave_sum(acc);
@@ -389,7 +390,7 @@ __global__ void __launch_bounds__(256) rowsum_bf16_kernel(const bf16* __restrict
 }
 
 // ---- row softmax: f32 scores -> bf16 probabilities, one block per row ------------------------------
-__global__ void __launch_bounds__(256) softmax_rows_kernel(const float* __restrict__ sin, bf16* __restrict__ pout, int cols,
+__global__ void __launch_bounds__(256) softmax_rows_kernel(const float* __restrict__ sin, h16* __restrict__ pout, int cols,
                                     int ld_in, int ld_out, float scale) {
   __shared__ float red[4];
   const int64_t row = blockIdx.x;
@@ -407,8 +408,8 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const float* __restri
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
   __syncthreads();
   const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
-  bf16* pr = pout + row * ld_out;
-  for (int c = threadIdx.x; c < ld_out; c += 256) pr[c] = (bf16)((c < cols) ? __expf(sr[c] * scale - mx) * inv : 0.f);
+  h16* pr = pout + row * ld_out;
+  for (int c = threadIdx.x; c < ld_out; c += 256) pr[c] = (h16)((c < cols) ? __expf(sr[c] * scale - mx) * inv : 0.f);
 }
 
 }  // namespace
@@ -424,14 +425,14 @@ void gn_finish(svg_ctx* ctx, const GnStats& st1, int C1, const GnStats* st2, int
   check_launch("gn_finish");
 }
 
-void gn_fold_weights(const float* W, const float* bias, const float* gamma, const float* beta, const float* stats, bf16* Wb, float* bb,
+void gn_fold_weights(const float* W, const float* bias, const float* gamma, const float* beta, const float* stats, h16* Wb, float* bb,
                      int B, int N, int C, int groups, hipStream_t s) {
   hipLaunchKernelGGL(gn_fold_weights_kernel, dim3(N, B), dim3(256), 0, s, W, bias, gamma, beta, stats, Wb, bb, N, C, groups);
   check_launch("gn_fold_weights");
 }
 
-void groupnorm(svg_ctx* ctx, const bf16* x, int C1, const bf16* x2, int C2, const float* gamma, const float* beta,
-               bf16* out, int B, int HW, int groups, float eps, int silu, hipStream_t s, const GnStats* st1, const GnStats* st2) {
+void groupnorm(svg_ctx* ctx, const h16* x, int C1, const h16* x2, int C2, const float* gamma, const float* beta,
+               h16* out, int B, int HW, int groups, float eps, int silu, hipStream_t s, const GnStats* st1, const GnStats* st2) {
   const int C = C1 + C2;
   SVG_CHECK(C % groups == 0 && C % 8 == 0 && C1 % 8 == 0 && groups <= 64, "groupnorm: C=%d groups=%d unsupported", C, groups);
   const int CV = C / 8;
@@ -503,7 +504,7 @@ void groupnorm(svg_ctx* ctx, const bf16* x, int C1, const bf16* x2, int C2, cons
   ctx->arena.pop();
 }
 
-void layernorm(svg_ctx* ctx, const bf16* x, const float* gamma, const float* beta, bf16* out, int M, int C, float eps,
+void layernorm(svg_ctx* ctx, const h16* x, const float* gamma, const float* beta, h16* out, int M, int C, float eps,
                hipStream_t s) {
   SVG_CHECK(C % 8 == 0 && C <= 2048, "layernorm: C=%d unsupported", C);
   if (!SVG_LAUNCHING(ctx)) return;
@@ -512,7 +513,7 @@ void layernorm(svg_ctx* ctx, const bf16* x, const float* gamma, const float* bet
   check_launch("layernorm");
 }
 
-void ln_stats(svg_ctx* ctx, const bf16* x, float* rs, float* rm, int M, int C, float eps, hipStream_t s) {
+void ln_stats(svg_ctx* ctx, const h16* x, float* rs, float* rm, int M, int C, float eps, hipStream_t s) {
   SVG_CHECK(C % 8 == 0 && C <= 2048, "ln_stats: C=%d unsupported", C);
   if (!SVG_LAUNCHING(ctx)) return;
   char tag[64];
@@ -535,15 +536,17 @@ void fold_ln_weights(float* w, const float* bias_in, const float* gamma, const f
   hipLaunchKernelGGL(fold_ln_kernel, dim3(N), dim3(256), 0, s, w, bias_in, gamma, beta, bias_out, K);
   check_launch("fold_ln");
 }
-void rowsum_bf16(const bf16* w, float* out, int N, int K, hipStream_t s) {
-  hipLaunchKernelGGL(rowsum_bf16_kernel, dim3(N), dim3(256), 0, s, w, out, K);
-  check_launch("rowsum_bf16");
+void rowsum_h16(const h16* w, float* out, int N, int K, hipStream_t s) {
+  hipLaunchKernelGGL(rowsum_h16_kernel, dim3(N), dim3(256), 0, s, w, out, K);
+  check_launch("rowsum_h16");
 }
 
-void softmax_rows(svg_ctx* ctx, const float* s_in, bf16* p_out, int64_t rows, int cols, int ld_in, int ld_out, float scale,
+void softmax_rows(svg_ctx* ctx, const float* s_in, h16* p_out, int64_t rows, int cols, int ld_in, int ld_out, float scale,
                   hipStream_t s) {
   if (!SVG_LAUNCHING(ctx)) return;
   ProfScope ps(ctx, PK_SOFTMAX, s, 0, (double)rows * cols * 10.0);
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, s_in, p_out, cols, ld_in, ld_out, scale);
   check_launch("softmax_rows");
 }
+
+}  // namespace SDNS

@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <cstdlib>
 
+namespace SDNS {
+
 // elements one kernel launch may address per operand (32-bit byte offsets); $SVG_CHUNK_LIMIT lowers it so that the tests can
 // drive the batch / row chunking of conv3x3() and linear() at small sizes (read per call: the tests toggle it in-process)
 static int64_t chunk_limit() {
@@ -27,7 +29,7 @@ ConvW load_conv3x3(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int
   cw.Opad = (int)align_up(Cout, 4);
   cw.Cin = (Cin < 64) ? 8 : Cin;       // small-Cin convs (image / latent inputs) run on 8 padded channels
   SVG_CHECK(Cin <= 8 || Cin % 64 == 0, "conv %s: Cin=%d must be <= 8 or a multiple of 64", prefix.c_str(), Cin);
-  cw.w = (bf16*)ctx->dalloc((int64_t)cw.Opad * 9 * cw.Cin * sizeof(bf16));
+  cw.w = (h16*)ctx->dalloc((int64_t)cw.Opad * 9 * cw.Cin * sizeof(h16));
   pack_conv3x3(w.f32, cw.w, Cout, Cin, cw.Opad, cw.Cin, s);
   cw.b = (float*)ctx->dalloc(cw.Opad * sizeof(float));
   HIP_OK(hipMemsetAsync(cw.b, 0, cw.Opad * sizeof(float), s));
@@ -43,7 +45,7 @@ PackedLinear load_linear(svg_ctx* ctx, WeightStore& ws, const std::string& prefi
   SVG_CHECK(w.numel == (int64_t)N * K && w.shape[0] == N, "weight %s.weight: expected [%d,%d(,1,1)]", prefix.c_str(), N, K);
   PackedLinear pl;
   pl.N = (int)align_up(N, 4); pl.K = K; pl.n_valid = N;
-  pl.w = (bf16*)ctx->dalloc((int64_t)pl.N * K * sizeof(bf16));
+  pl.w = (h16*)ctx->dalloc((int64_t)pl.N * K * sizeof(h16));
   if (bias || fold) {
     pl.b = (float*)ctx->dalloc(pl.N * sizeof(float));
     HIP_OK(hipMemsetAsync(pl.b, 0, pl.N * sizeof(float), s));
@@ -56,7 +58,7 @@ PackedLinear load_linear(svg_ctx* ctx, WeightStore& ws, const std::string& prefi
   pack_linear(w.f32, pl.w, N, K, pl.N, s);
   if (fold) {
     pl.ln_s = (float*)ctx->dalloc(pl.N * sizeof(float));
-    rowsum_bf16(pl.w, pl.ln_s, pl.N, K, s);
+    rowsum_h16(pl.w, pl.ln_s, pl.N, K, s);
   }
   HIP_OK(hipStreamSynchronize(s));
   ws.release(prefix + ".weight");
@@ -67,7 +69,7 @@ void add_fp8_copy(svg_ctx* ctx, PackedLinear& pl, hipStream_t s) {
   if (!pl.w || pl.ln_s || pl.K % 128 != 0 || pl.N % 4 != 0 || pl.w8) return;
   pl.w8 = (uint8_t*)ctx->dalloc((int64_t)pl.N * pl.K);
   pl.w8s = (uint8_t*)ctx->dalloc((int64_t)pl.N * (pl.K / 32));
-  quant_mx_bf16(ctx, pl.w, pl.K, pl.w8, pl.w8s, pl.N, pl.K, s);
+  quant_mx_h16(ctx, pl.w, pl.K, pl.w8, pl.w8s, pl.N, pl.K, s);
   HIP_OK(hipStreamSynchronize(s));
 }
 
@@ -90,8 +92,8 @@ static void plan_gn_emit(GemmArgs& g, GnEmit* emit, int rows_per_sample) {
   emit->st.tiles_per_sample = rows_per_sample / rows;
 }
 
-void conv3x3(svg_ctx* ctx, const bf16* x, const ConvW& cw, void* out, int B, int H, int W, int amode, const float* bias_bn,
-             int bias_bn_ld, const bf16* residual, int out_f32, hipStream_t s, GnEmit* emit) {
+void conv3x3(svg_ctx* ctx, const h16* x, const ConvW& cw, void* out, int B, int H, int W, int amode, const float* bias_bn,
+             int bias_bn_ld, const h16* residual, int out_f32, hipStream_t s, GnEmit* emit) {
   // the kernels address an operand with 32-bit byte offsets: an input or output of 2^31 elements or more (the 512 x 512
   // VAE levels beyond ~30 images) is processed in batch chunks
   {
@@ -106,7 +108,7 @@ void conv3x3(svg_ctx* ctx, const bf16* x, const ConvW& cw, void* out, int B, int
       for (int b0 = 0; b0 < B; b0 += chunk) {
         const int nb = std::min(chunk, B - b0);
         const int64_t o = (int64_t)b0 * Ho * Wo * cw.Opad;
-        conv3x3(ctx, x + (int64_t)b0 * H * W * cin, cw, out_f32 ? (void*)((float*)out + o) : (void*)((bf16*)out + o), nb, H, W, amode,
+        conv3x3(ctx, x + (int64_t)b0 * H * W * cin, cw, out_f32 ? (void*)((float*)out + o) : (void*)((h16*)out + o), nb, H, W, amode,
                 bias_bn ? bias_bn + (int64_t)b0 * (bias_bn_ld ? bias_bn_ld : cw.Opad) : nullptr, bias_bn_ld,
                 residual ? residual + o : nullptr, out_f32, s);
       }
@@ -133,9 +135,9 @@ void conv3x3(svg_ctx* ctx, const bf16* x, const ConvW& cw, void* out, int B, int
   gemm_auto(ctx, g, s, PK_CONV3);
 }
 
-void linear(svg_ctx* ctx, const bf16* A, int lda, const PackedLinear& pl, void* C, int ldc, int M, int act, const bf16* residual,
+void linear(svg_ctx* ctx, const h16* A, int lda, const PackedLinear& pl, void* C, int ldc, int M, int act, const h16* residual,
             int ldr, int out_f32, hipStream_t s, const float* ln_rs, const float* ln_rm, GnEmit* emit, int rows_per_sample,
-            const bf16* A2, int lda2, int k_split, LnEmit* ln) {
+            const h16* A2, int lda2, int k_split, LnEmit* ln) {
   if (ln) ln->tiles = 0;
   SVG_CHECK((pl.ln_s != nullptr) == (ln_rs != nullptr), "linear: LayerNorm-folded weights need the row statistics (and only they)");
   {   // 32-bit operand offsets in the kernels: split very tall problems (1 x 1 convs on the 512 x 512 VAE levels) by rows
@@ -157,7 +159,7 @@ void linear(svg_ctx* ctx, const bf16* A, int lda, const PackedLinear& pl, void* 
     ctx->arena.push();
     uint8_t* aq = ctx->arena.get<uint8_t>((int64_t)M * pl.K);
     uint8_t* as = ctx->arena.get<uint8_t>((int64_t)M * (pl.K / 32));
-    quant_mx_bf16(ctx, A, lda, aq, as, M, pl.K, s);
+    quant_mx_h16(ctx, A, lda, aq, as, M, pl.K, s);
     GemmArgs g8;
     g8.M = M; g8.N = pl.N; g8.K = pl.K; g8.bias = pl.b; g8.act = act; g8.residual = residual; g8.ldr = ldr; g8.C = C; g8.ldc = ldc; g8.out_f32 = out_f32;
     gemm_fp8(ctx, aq, as, pl.w8, pl.w8s, g8, s);
@@ -177,3 +179,14 @@ void linear(svg_ctx* ctx, const bf16* A, int lda, const PackedLinear& pl, void* 
   }
   gemm_auto(ctx, g, s, PK_GEMM);
 }
+
+// per-device kernel attributes (dynamic LDS limits) of every kernel instantiation of this namespace
+void sd_init_device() {
+  gemm_init_device();
+  gemm_pp_init_device();
+  conv_halo_init_device();
+  ff_fused_init_device();
+  gemm_fp8_init_device();
+}
+
+}  // namespace SDNS

@@ -1,9 +1,10 @@
 // SD UNet2DConditionModel graph (diffusers 0.2.x layout) and the DDIM img2img loop
 // (utils/sd_utils.py:222-267) on NHWC bf16 activations.
 #include "models.h"
-#include "../../include/svg_hip.h"
 #include <algorithm>
 #include <cstdlib>
+
+namespace SDNS {
 
 void UnetModel::configure(const char* kv) {
   auto m = parse_kv(kv);
@@ -48,8 +49,8 @@ PackedLinear load_stacked(svg_ctx* ctx, WeightStore& ws, const std::vector<std::
   int N = 0;
   for (int n : ns) N += n;
   pl.N = (int)align_up(N, 4); pl.K = K; pl.n_valid = N;
-  pl.w = (bf16*)ctx->dalloc((int64_t)pl.N * K * sizeof(bf16));
-  HIP_OK(hipMemsetAsync(pl.w, 0, (size_t)pl.N * K * sizeof(bf16), s));
+  pl.w = (h16*)ctx->dalloc((int64_t)pl.N * K * sizeof(h16));
+  HIP_OK(hipMemsetAsync(pl.w, 0, (size_t)pl.N * K * sizeof(h16), s));
   if (bias || fold) {
     pl.b = (float*)ctx->dalloc(pl.N * sizeof(float));
     HIP_OK(hipMemsetAsync(pl.b, 0, pl.N * sizeof(float), s));
@@ -66,7 +67,7 @@ PackedLinear load_stacked(svg_ctx* ctx, WeightStore& ws, const std::vector<std::
   }
   if (fold) {
     pl.ln_s = (float*)ctx->dalloc(pl.N * sizeof(float));
-    rowsum_bf16(pl.w, pl.ln_s, pl.N, K, s);
+    rowsum_h16(pl.w, pl.ln_s, pl.N, K, s);
   }
   HIP_OK(hipStreamSynchronize(s));
   for (auto& n : names) ws.release(n + ".weight");
@@ -117,7 +118,7 @@ XfBlockW load_xf(svg_ctx* ctx, WeightStore& ws, const std::string& p, int C, int
     const int F = 4 * C;
     const Weight& w = ws.get(t + ".ff.net.0.proj.weight", {2 * F, C});
     b.ff1.N = 2 * F; b.ff1.K = C; b.ff1.n_valid = 2 * F;
-    b.ff1.w = (bf16*)ctx->dalloc((int64_t)2 * F * C * sizeof(bf16));
+    b.ff1.w = (h16*)ctx->dalloc((int64_t)2 * F * C * sizeof(h16));
     b.ff1.b = (float*)ctx->dalloc(2 * F * sizeof(float));
     float* bias = keep_f32(ctx, ws, t + ".ff.net.0.proj.bias", 2 * F);
     float* btmp = nullptr;
@@ -129,7 +130,7 @@ XfBlockW load_xf(svg_ctx* ctx, WeightStore& ws, const std::string& p, int C, int
     pack_geglu(w.f32, bias, b.ff1.w, b.ff1.b, F, C, s);
     if (fold) {
       b.ff1.ln_s = (float*)ctx->dalloc((size_t)2 * F * sizeof(float));
-      rowsum_bf16(b.ff1.w, b.ff1.ln_s, 2 * F, C, s);
+      rowsum_h16(b.ff1.w, b.ff1.ln_s, 2 * F, C, s);
     }
     HIP_OK(hipStreamSynchronize(s));
     if (btmp) HIP_OK(hipFree(btmp));
@@ -137,7 +138,7 @@ XfBlockW load_xf(svg_ctx* ctx, WeightStore& ws, const std::string& p, int C, int
   }
   if (ff_fused_supported(C, 1 << 30)) {   // k-permuted copy of ff.net.2 for the fused feed-forward
     const Weight& w2 = ws.get(t + ".ff.net.2.weight", {C, 4 * C});
-    b.ff2p = (bf16*)ctx->dalloc((int64_t)C * 4 * C * sizeof(bf16));
+    b.ff2p = (h16*)ctx->dalloc((int64_t)C * 4 * C * sizeof(h16));
     pack_ff2_perm(w2.f32, b.ff2p, C, 4 * C, s);
     HIP_OK(hipStreamSynchronize(s));
   }
@@ -242,7 +243,7 @@ void UnetModel::ddim_coefs(int t, int t_prev, float* sa, float* s1a, float* sap,
 namespace {
 struct UnetRun {
   svg_ctx* ctx; UnetModel* m; hipStream_t s; int N;
-  const bf16* ctxb; int L, Lp;     // context (N*L, ctx_dim) bf16; Lp = L padded to 8
+  const h16* ctxb; int L, Lp;     // context (N*L, ctx_dim) bf16; Lp = L padded to 8
   const float* temb;               // (N, temb_total) f32: every resnet's time_emb_proj(silu(temb))
   int temb_ld;
   KvCache* cache = nullptr;        // cross-attention K / V^T reuse across DDIM steps (constant context)
@@ -250,7 +251,7 @@ struct UnetRun {
 
   // an activation tensor with, when its producer could leave them, the GroupNorm column sums of its row tiles
   struct Act {
-    const bf16* p = nullptr;
+    const h16* p = nullptr;
     int C = 0;
     GnStats st;
   };
@@ -268,27 +269,27 @@ struct UnetRun {
     const int Cx = x.C, Cs = skip ? skip->C : 0, Cin = Cx + Cs;
     Act out;
     out.C = r.c2.Cout;
-    bf16* outp = ctx->arena.get<bf16>(P * r.c2.Opad);
+    h16* outp = ctx->arena.get<h16>(P * r.c2.Opad);
     GnEmit eo = emit_for(HW, r.c2.Opad);
     ctx->arena.push();
     const bool virt = skip && x.st.valid() && skip->st.valid() && Cx % 64 == 0 && r.has_sc;   // virtual concat
-    const bf16* xin = x.p;
+    const h16* xin = x.p;
     if (skip && !virt) {   // torch.cat([hidden, skip], dim=1)
-      bf16* cat = ctx->arena.get<bf16>(P * Cin);
+      h16* cat = ctx->arena.get<h16>(P * Cin);
       if (SVG_LAUNCHING(ctx)) { ProfScope ps(ctx, PK_ELT, s, 0, 4.0 * P * Cin); concat_channels(x.p, Cx, skip->p, Cs, cat, P, s); }
       xin = cat;
     }
-    bf16* t0 = ctx->arena.get<bf16>(P * Cin);
+    h16* t0 = ctx->arena.get<h16>(P * Cin);
     if (virt) groupnorm(ctx, x.p, Cx, skip->p, Cs, r.n1.g, r.n1.b, t0, N, HW, m->groups, 1e-5f, 1, s, &x.st, &skip->st);
     else groupnorm(ctx, xin, Cin, nullptr, 0, r.n1.g, r.n1.b, t0, N, HW, m->groups, 1e-5f, 1, s, skip ? nullptr : &x.st, nullptr);
-    bf16* t1 = ctx->arena.get<bf16>(P * r.c1.Opad);
+    h16* t1 = ctx->arena.get<h16>(P * r.c1.Opad);
     GnEmit e1 = emit_for(HW, r.c1.Opad);
     conv3x3(ctx, t0, r.c1, t1, N, H, W, A_CONV_S1, temb + r.temb_off, temb_ld, nullptr, 0, s, &e1);
-    bf16* t2 = ctx->arena.get<bf16>(P * r.n2.C);
+    h16* t2 = ctx->arena.get<h16>(P * r.n2.C);
     groupnorm(ctx, t1, r.n2.C, nullptr, 0, r.n2.g, r.n2.b, t2, N, HW, m->groups, 1e-5f, 1, s, &e1.st, nullptr);
-    const bf16* res = xin;
+    const h16* res = xin;
     if (r.has_sc) {
-      bf16* sc = ctx->arena.get<bf16>(P * r.sc.N);
+      h16* sc = ctx->arena.get<h16>(P * r.sc.N);
       if (virt) linear(ctx, x.p, Cx, r.sc, sc, r.sc.N, (int)P, ACT_NONE, nullptr, 0, 0, s, nullptr, nullptr, nullptr, 0, skip->p, Cs, Cx);
       else linear(ctx, xin, Cin, r.sc, sc, r.sc.N, (int)P, ACT_NONE, nullptr, 0, 0, s);
       res = sc;
@@ -300,7 +301,7 @@ struct UnetRun {
     return out;
   }
 
-  void attn_core(const bf16* q, int ldq, const bf16* k, int ldk, int64_t kb, const bf16* vt, int ldvt, int64_t vtb, bf16* o,
+  void attn_core(const h16* q, int ldq, const h16* k, int ldk, int64_t kb, const h16* vt, int ldvt, int64_t vtb, h16* o,
                  int C, int Sq, int Skv) {
     AttnArgs a;
     a.q = q; a.k = k; a.vt = vt; a.out = o;
@@ -312,7 +313,7 @@ struct UnetRun {
   }
 
   // V^T[b] (C x SkvPad) = Wv * src_b^T
-  void vt_proj_into(const PackedLinear& wv, const bf16* src, int rows, int rows_pad, int K, bf16* vt,
+  void vt_proj_into(const PackedLinear& wv, const h16* src, int rows, int rows_pad, int K, h16* vt,
                     const float* ln_rs = nullptr, const float* ln_rm = nullptr) {
     const int C = wv.N;
     GemmArgs g;
@@ -326,22 +327,22 @@ struct UnetRun {
     }
     gemm_auto(ctx, g, s, PK_GEMM);
   }
-  bf16* vt_proj(const PackedLinear& wv, const bf16* src, int rows, int rows_pad, int K, const float* ln_rs = nullptr,
+  h16* vt_proj(const PackedLinear& wv, const h16* src, int rows, int rows_pad, int K, const float* ln_rs = nullptr,
                 const float* ln_rm = nullptr) {
-    bf16* vt = ctx->arena.get<bf16>((int64_t)N * wv.N * rows_pad);
+    h16* vt = ctx->arena.get<h16>((int64_t)N * wv.N * rows_pad);
     vt_proj_into(wv, src, rows, rows_pad, K, vt, ln_rs, ln_rm);
     return vt;
   }
 
   Act spatial_transformer(const Act& xa, const XfBlockW& b, int H, int W) {
-    const bf16* x = xa.p;
+    const h16* x = xa.p;
     const int HW = H * W, C = b.C;
     const int64_t P = (int64_t)N * HW;
     const int M = (int)P;
-    bf16* out = ctx->arena.get<bf16>(P * C);
+    h16* out = ctx->arena.get<h16>(P * C);
     GnEmit eo = emit_for(HW, C);
     ctx->arena.push();
-    bf16* h = ctx->arena.get<bf16>(P * C);
+    h16* h = ctx->arena.get<h16>(P * C);
     // LayerNorm row partials: the three LayerNorm inputs of the block (proj_in output, the two attention residual sums) are written by
     // GEMM epilogues that leave per-tile row sums here; ln_finish replaces the statistics pass over the tensor (one buffer: a
     // LayerNorm's partials are consumed before the next producer runs)
@@ -353,7 +354,7 @@ struct UnetRun {
       // is never written: h_b = x_b (W diag(gamma rstd_b))^T + (bias + W (beta - mean_b rstd_b gamma)), one batched GEMM
       ctx->arena.push();
       float* stats = ctx->arena.get<float>((int64_t)N * m->groups * 2);
-      bf16* wb = ctx->arena.get<bf16>((int64_t)N * C * C);
+      h16* wb = ctx->arena.get<h16>((int64_t)N * C * C);
       float* bb = ctx->arena.get<float>((int64_t)N * C);
       gn_finish(ctx, xa.st, C, nullptr, 0, stats, N, HW, m->groups, 1e-6f, s);
       if (SVG_LAUNCHING(ctx)) {
@@ -373,16 +374,16 @@ struct UnetRun {
       gemm_auto(ctx, g, s, PK_GEMM);
       ctx->arena.pop();
     } else {
-      bf16* n0 = ctx->arena.get<bf16>(P * C);
+      h16* n0 = ctx->arena.get<h16>(P * C);
       groupnorm(ctx, x, C, nullptr, 0, b.gn.g, b.gn.b, n0, N, HW, m->groups, 1e-6f, 0, s, &xa.st, nullptr);
       linear(ctx, n0, C, b.proj_in, h, C, M, ACT_NONE, nullptr, 0, 0, s, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, &le);
     }
     // LayerNorms: folded into the consuming projections (row statistics only) unless SVG_LN_FOLD=0
     const bool fold = b.qk1.ln_s != nullptr;
-    bf16* ln = fold ? nullptr : ctx->arena.get<bf16>(P * C);
+    h16* ln = fold ? nullptr : ctx->arena.get<h16>(P * C);
     float* rs = fold ? ctx->arena.get<float>(M + 8) : nullptr;
     float* rm = fold ? ctx->arena.get<float>(M + 8) : nullptr;
-    auto norm = [&](const bf16* src, const NormW& n) -> const bf16* {
+    auto norm = [&](const h16* src, const NormW& n) -> const h16* {
       if (fold) {
         if (le.tiles > 0) ln_finish(ctx, le.buf, le.tiles, rs, rm, M, C, 1e-5f, s);   // src's producer left its row partials
         else ln_stats(ctx, src, rs, rm, M, C, 1e-5f, s);
@@ -392,37 +393,37 @@ struct UnetRun {
       layernorm(ctx, src, n.g, n.b, ln, M, C, 1e-5f, s);
       return ln;
     };
-    bf16* ao = ctx->arena.get<bf16>(P * C);
+    h16* ao = ctx->arena.get<h16>(P * C);
     // ---- self-attention
-    const bf16* a1 = norm(h, b.ln1);
+    const h16* a1 = norm(h, b.ln1);
     {
       ctx->arena.push();
       const int HWp = (int)align_up(HW, 8);
-      bf16* qk = ctx->arena.get<bf16>(P * 2 * C);
+      h16* qk = ctx->arena.get<h16>(P * 2 * C);
       linear(ctx, a1, C, b.qk1, qk, 2 * C, M, ACT_NONE, nullptr, 0, 0, s, rs, rm);
-      bf16* vt = vt_proj(b.v1, a1, HW, HWp, C, rs, rm);
+      h16* vt = vt_proj(b.v1, a1, HW, HWp, C, rs, rm);
       attn_core(qk, 2 * C, qk + C, 2 * C, (int64_t)HW * 2 * C, vt, HWp, (int64_t)C * HWp, ao, C, HW, HW);
       ctx->arena.pop();
     }
-    bf16* h1 = ctx->arena.get<bf16>(P * C);
+    h16* h1 = ctx->arena.get<h16>(P * C);
     linear(ctx, ao, C, b.o1, h1, C, M, ACT_NONE, h, C, 0, s, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, &le);
     // ---- cross-attention
-    const bf16* a2 = norm(h1, b.ln2);
+    const h16* a2 = norm(h1, b.ln2);
     {
       ctx->arena.push();
-      bf16* q = ctx->arena.get<bf16>(P * C);
+      h16* q = ctx->arena.get<h16>(P * C);
       linear(ctx, a2, C, b.q2, q, C, M, ACT_NONE, nullptr, 0, 0, s, rs, rm);
       const int idx = xf_idx++;
       const int64_t kn = (int64_t)N * L * C, vn = (int64_t)N * C * Lp;
-      bf16 *k, *vt;
+      h16 *k, *vt;
       if (cache && SVG_LAUNCHING(ctx)) {
         if ((int)cache->k.size() <= idx) { cache->k.resize(idx + 1, nullptr); cache->vt.resize(idx + 1, nullptr); cache->k_cap.resize(idx + 1, 0); cache->vt_cap.resize(idx + 1, 0); }
-        if (cache->k_cap[idx] < kn) { cache->k[idx] = (bf16*)ctx->dalloc(kn * sizeof(bf16)); cache->k_cap[idx] = kn; cache->valid = false; }
-        if (cache->vt_cap[idx] < vn) { cache->vt[idx] = (bf16*)ctx->dalloc(vn * sizeof(bf16)); cache->vt_cap[idx] = vn; cache->valid = false; }
+        if (cache->k_cap[idx] < kn) { cache->k[idx] = (h16*)ctx->dalloc(kn * sizeof(h16)); cache->k_cap[idx] = kn; cache->valid = false; }
+        if (cache->vt_cap[idx] < vn) { cache->vt[idx] = (h16*)ctx->dalloc(vn * sizeof(h16)); cache->vt_cap[idx] = vn; cache->valid = false; }
         k = cache->k[idx]; vt = cache->vt[idx];
       } else {
-        k = ctx->arena.get<bf16>(kn);
-        vt = ctx->arena.get<bf16>(vn);
+        k = ctx->arena.get<h16>(kn);
+        vt = ctx->arena.get<h16>(vn);
       }
       if (!(cache && cache->valid && SVG_LAUNCHING(ctx))) {
         linear(ctx, ctxb, m->ctx_dim, b.k2, k, C, N * L, ACT_NONE, nullptr, 0, 0, s);
@@ -431,11 +432,11 @@ struct UnetRun {
       attn_core(q, C, k, C, (int64_t)L * C, vt, Lp, (int64_t)C * Lp, ao, C, HW, L);
       ctx->arena.pop();
     }
-    bf16* h2 = ctx->arena.get<bf16>(P * C);
+    h16* h2 = ctx->arena.get<h16>(P * C);
     linear(ctx, ao, C, b.o2, h2, C, M, ACT_NONE, h1, C, 0, s, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, &le);
     // ---- GEGLU feed-forward
     const bool ff_one = fold && b.ff2p && ff_fused_supported(C, M);
-    const bf16* a3 = ff_one ? h2 : norm(h2, b.ln3);     // the fused feed-forward takes its LayerNorm statistics from the rows it holds
+    const h16* a3 = ff_one ? h2 : norm(h2, b.ln3);     // the fused feed-forward takes its LayerNorm statistics from the rows it holds
     {
       // The GEGLU intermediate is M x 4C (293 MB at 28 clips x 64 x 64 x 1280): written by ff1 and read back by ff2.  Run
       // the pair over row chunks whose intermediate fits the 256 MiB Infinity Cache (with the other stream group's share):
@@ -446,7 +447,7 @@ struct UnetRun {
       } else {
       ctx->arena.push();
       const int rows = ff_chunk_rows(M, C);
-      bf16* g = ctx->arena.get<bf16>((int64_t)std::min(rows, M) * 4 * C);
+      h16* g = ctx->arena.get<h16>((int64_t)std::min(rows, M) * 4 * C);
       for (int m0 = 0; m0 < M; m0 += rows) {
         const int mc = std::min(rows, M - m0);
         linear(ctx, a3 + (int64_t)m0 * C, C, b.ff1, g, 4 * C, mc, ACT_GEGLU, nullptr, 0, 0, s, rs ? rs + m0 : nullptr, rm ? rm + m0 : nullptr);
@@ -465,7 +466,12 @@ struct UnetRun {
 }  // namespace
 
 void UnetModel::forward(svg_ctx* ctx, const float* x, int N, int h, int w, const float* timesteps, const float* ctx_emb,
-                        int ctx_len, float* eps_out, hipStream_t s, KvCache* cache) {
+                        int ctx_len, float* eps_out, hipStream_t s) {
+  run_planned(ctx, [&]() { run(ctx, x, N, h, w, timesteps, ctx_emb, ctx_len, eps_out, s); });
+}
+
+void UnetModel::run(svg_ctx* ctx, const float* x, int N, int h, int w, const float* timesteps, const float* ctx_emb,
+                    int ctx_len, float* eps_out, hipStream_t s, KvCache* cache) {
   SVG_CHECK(ready, "unet: svg_finalize has not been called");
   const int nb = (int)block_out.size();
   const int down = 1 << (nb - 1);
@@ -476,15 +482,15 @@ void UnetModel::forward(svg_ctx* ctx, const float* x, int N, int h, int w, const
   r.cache = cache;
   r.L = ctx_len; r.Lp = (int)align_up(ctx_len, 8);
   // context -> bf16
-  bf16* cb = ctx->arena.get<bf16>((int64_t)N * ctx_len * ctx_dim);
-  if (SVG_LAUNCHING(ctx)) { ProfScope ps(ctx, PK_ELT, s, 0, 0); f32_to_bf16(ctx_emb, cb, (int64_t)N * ctx_len * ctx_dim, s); }
+  h16* cb = ctx->arena.get<h16>((int64_t)N * ctx_len * ctx_dim);
+  if (SVG_LAUNCHING(ctx)) { ProfScope ps(ctx, PK_ELT, s, 0, 0); f32_to_h16(ctx_emb, cb, (int64_t)N * ctx_len * ctx_dim, s); }
   r.ctxb = cb;
   // time embedding: sinusoid -> linear_1 -> SiLU -> linear_2 ; every resnet applies time_emb_proj(SiLU(temb))
-  bf16* te0 = ctx->arena.get<bf16>((int64_t)N * c0);
+  h16* te0 = ctx->arena.get<h16>((int64_t)N * c0);
   if (SVG_LAUNCHING(ctx)) { ProfScope ps(ctx, PK_ELT, s, 0, 0); timestep_embed(timesteps, te0, N, c0, s); }
-  bf16* te1 = ctx->arena.get<bf16>((int64_t)N * temb_dim);
+  h16* te1 = ctx->arena.get<h16>((int64_t)N * temb_dim);
   linear(ctx, te0, c0, time1, te1, temb_dim, N, ACT_SILU, nullptr, 0, 0, s);
-  bf16* te2 = ctx->arena.get<bf16>((int64_t)N * temb_dim);
+  h16* te2 = ctx->arena.get<h16>((int64_t)N * temb_dim);
   linear(ctx, te1, temb_dim, time2, te2, temb_dim, N, ACT_SILU, nullptr, 0, 0, s);   // SiLU(temb), shared by all resnets
   float* tall = ctx->arena.get<float>((int64_t)N * temb_all.N);
   linear(ctx, te2, temb_dim, temb_all, tall, temb_all.N, N, ACT_NONE, nullptr, 0, 1, s);
@@ -492,12 +498,12 @@ void UnetModel::forward(svg_ctx* ctx, const float* x, int N, int h, int w, const
 
   // ---- conv_in
   typedef UnetRun::Act Act;
-  bf16* x0 = ctx->arena.get<bf16>((int64_t)N * h * w * 8);
+  h16* x0 = ctx->arena.get<h16>((int64_t)N * h * w * 8);
   if (SVG_LAUNCHING(ctx)) { ProfScope ps(ctx, PK_ELT, s, 0, 0); nchw_to_act(x, x0, N, in_ch, h, w, 8, 1.f, s); }
   int H = h, W = w;
   Act cur;
   {
-    bf16* y = ctx->arena.get<bf16>((int64_t)N * H * W * conv_in.Opad);
+    h16* y = ctx->arena.get<h16>((int64_t)N * H * W * conv_in.Opad);
     GnEmit e = r.emit_for((int64_t)H * W, conv_in.Opad);
     conv3x3(ctx, x0, conv_in, y, N, H, W, A_CONV_S1, nullptr, 0, nullptr, 0, s, &e);
     cur.p = y; cur.C = c0; cur.st = e.st;
@@ -511,7 +517,7 @@ void UnetModel::forward(svg_ctx* ctx, const float* x, int N, int h, int w, const
       skips.push_back(cur);
     }
     if (i < nb - 1) {
-      bf16* y = ctx->arena.get<bf16>((int64_t)N * (H / 2) * (W / 2) * down_s[i].Opad);
+      h16* y = ctx->arena.get<h16>((int64_t)N * (H / 2) * (W / 2) * down_s[i].Opad);
       GnEmit e = r.emit_for((int64_t)(H / 2) * (W / 2), down_s[i].Opad);
       conv3x3(ctx, cur.p, down_s[i], y, N, H, W, A_CONV_S2P1, nullptr, 0, nullptr, 0, s, &e);
       cur.p = y; cur.st = e.st; H /= 2; W /= 2;
@@ -531,14 +537,14 @@ void UnetModel::forward(svg_ctx* ctx, const float* x, int N, int h, int w, const
       if (attn[bi]) cur = r.spatial_transformer(cur, up_attn[i][j], H, W);
     }
     if (i < nb - 1) {
-      bf16* y = ctx->arena.get<bf16>((int64_t)N * (2 * H) * (2 * W) * up_s[i].Opad);
+      h16* y = ctx->arena.get<h16>((int64_t)N * (2 * H) * (2 * W) * up_s[i].Opad);
       GnEmit e = r.emit_for((int64_t)4 * H * W, up_s[i].Opad);
       conv3x3(ctx, cur.p, up_s[i], y, N, H, W, A_CONV_UP2, nullptr, 0, nullptr, 0, s, &e);
       cur.p = y; cur.st = e.st; H *= 2; W *= 2;
     }
   }
   // ---- out
-  bf16* t = ctx->arena.get<bf16>((int64_t)N * H * W * c0);
+  h16* t = ctx->arena.get<h16>((int64_t)N * H * W * c0);
   groupnorm(ctx, cur.p, c0, nullptr, 0, norm_out.g, norm_out.b, t, N, H * W, groups, 1e-5f, 1, s, &cur.st, nullptr);
   float* o = ctx->arena.get<float>((int64_t)N * H * W * conv_out.Opad);
   conv3x3(ctx, t, conv_out, o, N, H, W, A_CONV_S1, nullptr, 0, nullptr, 1, s);
@@ -584,7 +590,7 @@ void UnetModel::ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const flo
       // guidance == 0: noise_pred = uncond + 0*(text - uncond) == uncond — only the uncond half is needed
       std::unique_ptr<ProfScope> step_scope;
       if (SVG_LAUNCHING(ctx)) step_scope.reset(new ProfScope(ctx, PK_UNET_STEP, s, 0, 0));
-      forward(ctx, cfg ? zin : z, NB, h, w, tvec, text_emb, ctx_len, eps, s, &kv);
+      run(ctx, cfg ? zin : z, NB, h, w, tvec, text_emb, ctx_len, eps, s, &kv);
       if (SVG_LAUNCHING(ctx)) {
         float sa, s1a, sap, s1ap;
         ddim_coefs(t, t - ratio, &sa, &s1a, &sap, &s1ap);
@@ -601,30 +607,10 @@ void UnetModel::ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const flo
   run_planned(ctx, body);
 }
 
-extern "C" {
-int svg_unet_forward(svg_ctx* ctx, const float* x, int N, int h, int w, const float* timesteps, const float* ctx_emb, int ctx_len,
-                     float* eps_out, void* stream) {
-  try {
-    SVG_CHECK(ctx && ctx->unet, "unet: model not configured");
-    run_planned(ctx, [&]() { ctx->unet->forward(ctx, x, N, h, w, timesteps, ctx_emb, ctx_len, eps_out, (hipStream_t)stream); });
-    return 0;
-  } catch (const std::exception& e) { return svg_fail(ctx, e); }
-}
-int svg_ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const float* text_emb, int ctx_len, int num_steps, int start_step,
-                  float guidance, const float* noise, float* hist, void* stream) {
-  try {
-    SVG_CHECK(ctx && ctx->unet, "unet: model not configured");
-    ctx->unet->ddim_loop(ctx, z, N, h, w, text_emb, ctx_len, num_steps, start_step, guidance, noise, hist, (hipStream_t)stream);
-    return 0;
-  } catch (const std::exception& e) { return svg_fail(ctx, e); }
-}
-int svg_ddim_step(svg_ctx* ctx, const float* x, const float* eps, float* prev, int64_t n, int t, int t_prev, void* stream) {
-  try {
-    SVG_CHECK(ctx && ctx->unet && ctx->unet->ready, "unet: model not finalized");
-    float sa, s1a, sap, s1ap;
-    ctx->unet->ddim_coefs(t, t_prev, &sa, &s1a, &sap, &s1ap);
-    ddim_step(x, eps, nullptr, 0.f, prev, n, sa, s1a, sap, s1ap, (hipStream_t)stream);
-    return 0;
-  } catch (const std::exception& e) { return svg_fail(ctx, e); }
-}
-}
+}  // namespace SDNS
+
+#if SD_F16
+UnetIface* new_unet_f16() { return new sd_f16::UnetModel(); }
+#else
+UnetIface* new_unet_bf16() { return new sd_bf16::UnetModel(); }
+#endif

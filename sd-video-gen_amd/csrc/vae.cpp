@@ -1,7 +1,8 @@
 // SD AutoencoderKL graph (diffusers 0.2.x layout) on NHWC bf16 activations.
 // Reference call sites: utils/sd_utils.py:128-145 (encode_img) and :156-169 (decode_img_latents).
 #include "models.h"
-#include "../../include/svg_hip.h"
+
+namespace SDNS {
 
 void VaeModel::configure(const char* kv) {
   auto m = parse_kv(kv);
@@ -32,7 +33,7 @@ static VaeAttnW load_vae_attn(svg_ctx* ctx, WeightStore& ws, const std::string& 
     const Weight& wq = ws.get(p + ".query.weight", {C, C});
     const Weight& wk = ws.get(p + ".key.weight", {C, C});
     a.qk.N = 2 * C; a.qk.K = C; a.qk.n_valid = 2 * C;
-    a.qk.w = (bf16*)ctx->dalloc((int64_t)2 * C * C * sizeof(bf16));
+    a.qk.w = (h16*)ctx->dalloc((int64_t)2 * C * C * sizeof(h16));
     pack_linear(wq.f32, a.qk.w, C, C, C, s);
     pack_linear(wk.f32, a.qk.w + (int64_t)C * C, C, C, C, s);
     a.qk.b = (float*)ctx->dalloc(2 * C * sizeof(float));
@@ -103,7 +104,7 @@ struct VaeRun {
 
   // an activation tensor with, when its producer's epilogue left them, the GroupNorm column sums of its row tiles
   struct Act {
-    bf16* p = nullptr;
+    h16* p = nullptr;
     GnStats st;
   };
   GnEmit emit_for(int64_t hw, int Cout) {
@@ -111,10 +112,10 @@ struct VaeRun {
     if (hw >= 1024) e.buf = ctx->arena.get<float>(gn_part_floats(N, hw, Cout));
     return e;
   }
-  Act conv(const bf16* x, const ConvW& cw, int H, int W, int amode) {
+  Act conv(const h16* x, const ConvW& cw, int H, int W, int amode) {
     const int Ho = amode == A_CONV_UP2 ? 2 * H : (amode == A_CONV_S2ASYM ? H / 2 : H), Wo = amode == A_CONV_UP2 ? 2 * W : (amode == A_CONV_S2ASYM ? W / 2 : W);
     Act y;
-    y.p = ctx->arena.get<bf16>((int64_t)N * Ho * Wo * cw.Opad);
+    y.p = ctx->arena.get<h16>((int64_t)N * Ho * Wo * cw.Opad);
     GnEmit e = emit_for((int64_t)Ho * Wo, cw.Opad);
     conv3x3(ctx, x, cw, y.p, N, H, W, amode, nullptr, 0, nullptr, 0, s, &e);
     y.st = e.st;
@@ -125,19 +126,19 @@ struct VaeRun {
   Act resnet(const Act& x, const ResW& r, int H, int W) {
     const int64_t P = (int64_t)N * H * W;
     Act out;
-    out.p = ctx->arena.get<bf16>(P * r.c2.Opad);
+    out.p = ctx->arena.get<h16>(P * r.c2.Opad);
     GnEmit eo = emit_for((int64_t)H * W, r.c2.Opad);
     ctx->arena.push();
-    bf16* t0 = ctx->arena.get<bf16>(P * r.n1.C);
+    h16* t0 = ctx->arena.get<h16>(P * r.n1.C);
     groupnorm(ctx, x.p, r.n1.C, nullptr, 0, r.n1.g, r.n1.b, t0, N, H * W, m->groups, EPS, 1, s, &x.st, nullptr);
-    bf16* t1 = ctx->arena.get<bf16>(P * r.c1.Opad);
+    h16* t1 = ctx->arena.get<h16>(P * r.c1.Opad);
     GnEmit e1 = emit_for((int64_t)H * W, r.c1.Opad);
     conv3x3(ctx, t0, r.c1, t1, N, H, W, A_CONV_S1, nullptr, 0, nullptr, 0, s, &e1);
-    bf16* t2 = ctx->arena.get<bf16>(P * r.n2.C);
+    h16* t2 = ctx->arena.get<h16>(P * r.n2.C);
     groupnorm(ctx, t1, r.n2.C, nullptr, 0, r.n2.g, r.n2.b, t2, N, H * W, m->groups, EPS, 1, s, &e1.st, nullptr);
-    const bf16* res = x.p;
+    const h16* res = x.p;
     if (r.has_sc) {
-      bf16* sc = ctx->arena.get<bf16>(P * r.sc.N);
+      h16* sc = ctx->arena.get<h16>(P * r.sc.N);
       linear(ctx, x.p, r.n1.C, r.sc, sc, r.sc.N, (int)P, ACT_NONE, nullptr, 0, 0, s);
       res = sc;
     }
@@ -149,19 +150,19 @@ struct VaeRun {
 
   // single-head attention over HW tokens, unfused (d = C = 512): S and P go through HBM
   Act attn(const Act& xa, const VaeAttnW& a, int H, int W) {
-    const bf16* x = xa.p;
+    const h16* x = xa.p;
     const int HW = H * W, C = a.C;
     const int64_t P = (int64_t)N * HW;
     const int HWp = (int)align_up(HW, 8);
-    bf16* out = ctx->arena.get<bf16>(P * C);
+    h16* out = ctx->arena.get<h16>(P * C);
     GnEmit eo = emit_for(HW, C);
     ctx->arena.push();
-    bf16* n = ctx->arena.get<bf16>(P * C);
+    h16* n = ctx->arena.get<h16>(P * C);
     groupnorm(ctx, x, C, nullptr, 0, a.gn.g, a.gn.b, n, N, HW, m->groups, EPS, 0, s, &xa.st, nullptr);
-    bf16* qk = ctx->arena.get<bf16>(P * 2 * C);
+    h16* qk = ctx->arena.get<h16>(P * 2 * C);
     linear(ctx, n, C, a.qk, qk, 2 * C, (int)P, ACT_NONE, nullptr, 0, 0, s);
     // V^T[b] = Wv * n_b^T + bv (per row)
-    bf16* vt = ctx->arena.get<bf16>((int64_t)N * C * HWp);
+    h16* vt = ctx->arena.get<h16>((int64_t)N * C * HWp);
     {
       GemmArgs g;
       g.A = a.v.w; g.lda = C; g.Wt = n; g.ldb = C; g.M = C; g.N = HWp; g.n_valid = HW; g.K = C;
@@ -177,9 +178,9 @@ struct VaeRun {
       g.C = S; g.ldc = HWp; g.out_f32 = 1;
       gemm_auto(ctx, g, s, PK_GEMM);
     }
-    bf16* Pm = ctx->arena.get<bf16>((int64_t)N * HW * HWp);
+    h16* Pm = ctx->arena.get<h16>((int64_t)N * HW * HWp);
     softmax_rows(ctx, S, Pm, (int64_t)N * HW, HW, HWp, HWp, 1.f / sqrtf((float)C), s);
-    bf16* o = ctx->arena.get<bf16>(P * C);
+    h16* o = ctx->arena.get<h16>(P * C);
     {
       GemmArgs g;
       g.A = Pm; g.lda = HWp; g.Wt = vt; g.ldb = HWp; g.M = HW; g.N = C; g.n_valid = C; g.K = HWp;
@@ -194,8 +195,8 @@ struct VaeRun {
     return y;
   }
 
-  bf16* norm_act(const Act& x, const NormW& nw, int H, int W) {
-    bf16* t = ctx->arena.get<bf16>((int64_t)N * H * W * nw.C);
+  h16* norm_act(const Act& x, const NormW& nw, int H, int W) {
+    h16* t = ctx->arena.get<h16>((int64_t)N * H * W * nw.C);
     groupnorm(ctx, x.p, nw.C, nullptr, 0, nw.g, nw.b, t, N, H * W, m->groups, EPS, 1, s, &x.st, nullptr);
     return t;
   }
@@ -210,7 +211,7 @@ void VaeModel::encode(svg_ctx* ctx, const uint8_t* img, int N, int srcH, int src
   SVG_CHECK(N >= 1 && H % down == 0 && W % down == 0 && H >= down && W >= down, "vae encode: bad size %dx%d (batch %d)", H, W, N);
   run_planned(ctx, [&]() {
     VaeRun r{ctx, this, s, N};
-    bf16* x0 = ctx->arena.get<bf16>((int64_t)N * H * W * 8);
+    h16* x0 = ctx->arena.get<h16>((int64_t)N * H * W * 8);
     if (SVG_LAUNCHING(ctx)) { ProfScope ps(ctx, PK_ELT, s, 0, 0); img_to_act(img, x0, N, srcH, srcW, H, W, s); }
     int h = H, w = W;
     VaeRun::Act x = r.conv(x0, e_conv_in, h, w, A_CONV_S1);
@@ -224,7 +225,7 @@ void VaeModel::encode(svg_ctx* ctx, const uint8_t* img, int N, int srcH, int src
     x = r.resnet(x, e_mid0, h, w);
     x = r.attn(x, e_attn, h, w);
     x = r.resnet(x, e_mid1, h, w);
-    bf16* t = r.norm_act(x, e_norm_out, h, w);
+    h16* t = r.norm_act(x, e_norm_out, h, w);
     const int64_t P = (int64_t)N * h * w;
     float* mom0 = ctx->arena.get<float>(P * 8);
     conv3x3(ctx, t, e_conv_out, mom0, N, h, w, A_CONV_S1, nullptr, 0, nullptr, 1, s);
@@ -248,12 +249,12 @@ void VaeModel::decode(svg_ctx* ctx, const float* z, int N, int h, int w, uint8_t
     // sd_utils.py:159: latents / 0.18215, then post_quant_conv (1x1, 4->4) in f32
     float* zl = ctx->arena.get<float>(P0 * 4);
     float* zq = ctx->arena.get<float>(P0 * 4);
-    bf16* x0 = ctx->arena.get<bf16>(P0 * 8);
+    h16* x0 = ctx->arena.get<h16>(P0 * 8);
     if (SVG_LAUNCHING(ctx)) {
       ProfScope ps(ctx, PK_ELT, s, 0, 0);
       nchw_to_actf32(z, zl, N, 4, h, w, 1.f / 0.18215f, s);
       pixel_linear_f32(zl, 4, pquant_w, pquant_b, zq, 4, P0, 4, 4, s);
-      actf32_pad_bf16(zq, 4, x0, 8, P0, s);
+      actf32_pad_h16(zq, 4, x0, 8, P0, s);
     }
     int H = h, W = w;
     VaeRun::Act x = r.conv(x0, d_conv_in, H, W, A_CONV_S1);
@@ -267,7 +268,7 @@ void VaeModel::decode(svg_ctx* ctx, const float* z, int N, int h, int w, uint8_t
         H *= 2; W *= 2;
       }
     }
-    bf16* t = r.norm_act(x, d_norm_out, H, W);
+    h16* t = r.norm_act(x, d_norm_out, H, W);
     float* o = ctx->arena.get<float>((int64_t)N * H * W * 4);
     conv3x3(ctx, t, d_conv_out, o, N, H, W, A_CONV_S1, nullptr, 0, nullptr, 1, s);
     if (SVG_LAUNCHING(ctx)) {
@@ -277,21 +278,10 @@ void VaeModel::decode(svg_ctx* ctx, const float* z, int N, int h, int w, uint8_t
   });
 }
 
-extern "C" {
-int svg_vae_encode(svg_ctx* ctx, const uint8_t* img, int N, int srcH, int srcW, int H, int W, const float* eps, float* z_out,
-                   float* moments_out, void* stream) {
-  try {
-    SVG_CHECK(ctx && ctx->vae, "vae: model not configured");
-    ctx->vae->encode(ctx, img, N, srcH, srcW, H, W, eps, z_out, moments_out, (hipStream_t)stream);
-    return 0;
-  } catch (const std::exception& e) { return svg_fail(ctx, e); }
-}
-int svg_vae_decode(svg_ctx* ctx, const float* z, int N, int h, int w, uint8_t* img_out, int outH, int outW, float* float_out,
-                   void* stream) {
-  try {
-    SVG_CHECK(ctx && ctx->vae, "vae: model not configured");
-    ctx->vae->decode(ctx, z, N, h, w, img_out, outH, outW, float_out, (hipStream_t)stream);
-    return 0;
-  } catch (const std::exception& e) { return svg_fail(ctx, e); }
-}
-}
+}  // namespace SDNS
+
+#if SD_F16
+VaeIface* new_vae_f16() { return new sd_f16::VaeModel(); }
+#else
+VaeIface* new_vae_bf16() { return new sd_bf16::VaeModel(); }
+#endif

@@ -299,7 +299,7 @@ void loss_pass(svg_ctx* ctx, XfModel* m, const svg_train_cfg& cfg, const float* 
       r.mha_bwd(t.sa, dzd, dx0, dz, nullptr, false);
       dxt = dx0;
     }
-    if (!dmem_set && r.go()) fill_f32(dmem, (int64_t)Ms * d, 0.f, s);
+    if (!dmem_set && r.go()) SDNS::fill_f32(dmem, (int64_t)Ms * d, 0.f, s);
     float* dxs = r.add_ln_bwd(n_enc, dmem, nullptr);
     for (int i = m->enc_layers - 1; i >= 0; --i) {
       EncTape& t = enc[i];

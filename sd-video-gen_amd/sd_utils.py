@@ -232,7 +232,7 @@ class LMSDiscreteScheduler:
 
 
 class SDUtils():
-    def __init__(self, weights=None, text_embeddings=None, seed=0, verbose=True, arch=None, ctx=None, fp8=None):
+    def __init__(self, weights=None, text_embeddings=None, seed=0, verbose=True, arch=None, ctx=None, fp8=None, dtype=None):
         self.config, self.args = parse_config_args()             # sd_utils.py:22
         self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
         if self.device.type != "cuda":
@@ -249,6 +249,11 @@ class SDUtils():
         self._text_embeddings = text_embeddings
         # BASELINE configs[4]: MX block-scaled fp8 for the qualifying dense projections of the UNet (svg_hip.h, key fp8)
         self.fp8 = bool(int(os.environ.get("SVG_UNET_FP8", "0"))) if fp8 is None else bool(fp8)
+        # storage type of the SD networks: 'fp16' is what the reference's autocast executes in the UNet loop (sd_utils.py:246);
+        # 'bf16' (default, BASELINE configs[1]) has 3 fewer mantissa bits and a stated, looser tolerance
+        self.dtype = (dtype or os.environ.get("SVG_SD_DTYPE", "bf16")).lower().replace("float16", "fp16").replace("half", "fp16")
+        if self.dtype not in ("bf16", "fp16"):
+            raise ValueError("SDUtils dtype must be 'bf16' or 'fp16', got %r" % (self.dtype,))
         # `arch` overrides the SD v1.4 widths (reduced-size parity tests): {'vae': {...}, 'unet': {...}}
         # (a local diffusers directory's config.json plays the same role, as it does for from_pretrained)
         local = os.environ.get("SVG_SD_WEIGHTS")
@@ -298,7 +303,8 @@ class SDUtils():
         ctx = self.ctx
         va = self.vae_arch
         sd, self.vae_source = self._weights_for("vae", weights, lambda: sd_layout.vae_shapes(va), self._seed + 1)
-        ctx.configure(_lib.SVG_VAE, block_out=list(va["block_out"]), layers=va["layers"], groups=va["groups"], latent=4)
+        ctx.configure(_lib.SVG_VAE, block_out=list(va["block_out"]), layers=va["layers"], groups=va["groups"], latent=4,
+                      f16=int(self.dtype == "fp16"))
         ctx.load_state_dict(_lib.SVG_VAE, sd)
         vae = _VAE(ctx, ctx.finalize(_lib.SVG_VAE))
         del sd
@@ -312,7 +318,8 @@ class SDUtils():
         c = self.unet_arch
         sd, self.unet_source = self._weights_for("unet", weights, lambda: sd_layout.unet_shapes(c), self._seed + 2)
         ctx.configure(_lib.SVG_UNET, block_out=list(c["block_out"]), layers=c["layers"], heads=c["heads"], ctx_dim=c["ctx_dim"],
-                      groups=c["groups"], in_ch=4, out_ch=4, attn=list(c["attn"]), fp8=int(self.fp8))
+                      groups=c["groups"], in_ch=4, out_ch=4, attn=list(c["attn"]), fp8=int(self.fp8),
+                      f16=int(self.dtype == "fp16"))
         ctx.load_state_dict(_lib.SVG_UNET, sd)
         unet = _UNet(ctx, ctx.finalize(_lib.SVG_UNET))
         del sd
