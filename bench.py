@@ -42,8 +42,10 @@ def parse():
     p.add_argument("--start_step", type=int, default=0)
     p.add_argument("--config", type=str, default="1_16_kitti_L1_64")
     p.add_argument("--no-denoise", action="store_true")
-    p.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16",
-                   help="fp8 = BASELINE configs[4]: qualifying dense projections of the UNet in MX block-scaled fp8 (the rest stays bf16)")
+    p.add_argument("--dtype", choices=["bf16", "fp16", "fp8"], default=os.environ.get("SVG_BENCH_DTYPE", "bf16"),
+                   help="storage type of the SD networks (f32 accumulation): bf16 (BASELINE configs[1]), fp16 (the reference's autocast "
+                        "arithmetic, sd_utils.py:246; tighter parity), fp8 = BASELINE configs[4]: qualifying dense projections of the UNet in MX "
+                        "block-scaled fp8 (the rest stays bf16)")
     p.add_argument("--train", action="store_true",
                    help="SURVEY 8(f1): optimisation steps of the latent Transformer (trainers/trainer.py:141-165) instead of the sampling loop; "
                         "one step = forward in train mode + criterion + backward + Adam on the config's own batch")
@@ -375,6 +377,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus, "process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus)
 
     from sd_video_gen_amd import config as svg_config, sharding
     from sd_video_gen_amd import _lib
@@ -392,7 +395,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.manual_seed(0)
     fp8 = args.dtype == "fp8"
-    sd_utils = SDUtils(weights="synthetic", seed=0, verbose=(rank == 0), fp8=fp8)
+    sd_dtype = "fp16" if args.dtype == "fp16" else "bf16"
+    sd_utils = SDUtils(weights="synthetic", seed=0, verbose=(rank == 0), fp8=fp8, dtype=sd_dtype)
     torch.manual_seed(0)
     model = Transformer(num_tokens=0, dim_model=cfg.DIM_MODEL[0], num_heads=cfg.NUM_HEADS[0],
                         num_encoder_layers=cfg.NUM_ENCODER_LAYERS[0], num_decoder_layers=cfg.NUM_DECODER_LAYERS[0],
@@ -409,7 +413,7 @@ def main():
     for _ in range(1, args.streams):
         c2 = _lib.Context(local_rank)
         torch.manual_seed(0)
-        sdu2 = SDUtils(weights="synthetic", seed=0, verbose=False, ctx=c2, fp8=fp8)
+        sdu2 = SDUtils(weights="synthetic", seed=0, verbose=False, ctx=c2, fp8=fp8, dtype=sd_dtype)
         torch.manual_seed(0)
         m2 = Transformer(num_tokens=0, dim_model=cfg.DIM_MODEL[0], num_heads=cfg.NUM_HEADS[0],
                          num_encoder_layers=cfg.NUM_ENCODER_LAYERS[0], num_decoder_layers=cfg.NUM_DECODER_LAYERS[0],
@@ -453,7 +457,8 @@ def main():
     line = {"metric": metric, "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("fp8 (MX e4m3 projections) + bf16" if fp8 else "bf16") if denoise else "f32", "data": "synthetic",
+            "dtype": ("fp8 (MX e4m3 projections) + bf16" if fp8 else sd_dtype) if denoise else "f32", "data": "synthetic",
+            "ranks_seen": (dist.get_world_size() if world > 1 else 1),
             "config": {"workload": "configs[2]: %s F=%d, --denoise --denoise_start_step %d (%d DDIM steps of the SD-v1.4 UNet at 64x64 latents, "
                                    "VAE enc/dec at 512x512), guidance_scale 0" % (args.config, F, args.start_step, 50 - args.start_step)
                        if denoise else "%s F=%d no --denoise (latent Transformer only)" % (args.config, F),
@@ -467,6 +472,7 @@ def main():
     if rank == 0:
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()            # the other ranks stay in the group until rank 0's instrumented pass is over
         dist.destroy_process_group()
 
 

@@ -3,12 +3,17 @@ as small fixtures so that the GPU parity tests need not spend minutes of CPU per
 THIS repository's oracle (oracle/sd_oracle.py — parity unpinned, see its header: the reference holds no SD fixtures and
 diffusers is not installable here), on seeded weights and CPU-generator noise; nothing of the reference is involved.
 
-    python oracle/gen_golden_sd.py [cfg2] [cfg1] [cfg3]          (~25 min of 8 CPU threads in total)
+    python oracle/gen_golden_sd.py [cfg2] [cfg2c] [cfg1] [cfg3]          (~45 min of 8 CPU threads in total)
 
   sd_cfg2_frame.pt    configs[2]: 1_16_kitti_L1_64, F=64, one clip, ONE predicted frame, --denoise_start_step 0:
                       50 DDIM steps of the SD-v1.4 UNet at 64x64 latents between the 512x512 VAE passes; keeps the
                       latent entering the loop and the loop's whole latent history (free-running drift table and
                       per-step, teacher-forced errors)
+  sd_cfg2_contractive.pt  the same configs[2] frame with the UNet's conv_out weight and bias scaled by CONTRACTIVE_CONV_OUT (0.1):
+                      with |eps| ~ 0.16 |x| the 50-step DDIM map of the random-weight network is no longer chaotic (a 1e-3
+                      perturbation grows 1.95x over the 50 steps, HIP against HIP: tools/ddim_regime.py ->
+                      profiles/r03_ddim_regimes.json) while the network still moves the result by 0.28 rel-L2, so the
+                      FREE-RUNNING 50-step latent and the generated frame can be asserted at an arithmetic tolerance
   sd_cfg1_rollout.pt  configs[1]: same model, 8 predicted frames, --denoise_start_step 25 (25 steps per frame)
   sd_cfg3_rollout.pt  configs[3]: 11_27_ucf_final, F=128, 16 predicted frames, start step 48 (2 steps per frame: the
                       full 50 would be 800 UNet calls)
@@ -35,6 +40,16 @@ from oracle import loop_oracle, sd_oracle as SO  # noqa: E402
 OUT = os.path.join(ROOT, "tests", "golden")
 HIST_STEPS = list(range(51))      # the whole history (3.3 MB f32): the per-step (teacher-forced) test needs consecutive pairs
 UNET_SEED, VAE_SEED, XF_SEED, CLIP_SEED, NOISE_SEED, EMB_SEED = 31, 32, 7, 4, 5, 123
+CONTRACTIVE_CONV_OUT = 0.1        # scale on conv_out.{weight,bias} of the seeded UNet in the non-chaotic regime
+CONTRACTIVE_STEPS = [0, 1, 2, 3, 5, 10, 15, 20, 30, 40, 50]
+
+
+def contractive_unet(usd):
+    """the seeded UNet of the fixtures with conv_out scaled: same network, eps magnitude x CONTRACTIVE_CONV_OUT"""
+    out = dict(usd)
+    out["conv_out.weight"] = usd["conv_out.weight"] * CONTRACTIVE_CONV_OUT
+    out["conv_out.bias"] = usd["conv_out.bias"] * CONTRACTIVE_CONV_OUT
+    return out
 
 
 def loop_noise(seed, F, pred_frames, start_step, res=512, down=8):
@@ -66,10 +81,12 @@ def build_transformer(cfg_name, seed=XF_SEED):
     return m, cfg
 
 
-def run(cfg_name, pred_frames, start_step, out_name, keep_hist):
+def run(cfg_name, pred_frames, start_step, out_name, keep_hist, contractive=False):
     from sd_video_gen_amd.predict import bouncing_ball_clips
     t0 = time.time()
     usd = SO.seeded_weights(SO.unet_shapes(), UNET_SEED)
+    if contractive:
+        usd = contractive_unet(usd)
     vsd = SO.seeded_weights(SO.vae_shapes(), VAE_SEED)
     m, cfg = build_transformer(cfg_name)
     xsd = {k: v.detach() for k, v in m.state_dict().items()}
@@ -93,7 +110,7 @@ def run(cfg_name, pred_frames, start_step, out_name, keep_hist):
            "pred": torch.stack([t["pred"] for t in trace]), "unet_calls": calls[0]}
     if keep_hist:
         h = trace[0]["hist"]
-        steps = [s for s in HIST_STEPS if s < h.shape[0]]
+        steps = [s for s in (CONTRACTIVE_STEPS if contractive else HIST_STEPS) if s < h.shape[0]]
         rec.update(lat0=trace[0]["lat0"], hist_steps=steps, hist=h[steps].clone())
     torch.save(rec, os.path.join(OUT, out_name))
     print("%s: %d UNet calls, %.0f s, |lat| %.4f" % (out_name, calls[0], time.time() - t0, float(lat.abs().mean())), flush=True)
@@ -104,6 +121,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["cfg2", "cfg1", "cfg3"]
     if "cfg2" in which:
         run("1_16_kitti_L1_64", 1, 0, "sd_cfg2_frame.pt", True)
+    if "cfg2c" in which:
+        run("1_16_kitti_L1_64", 1, 0, "sd_cfg2_contractive.pt", True, contractive=True)
     if "cfg3" in which:
         run("11_27_ucf_final", 16, 48, "sd_cfg3_rollout.pt", False)
     if "cfg1" in which:

@@ -28,7 +28,8 @@ from sd_video_gen_amd import _lib  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 FORCED_TOL = 4.5e-2  # one DDIM step from the oracle's latent: measured 1.5e-2 worst (bf16 UNet call 1e-2, amplified by 1/sqrt(alpha_t))
-SATURATION = 0.9     # two decorrelated latents of equal norm differ by ~sqrt(2) x correlation loss; measured 0.55 (both HIP-vs-HIP and HIP-vs-oracle)
+# The free-running 50-step comparison is ASSERTED in the non-chaotic weight regime (test_config2_free_running_contractive);
+# on the chaotic unscaled network the free-running distances are printed only (they measure conditioning, not arithmetic).
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
@@ -55,17 +56,17 @@ def nets():
     return usd, vsd
 
 
-def _sdu(cfg_name, nets):
+def _sdu(cfg_name, nets, dtype="bf16"):
     from sd_video_gen_amd import config as svg_config
     from sd_video_gen_amd.sd_utils import SDUtils
     svg_config.set_args(["--dataset", "synthetic-ball", "--config", cfg_name, "--denoise", "1"])
     usd, vsd = nets
-    return SDUtils(weights={"vae": vsd, "unet": usd, "text_encoder": "synthetic"}, verbose=False)
+    return SDUtils(weights={"vae": vsd, "unet": usd, "text_encoder": "synthetic"}, verbose=False, dtype=dtype)
 
 
-def _rollout(cfg_name, g, nets):
+def _rollout(cfg_name, g, nets, dtype="bf16"):
     from sd_video_gen_amd.predict import sample_clips, bouncing_ball_clips
-    sdu = _sdu(cfg_name, nets)
+    sdu = _sdu(cfg_name, nets, dtype)
     m, cfg = GG.build_transformer(cfg_name)
     clip = bouncing_ball_clips(1, cfg.FRAME_SIZE, 5, seed=GG.CLIP_SEED)
     lat = sample_clips(m, sdu, clip.cuda(), g["pred_frames"], denoise=True, start_step=g["start_step"], seeds=[GG.NOISE_SEED],
@@ -123,8 +124,50 @@ def test_config2_full_frame_50_steps(ctx, nets):
     margin("cfg2 conditioning latents (VAE encode @64)", e_cond, 1.2e-2)
     margin("cfg2 DDIM step, teacher-forced, worst of the 50 steps", max(forced), FORCED_TOL)
     margin("cfg2 DDIM free-running, after the first step", table[1][1], FORCED_TOL)
-    margin("cfg2 DDIM free-running after 50 steps (chaotic map: saturation level)", table[-1][1], SATURATION)
-    margin("cfg2 generated frame latent after 50 DDIM steps + 3 uint8 round trips (same)", e_frame, SATURATION)
+    print("[parity] cfg2 on the CHAOTIC unscaled network (printed, not asserted): free-running after 50 steps %.3f, generated frame %.3f"
+          % (table[-1][1], e_frame))
+
+
+@pytest.mark.parametrize("dtype,tol_loop,tol_frame", [("fp16", 5e-3, 1.5e-2), ("bf16", 3e-2, 6e-2)])
+def test_config2_free_running_contractive(ctx, nets, dtype, tol_loop, tol_frame):
+    """configs[2] END TO END, free-running, at a real tolerance: the headline workload (one generated frame = VAE passes at 512 x 512 +
+    all 50 DDIM steps of the full-size UNet, nothing teacher-forced) against the fp32 oracle, in the synthetic-weight regime whose
+    DDIM map is not chaotic (oracle/gen_golden_sd.py: the seeded UNet with conv_out x 0.1; a 1e-3 perturbation grows < 3x over the
+    50 steps — asserted below HIP against HIP — while the network still moves the final latent by 0.28 rel-L2).
+    Tolerances: the loop's final latent <= 5e-3 in fp16 storage (the reference's arithmetic) and <= 3e-2 in bf16; the generated
+    frame's latent additionally passes three uint8 quantisations (decode @512 -> encode @64), stated separately."""
+    g = gold("sd_cfg2_contractive.pt")
+    usd, vsd = nets
+    cnets = (GG.contractive_unet(usd), vsd)
+    lat, sdu = _rollout("1_16_kitti_L1_64", g, cnets, dtype)
+    assert sdu.ctx.model_dtype(_lib.SVG_UNET) == dtype and sdu.ctx.model_dtype(_lib.SVG_VAE) == dtype
+    e_frame = rel_l2(lat[:, 4:], g["all_latents"][:, 4:])
+    emb = GG.text_emb().cuda()
+    ks = g["hist_steps"]
+    assert ks[-1] == 50
+    c = sdu.unet.ctx
+    hist = c.ddim_loop(g["lat0"].cuda(), emb, num_steps=50, start_step=0, guidance=0.0, return_hist=True).cpu()
+    table = [(k, rel_l2(hist[k], g["hist"][i])) for i, k in enumerate(ks)]
+    print("[parity] %s free-running DDIM (contractive regime) vs the fp32 oracle after k steps: " % dtype + "  ".join("k=%d: %.2e" % t for t in table))
+    gp = torch.Generator().manual_seed(99)
+    d = torch.randn(g["lat0"].shape, generator=gp)
+    pert = g["lat0"] + 1e-3 * d * (g["lat0"].norm() / d.norm())
+    hist_p = c.ddim_loop(pert.cuda(), emb, num_steps=50, start_step=0, guidance=0.0, return_hist=True).cpu()
+    growth = max(rel_l2(hist_p[k], hist[k]) for k in range(1, 51)) / 1e-3
+    if dtype == "fp16":   # (bf16's own rounding noise, 5e-3, is above the 1e-3 perturbation: the growth is a property of the map, measured in fp16)
+        margin("cfg2 contractive regime (fp16): growth of a 1e-3 perturbation over the 50 steps, HIP vs HIP", growth, 3.0, unit="x")
+    else:
+        print("[parity] bf16: distance of the perturbed run / 1e-3 = %.2f (includes bf16's own 5e-3 rounding noise)" % growth)
+    # the network matters in this regime: zeroing eps (the scheduler alone) lands far from the result
+    ac = torch.cumprod(1 - torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000) ** 2, 0)
+    z = g["lat0"].clone()
+    for i in range(50):
+        t = 980 - 20 * i
+        z = (ac[t - 20] if t >= 20 else torch.tensor(1.0)).sqrt() * (z / ac[t].sqrt()).clamp(-1, 1)
+    assert rel_l2(g["hist"][-1], z) > 0.2, "the regime must keep the UNet relevant to the result"
+    margin("cfg2 contractive regime (%s): FREE-RUNNING latent after all 50 DDIM steps" % dtype, table[-1][1], tol_loop)
+    margin("cfg2 contractive regime (%s): worst step of the free-running history" % dtype, max(t[1] for t in table), tol_loop)
+    margin("cfg2 contractive regime (%s): generated frame latent (50 steps + VAE @512 + 3 uint8 round trips)" % dtype, e_frame, tol_frame)
 
 
 def test_config1_rollout_8_frames_start25(ctx, nets):
