@@ -53,7 +53,7 @@ extern "C" {
 
 typedef struct svg_ctx svg_ctx;
 
-enum svg_model { SVG_TRANSFORMER = 0, SVG_VAE = 1, SVG_UNET = 2, SVG_CLIP_TEXT = 3 };
+enum svg_model { SVG_TRANSFORMER = 0, SVG_VAE = 1, SVG_UNET = 2, SVG_CLIP_TEXT = 3, SVG_MINILM = 4 };
 enum svg_status { SVG_OK = 0, SVG_ERR_RUNTIME = -1, SVG_ERR_INVALID = -2 };
 
 /* ---- context ------------------------------------------------------------------------------ */
@@ -73,7 +73,10 @@ const char* svg_version(void);
  *            OCP e4m3 + E8M0 per 32 — with activations quantised on the way in; everything else stays 16-bit),
  *            f16 (0; 1 = fp16 storage instead of bf16: utils/sd_utils.py:246 autocast).
  * CLIP text keys: vocab (49408), d_model (768), heads (12), layers (12), ffn (3072), max_pos (77); tensors by their
- *   transformers names without the "text_model." prefix (embeddings.token_embedding.weight, encoder.layers.N.*, ...). */
+ *   transformers names without the "text_model." prefix (embeddings.token_embedding.weight, encoder.layers.N.*, ...).
+ * MiniLM keys: vocab (30522), d_model (384), heads (12), layers (6), ffn (1536), max_pos (512); tensors by their transformers
+ *   BertModel names (embeddings.word_embeddings.weight, encoder.layer.N.attention.self.query.weight, ...; the reference's text
+ *   checkpoints carry them as sent_transformer.0.auto_model.<name>). */
 int svg_model_configure(svg_ctx* ctx, int model, const char* kv);
 /* data: f32, host or device memory (hipMemcpyDefault); shape/ndim as in the state_dict. */
 int svg_load_weight(svg_ctx* ctx, int model, const char* name, const float* data,
@@ -81,7 +84,7 @@ int svg_load_weight(svg_ctx* ctx, int model, const char* name, const float* data
 /* packs fused layouts, checks that every expected tensor arrived (error names the first
  * missing key), returns the model's parameter count through *n_params if non-NULL. */
 int svg_finalize(svg_ctx* ctx, int model, int64_t* n_params);
-/* storage type of a configured model: "bf16" / "fp16" (SVG_VAE, SVG_UNET), "f32" (SVG_TRANSFORMER, SVG_CLIP_TEXT); NULL if absent */
+/* storage type of a configured model: "bf16" / "fp16" (SVG_VAE, SVG_UNET), "f32" (SVG_TRANSFORMER, SVG_CLIP_TEXT, SVG_MINILM); NULL if absent */
 const char* svg_model_dtype(svg_ctx* ctx, int model);
 
 /* ---- latent Transformer -------------------------------------------------------------------- */
@@ -97,6 +100,14 @@ int svg_transformer_forward(svg_ctx* ctx, const float* src, const float* tgt, in
  * token = cat(project_image_embedding(x), text[b]) * sqrt(d_model) + PE, d_model = DIM_MODEL + text_dim. */
 int svg_transformer_forward_text(svg_ctx* ctx, const float* src, const float* tgt, const float* text, int B, int Ts,
                                  int Tt, const float* mask, const int32_t* pe_row, float* out, void* stream);
+
+/* The same forward with nn.Transformer's key-padding masks (models/transformer.py:64: src_key_padding_mask = src_pad_mask,
+ * tgt_key_padding_mask = tgt_pad_mask): src_pad (B,Ts) / tgt_pad (B,Tt) are ADDITIVE f32 biases on the scores of every query and
+ * head of batch row b (a bool mask's True is -inf, as torch canonicalises it), applied to the encoder / decoder SELF-attention keys;
+ * the cross-attention gets none (the reference passes no memory_key_padding_mask).  Either may be NULL; text as above or NULL. */
+int svg_transformer_forward_padded(svg_ctx* ctx, const float* src, const float* tgt, const float* text, int B, int Ts, int Tt,
+                                   const float* mask, const float* src_pad, const float* tgt_pad, const int32_t* pe_row,
+                                   float* out, void* stream);
 
 /* ---- latent Transformer: training step ------------------------------------------------------- */
 /* Replaces the body of trainers/trainer.py:111-190 (train_loop: forward in train mode, criterion, loss.backward(),
@@ -133,6 +144,14 @@ int svg_transformer_tensor(svg_ctx* ctx, int kind, const char* name, float* out,
 /* input_ids (B,T) int32 token ids (T <= max_pos; the reference pads to 77); out (B,T,d_model) f32 = last_hidden_state.
  * Causal mask only (the reference passes no attention mask); f32 arithmetic like the reference. */
 int svg_clip_text_forward(svg_ctx* ctx, const int32_t* input_ids, int B, int T, float* out, void* stream);
+
+/* ---- MiniLM sentence encoder ------------------------------------------------------------------ */
+/* models/transformer_text.py:82-83: txt = self.sent_transformer.encode(cls_list) with SentenceTransformer('all-MiniLM-L6-v2')
+ * (:12): BertModel -> attention-mask-weighted mean pooling -> L2 normalisation.  input_ids (B,T) int32: [CLS] tokens [SEP],
+ * then padding; lengths (B) int32: tokens of each row that are not padding; out (B,d_model) f32 unit-norm embeddings;
+ * hidden (optional, may be NULL): (B,T,d_model) last_hidden_state.  T <= 128.  Tokenisation (WordPiece) stays on the host. */
+int svg_minilm_encode(svg_ctx* ctx, const int32_t* input_ids, const int32_t* lengths, int B, int T, float* out, float* hidden,
+                      void* stream);
 
 /* ---- VAE ------------------------------------------------------------------------------------ */
 /* img: u8 NHWC (N,srcH,srcW,3); nearest-resized to (H,W) on the fly when they differ.

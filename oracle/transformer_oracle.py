@@ -48,8 +48,18 @@ def get_tgt_mask(size):
     return mask
 
 
-def _mha(sd, prefix, q_in, kv_in, num_heads, mask=None, drop=None):
-    """nn.MultiheadAttention (seq-first): q_in (Tq,B,d), kv_in (Tk,B,d).  drop: train-mode dropout on the probabilities."""
+def _pad_bias(pad):
+    """key_padding_mask (B,Tk) as nn.MultiheadAttention canonicalises it: bool True -> -inf, float -> added as is"""
+    if pad is None:
+        return None
+    if pad.dtype == torch.bool:
+        return torch.zeros(pad.shape, dtype=torch.float32).masked_fill(pad, float("-inf"))
+    return pad.float()
+
+
+def _mha(sd, prefix, q_in, kv_in, num_heads, mask=None, drop=None, key_pad=None):
+    """nn.MultiheadAttention (seq-first): q_in (Tq,B,d), kv_in (Tk,B,d).  drop: train-mode dropout on the probabilities.
+    key_pad (B,Tk): key-padding mask, added to the scores of every head and query of batch row b (transformer.py:64)."""
     Tq, B, d = q_in.shape
     Tk = kv_in.shape[0]
     hd = d // num_heads
@@ -64,6 +74,8 @@ def _mha(sd, prefix, q_in, kv_in, num_heads, mask=None, drop=None):
     s = torch.bmm(q, k.transpose(1, 2)) / math.sqrt(hd)
     if mask is not None:
         s = s + mask
+    if key_pad is not None:
+        s = s + _pad_bias(key_pad)[:, None, None, :].expand(B, num_heads, 1, Tk).reshape(B * num_heads, 1, Tk)
     p = torch.softmax(s, dim=-1)
     if drop is not None:
         p = drop(p)
@@ -89,13 +101,15 @@ def count_layers(sd, stem):
     return n
 
 
-def forward(sd, src, tgt, num_heads, tgt_mask=None, txt=None, drop=None):
+def forward(sd, src, tgt, num_heads, tgt_mask=None, txt=None, drop=None, src_pad_mask=None, tgt_pad_mask=None):
     """transformer.py:47-68.  src/tgt (B,T,D_lat) -> (T_tgt,B,D_lat).  eval mode (no dropout) unless `drop` is given:
     drop(x) is then applied at every dropout site of the train-mode module, in execution order — after the positional
     encoding of src and of tgt (positional_encoding.py:35), and per nn.Transformer layer on the attention probabilities,
     after each attention / feed-forward sublayer (dropout1/2/3) and inside the feed-forward (activation -> dropout -> linear2).
     With `txt` (B,384): the text-conditioned variant, models/transformer_text.py:71-111 — the embedding layer is
     `project_image_embedding` and every token is cat(proj(x), txt[b]) * sqrt(d), d = DIM_MODEL + 384 (:33-35,:82-92).
+    src_pad_mask (B,Ts) / tgt_pad_mask (B,Tt): nn.Transformer's src_key_padding_mask (encoder self-attention keys) and
+    tgt_key_padding_mask (decoder self-attention keys); the cross-attention gets none (memory_key_padding_mask is not passed).
     (That file cannot be imported here — sentence_transformers is missing — so this branch is pinned through its exact
     equivalence with the pinned base path: tests/test_oracle_transformer.py::test_text_variant_equivalence.)"""
     if txt is None:
@@ -121,13 +135,13 @@ def forward(sd, src, tgt, num_heads, tgt_mask=None, txt=None, drop=None):
     # encoder
     for i in range(count_layers(sd, "transformer.encoder.layers.")):
         p = "transformer.encoder.layers.%d." % i
-        s = _ln(sd, p + "norm1.", s + dr(_mha(sd, p + "self_attn.", s, s, num_heads, drop=drop)))
+        s = _ln(sd, p + "norm1.", s + dr(_mha(sd, p + "self_attn.", s, s, num_heads, drop=drop, key_pad=src_pad_mask)))
         s = _ln(sd, p + "norm2.", s + dr(_ffn(sd, p, s, drop)))
     mem = _ln(sd, "transformer.encoder.norm.", s)
     # decoder
     for i in range(count_layers(sd, "transformer.decoder.layers.")):
         p = "transformer.decoder.layers.%d." % i
-        t = _ln(sd, p + "norm1.", t + dr(_mha(sd, p + "self_attn.", t, t, num_heads, tgt_mask, drop=drop)))
+        t = _ln(sd, p + "norm1.", t + dr(_mha(sd, p + "self_attn.", t, t, num_heads, tgt_mask, drop=drop, key_pad=tgt_pad_mask)))
         t = _ln(sd, p + "norm2.", t + dr(_mha(sd, p + "multihead_attn.", t, mem, num_heads, drop=drop)))
         t = _ln(sd, p + "norm3.", t + dr(_ffn(sd, p, t, drop)))
     t = _ln(sd, "transformer.decoder.norm.", t)

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVG_LIB") or os.path.join(_HERE, "libsvg_hip.so")   # $SVG_LIB: A/B another build of the same ABI
 
-SVG_TRANSFORMER, SVG_VAE, SVG_UNET, SVG_CLIP_TEXT = 0, 1, 2, 3
+SVG_TRANSFORMER, SVG_VAE, SVG_UNET, SVG_CLIP_TEXT, SVG_MINILM = 0, 1, 2, 3, 4
 SVG_ERR_RUNTIME, SVG_ERR_INVALID = -1, -2        # enum svg_status
 
 _lib = None
@@ -41,11 +41,13 @@ SIGNATURES = {
     "svg_finalize": [_vp, _i, C.POINTER(_i64)],
     "svg_transformer_forward": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "svg_transformer_forward_text": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "svg_transformer_forward_padded": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "svg_transformer_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp],
     "svg_transformer_forward_train": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _f, C.c_uint64, _vp, _vp],
     "svg_transformer_adam_step": [_vp, _f, _f, _f, _f, _vp],
     "svg_transformer_tensor": [_vp, _i, C.c_char_p, _vp, _i64, _vp],
     "svg_clip_text_forward": [_vp, _vp, _i, _i, _vp, _vp],
+    "svg_minilm_encode": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
     "svg_vae_encode": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "svg_vae_decode": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp],
     "svg_unet_forward": [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp],
@@ -193,9 +195,32 @@ class Context:
         return n.value
 
     # ---- hot path ----------------------------------------------------------------------------
-    def transformer_forward(self, src, tgt, mask=None, pe_row=None, text=None):
+    @staticmethod
+    def _pad_bias(pad, B, T, device):
+        """key-padding mask (B,T) -> additive f32 bias: bool True -> -inf (as torch canonicalises it), float -> as is"""
+        if pad is None:
+            return None
+        pad = torch.as_tensor(pad).to(device)
+        if tuple(pad.shape) != (B, T):
+            raise ValueError("key-padding mask must be (batch, sequence) = (%d, %d), got %s" % (B, T, tuple(pad.shape)))
+        if pad.dtype == torch.bool:
+            return torch.zeros((B, T), device=device, dtype=torch.float32).masked_fill(pad, float("-inf")).contiguous()
+        return pad.float().contiguous()
+
+    def transformer_forward(self, src, tgt, mask=None, pe_row=None, text=None, src_pad_mask=None, tgt_pad_mask=None):
         B, Ts, D = src.shape
         Tt = tgt.shape[1]
+        if src_pad_mask is not None or tgt_pad_mask is not None:
+            src = src.contiguous().float()
+            tgt_c = src if tgt is src else tgt.contiguous().float()
+            out = torch.empty((Tt, B, D), device=src.device, dtype=torch.float32)
+            mask = mask.contiguous().float() if mask is not None else None
+            pe_row = pe_row.to(device=src.device, dtype=torch.int32).contiguous() if pe_row is not None else None
+            text = text.to(device=src.device, dtype=torch.float32).contiguous() if text is not None else None
+            sp, tp = self._pad_bias(src_pad_mask, B, Ts, src.device), self._pad_bias(tgt_pad_mask, B, Tt, src.device)
+            self.check(self.lib.svg_transformer_forward_padded(self.h, _ptr(src), _ptr(tgt_c), _ptr(text), B, Ts, Tt, _ptr(mask), _ptr(sp),
+                                                               _ptr(tp), _ptr(pe_row), _ptr(out), _stream()), "svg_transformer_forward_padded")
+            return out
         src = src.contiguous().float()
         tgt_c = src if tgt is src else tgt.contiguous().float()
         out = torch.empty((Tt, B, D), device=src.device, dtype=torch.float32)
@@ -266,6 +291,16 @@ class Context:
         out = torch.empty((B, T, d_model), device=self.device, dtype=torch.float32)
         self.check(self.lib.svg_clip_text_forward(self.h, _ptr(ids), B, T, _ptr(out), _stream()), "svg_clip_text_forward")
         return out
+
+    def minilm_encode(self, input_ids, lengths, d_model=384, return_hidden=False):
+        """input_ids (B,T), lengths (B) integer tensors -> (B,d_model) unit-norm sentence embeddings [, (B,T,d_model) hidden states]"""
+        ids = input_ids.to(device=self.device, dtype=torch.int32).contiguous()
+        lens = lengths.to(device=self.device, dtype=torch.int32).contiguous()
+        B, T = ids.shape
+        out = torch.empty((B, d_model), device=self.device, dtype=torch.float32)
+        hid = torch.empty((B, T, d_model), device=self.device, dtype=torch.float32) if return_hidden else None
+        self.check(self.lib.svg_minilm_encode(self.h, _ptr(ids), _ptr(lens), B, T, _ptr(out), _ptr(hid), _stream()), "svg_minilm_encode")
+        return (out, hid) if return_hidden else out
 
     def vae_encode(self, img_u8, H=None, W=None, eps=None, return_moments=False):
         """img_u8: (N,h,w,3) uint8 on device; nearest-resized to (H,W) when given."""

@@ -127,8 +127,9 @@ struct svg_ctx {
   struct VaeIface* vae = nullptr;     // sd_bf16::VaeModel or sd_f16::VaeModel (configure key f16=1)
   struct UnetIface* unet = nullptr;
   struct ClipTextModel* clip = nullptr;
-  static constexpr int kCtxSlot = 4;                 // owned[] index of allocations that belong to the context itself
-  std::vector<void*> owned[5];   // device allocations per model id (kCtxSlot = context) freed at reconfigure / destroy
+  struct MiniLmModel* minilm = nullptr;
+  static constexpr int kCtxSlot = 5;                 // owned[] index of allocations that belong to the context itself
+  std::vector<void*> owned[6];   // device allocations per model id (kCtxSlot = context) freed at reconfigure / destroy
   int cur_model = kCtxSlot;
   uint64_t* seed_scratch = nullptr;   // device word for svg_op_dropout_mask
   void* dalloc(int64_t bytes);

@@ -191,16 +191,23 @@ void fill_f32(float* p, int64_t n, float v, hipStream_t s);
 }  // namespace SDNS
 
 void xf_train_init_device();
+void xformer_init_device();
 
 // ------------------------------------------------------------------------------------------------
 // latent Transformer (f32, f32-input MFMA)
 // ------------------------------------------------------------------------------------------------
-// act_in on X: 0 none, 1 ReLU, 2 quick-GELU; Y = act_in(X) W^T + bias (+ residual[M][N]); M <= 336
+// act_in on X: 0 none, 1 ReLU, 2 quick-GELU, 3 exact GELU (erf); Y = act_in(X) W^T + bias (+ residual[M][N]); M <= 336
 void xf_gemm(svg_ctx* ctx, const float* X, const float* W, const float* bias, float* Y, int M, int N,
              int K, int act_in, hipStream_t s, const float* residual = nullptr);
 // CLIP text tower pieces (f32): token + position embedding lookup; causal self-attention on packed [q|k|v] rows
 void xf_embed_tokens(const int32_t* ids, const float* tok, const float* pos, float* y, int rows, int T, int d, int vocab, hipStream_t s);
 void xf_attention_causal(const float* qkv, float* o, int B, int T, int heads, int hd, hipStream_t s);
+// BERT (MiniLM sentence encoder): bidirectional attention over the first lens[b] keys of packed [q|k|v] rows; word + position +
+// token-type-0 embedding lookup; masked mean pooling + L2 normalisation (sentence-transformers Pooling + Normalize)
+void xf_attention_padded(const float* qkv, const int32_t* lens, float* o, int B, int T, int heads, int hd, hipStream_t s);
+void xf_embed_bert(const int32_t* ids, const float* word, const float* pos, const float* type0, float* y, int rows, int T, int d, int vocab,
+                   hipStream_t s);
+void xf_mean_pool_norm(const float* x, const int32_t* lens, float* out, int B, int T, int d, hipStream_t s);
 // y = LayerNorm(x + r) rows of d
 void xf_add_ln(const float* x, const float* r, const float* g, const float* b, float* y, int M, int d,
                float eps, hipStream_t s);
@@ -238,6 +245,7 @@ void xf_criterion(const float* pred, const float* expected, float* dpred, float*
                   int fh, int fw, float w_mse, float w_l1, float w_gdl, float alpha, float w_nce, float temperature, hipStream_t s);
 void xf_adam(const XfAdamTensor* tens, const XfAdamChunk* chunks, int n_chunks, float lr, float beta1, float beta2, float eps, int step,
              hipStream_t s);
-// seq-first MHA core on packed projections: q (Tq,B,ldq) k,v (Tk,B,ldk) -> o (Tq,B,d); mask (Tq,Tk) or null
+// seq-first MHA core on packed projections: q (Tq,B,ldq) k,v (Tk,B,ldk) -> o (Tq,B,d); mask (Tq,Tk) or null;
+// kpad (B,Tk) or null: additive key-padding bias per batch row
 void xf_attention(const float* q, int ldq, const float* k, const float* v, int ldk, const float* mask,
-                  float* o, int Tq, int Tk, int B, int heads, int hd, hipStream_t s);
+                  float* o, int Tq, int Tk, int B, int heads, int hd, hipStream_t s, const float* kpad = nullptr);

@@ -94,14 +94,15 @@ struct XfRun {
     }
     return y;
   }
-  float* mha(const std::string& p, const float* xq, int Tq, const float* xkv, int Tk, const float* mask, bool self) {
+  float* mha(const std::string& p, const float* xq, int Tq, const float* xkv, int Tk, const float* mask, bool self,
+             const float* kpad = nullptr) {
     const int d = m->d_model, hd = d / m->heads;
     float* o = ctx->arena.get<float>((int64_t)Tq * B * d);
     if (self) {
       float* qkv = gemm(xq, p + "in_proj_weight", p + "in_proj_bias", Tq * B, 3 * d, d);
       if (SVG_LAUNCHING(ctx)) {
         ProfScope ps(ctx, PK_XF_MISC, s, 0, 0);
-        xf_attention(qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, mask, o, Tq, Tk, B, m->heads, hd, s);
+        xf_attention(qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, mask, o, Tq, Tk, B, m->heads, hd, s, kpad);
       }
     } else {
       float* q = gemm(xq, p + "in_proj_weight", p + "in_proj_bias", Tq * B, d, d);
@@ -133,21 +134,24 @@ struct XfRun {
 
 // One chunk of batch rows (B*max(Ts,Tt) <= 336: the rows one pass of the weight stream serves).  pe_row must be non-null here.
 static void xf_forward_chunk(svg_ctx* ctx, XfModel* m, const float* src, const float* tgt, int B, int Ts, int Tt,
-                             const float* mask, const int32_t* pe_row, float* out_tb, hipStream_t s, const float* text) {
+                             const float* mask, const int32_t* pe_row, float* out_tb, hipStream_t s, const float* text,
+                             const float* src_pad, const float* tgt_pad) {
   XfRun r{ctx, m, s, B};
   r.text = text;
   float* xs = r.embed(src, Ts, pe_row);
   float* xt = (tgt == src && Ts == Tt) ? xs : r.embed(tgt, Tt, pe_row);
+  // nn.Transformer: src_key_padding_mask -> encoder self-attention keys, tgt_key_padding_mask -> decoder self-attention keys;
+  // the cross-attention takes none (memory_key_padding_mask is not passed at models/transformer.py:64)
   const int Ms = Ts * B, Mt = Tt * B;
   for (int i = 0; i < m->enc_layers; ++i) {
     std::string p = "transformer.encoder.layers." + std::to_string(i) + ".";
-    xs = r.add_ln(xs, r.mha(p + "self_attn.", xs, Ts, xs, Ts, nullptr, true), p + "norm1.", Ms);
+    xs = r.add_ln(xs, r.mha(p + "self_attn.", xs, Ts, xs, Ts, nullptr, true, src_pad), p + "norm1.", Ms);
     xs = r.add_ln(xs, r.ffn(p, xs, Ms), p + "norm2.", Ms);
   }
   float* mem = r.add_ln(xs, nullptr, "transformer.encoder.norm.", Ms);
   for (int i = 0; i < m->dec_layers; ++i) {
     std::string p = "transformer.decoder.layers." + std::to_string(i) + ".";
-    xt = r.add_ln(xt, r.mha(p + "self_attn.", xt, Tt, xt, Tt, mask, true), p + "norm1.", Mt);
+    xt = r.add_ln(xt, r.mha(p + "self_attn.", xt, Tt, xt, Tt, mask, true, tgt_pad), p + "norm1.", Mt);
     xt = r.add_ln(xt, r.mha(p + "multihead_attn.", xt, Tt, mem, Ts, nullptr, false), p + "norm2.", Mt);
     xt = r.add_ln(xt, r.ffn(p, xt, Mt), p + "norm3.", Mt);
   }
@@ -156,7 +160,7 @@ static void xf_forward_chunk(svg_ctx* ctx, XfModel* m, const float* src, const f
 }
 
 void XfModel::forward(svg_ctx* ctx, const float* src, const float* tgt, int B, int Ts, int Tt, const float* mask,
-                      const int32_t* pe_row, float* out, hipStream_t s, const float* text) {
+                      const int32_t* pe_row, float* out, hipStream_t s, const float* text, const float* src_pad, const float* tgt_pad) {
   SVG_CHECK(ready, "transformer: svg_finalize has not been called");
   SVG_CHECK((text_dim > 0) == (text != nullptr), "transformer: the text-conditioned variant needs (and only it takes) a text embedding");
   SVG_CHECK(B >= 1 && Ts >= 1 && Tt >= 1 && Ts <= 16 && Tt <= 16, "transformer: B=%d Ts=%d Tt=%d unsupported", B, Ts, Tt);
@@ -172,7 +176,7 @@ void XfModel::forward(svg_ctx* ctx, const float* src, const float* tgt, int B, i
       rows = r;
     }
     if (B <= Bc) {
-      xf_forward_chunk(ctx, this, src, tgt, B, Ts, Tt, mask, rows, out, s, text);
+      xf_forward_chunk(ctx, this, src, tgt, B, Ts, Tt, mask, rows, out, s, text, src_pad, tgt_pad);
     } else {
       for (int b0 = 0; b0 < B; b0 += Bc) {
         const int bc = std::min(Bc, B - b0);
@@ -180,7 +184,8 @@ void XfModel::forward(svg_ctx* ctx, const float* src, const float* tgt, int B, i
         float* tmp = ctx->arena.get<float>((int64_t)Tt * bc * d_lat);
         const float* srcc = src + (int64_t)b0 * Ts * d_lat;
         const float* tgtc = (tgt == src) ? srcc : tgt + (int64_t)b0 * Tt * d_lat;
-        xf_forward_chunk(ctx, this, srcc, tgtc, bc, Ts, Tt, mask, rows + b0, tmp, s, text ? text + (int64_t)b0 * text_dim : nullptr);
+        xf_forward_chunk(ctx, this, srcc, tgtc, bc, Ts, Tt, mask, rows + b0, tmp, s, text ? text + (int64_t)b0 * text_dim : nullptr,
+                         src_pad ? src_pad + (int64_t)b0 * Ts : nullptr, tgt_pad ? tgt_pad + (int64_t)b0 * Tt : nullptr);
         if (SVG_LAUNCHING(ctx))
           HIP_OK(hipMemcpy2DAsync(out + (int64_t)b0 * d_lat, (size_t)B * d_lat * sizeof(float), tmp,
                                   (size_t)bc * d_lat * sizeof(float), (size_t)bc * d_lat * sizeof(float), Tt,
@@ -196,6 +201,16 @@ extern "C" int svg_transformer_forward_text(svg_ctx* ctx, const float* src, cons
   try {
     SVG_CHECK(ctx && ctx->xf, "transformer: model not configured");
     ctx->xf->forward(ctx, src, tgt, B, Ts, Tt, mask, pe_row, out, (hipStream_t)stream, text);
+    return 0;
+  } catch (const std::exception& e) { return svg_fail(ctx, e); }
+}
+
+extern "C" int svg_transformer_forward_padded(svg_ctx* ctx, const float* src, const float* tgt, const float* text, int B, int Ts, int Tt,
+                                              const float* mask, const float* src_pad, const float* tgt_pad, const int32_t* pe_row, float* out,
+                                              void* stream) {
+  try {
+    SVG_CHECK(ctx && ctx->xf, "transformer: model not configured");
+    ctx->xf->forward(ctx, src, tgt, B, Ts, Tt, mask, pe_row, out, (hipStream_t)stream, text, src_pad, tgt_pad);
     return 0;
   } catch (const std::exception& e) { return svg_fail(ctx, e); }
 }

@@ -42,8 +42,10 @@ struct XfModel {
   struct XfTrain* train = nullptr;   // gradients + Adam moments (xf_trainer.cpp); dropped whenever weights are (re)loaded
   void configure(const char* kv);
   void finalize(svg_ctx* ctx, int64_t* n_params);
+  // src_pad (B,Ts) / tgt_pad (B,Tt): additive key-padding biases (models/transformer.py:64) or null
   void forward(svg_ctx* ctx, const float* src, const float* tgt, int B, int Ts, int Tt, const float* mask,
-               const int32_t* pe_row, float* out, hipStream_t s, const float* text = nullptr);
+               const int32_t* pe_row, float* out, hipStream_t s, const float* text = nullptr, const float* src_pad = nullptr,
+               const float* tgt_pad = nullptr);
 };
 
 // ---- CLIP text tower (transformers CLIPTextModel; reference call site utils/sd_utils.py:60,84,91) ---------------------
@@ -57,6 +59,20 @@ struct ClipTextModel {
   void finalize(svg_ctx* ctx, int64_t* n_params);
   // ids (B,T) int32 -> out (B,T,d_model) f32 = last_hidden_state (after final_layer_norm)
   void forward(svg_ctx* ctx, const int32_t* ids, int B, int T, float* out, hipStream_t s);
+};
+
+// ---- MiniLM sentence encoder (SentenceTransformer('all-MiniLM-L6-v2').encode; reference call site models/transformer_text.py:12,82-83)
+// BertModel (6 layers, d 384, 12 heads, ffn 1536) + masked mean pooling + L2 normalisation, f32 on the weight-streaming kernels.
+struct MiniLmModel {
+  WeightStore ws;
+  int vocab = 30522, d_model = 384, heads = 12, layers = 6, ffn = 1536, max_pos = 512;
+  bool ready = false;
+  std::vector<float*> qkv_w, qkv_b;        // per layer: [Wq; Wk; Wv] stacked
+  void configure(const char* kv);
+  void finalize(svg_ctx* ctx, int64_t* n_params);
+  // ids (B,T) int32 ([CLS] ... [SEP] then padding), lens (B) valid tokens per row -> out (B,d_model) unit-norm sentence embeddings;
+  // hidden (optional): (B,T,d_model) last_hidden_state
+  void encode(svg_ctx* ctx, const int32_t* ids, const int32_t* lens, int B, int T, float* out, float* hidden, hipStream_t s);
 };
 
 void xf_train_free(XfModel* m);

@@ -167,6 +167,7 @@ int svg_create(int device_id, svg_ctx** out) {
   sd_bf16::sd_init_device();
   sd_f16::sd_init_device();
   xf_train_init_device();
+  xformer_init_device();
   ctx = new svg_ctx();
   ctx->device = device_id;
   ctx->prof_entries.resize(PK_COUNT);

@@ -68,6 +68,9 @@ __global__ void __launch_bounds__(512) xf_gemm_kernel(const float* __restrict__ 
       } else if (act_in == 2) {   // quick-GELU x * sigmoid(1.702 x) on the input (CLIP's MLP)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { x0[j] = x0[j] / (1.f + __expf(-1.702f * x0[j])); x1[j] = x1[j] / (1.f + __expf(-1.702f * x1[j])); }
+      } else if (act_in == 3) {   // exact GELU x * Phi(x) on the input (BERT's intermediate activation)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x0[j] = 0.5f * x0[j] * (1.f + erff(x0[j] * 0.70710678118654752f)); x1[j] = 0.5f * x1[j] * (1.f + erff(x1[j] * 0.70710678118654752f)); }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[j], x0[j], acc[t], 0, 0, 0);
@@ -200,6 +203,9 @@ __global__ void __launch_bounds__(256) xf_gemm2_kernel(const float* __restrict__
             } else if (act_in == 2) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) { x0[j] = x0[j] / (1.f + __expf(-1.702f * x0[j])); x1[j] = x1[j] / (1.f + __expf(-1.702f * x1[j])); }
+            } else if (act_in == 3) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { x0[j] = 0.5f * x0[j] * (1.f + erff(x0[j] * 0.70710678118654752f)); x1[j] = 0.5f * x1[j] * (1.f + erff(x1[j] * 0.70710678118654752f)); }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[j], x0[j], acc[t], 0, 0, 0);
@@ -303,8 +309,10 @@ __global__ void xf_embed_post_kernel(const float* __restrict__ emb, const float*
 }
 
 // one workgroup per (batch row, head); Tq, Tk <= 16
+// kpad (B,Tk) or null: additive key-padding bias of batch row b (nn.Transformer's *_key_padding_mask: 0 / -inf, or a float bias)
 __global__ void __launch_bounds__(256) xf_attention_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                                                             const float* __restrict__ v, int ldk, const float* __restrict__ mask,
+                                                            const float* __restrict__ kpad,
                                                             float* __restrict__ o, int Tq, int Tk, int B, int heads, int hd) {
   __shared__ float sc[16][17];
   const int b = blockIdx.x, hh = blockIdx.y;
@@ -318,7 +326,7 @@ __global__ void __launch_bounds__(256) xf_attention_kernel(const float* __restri
     float s = 0.f;
     for (int c = lane; c < hd; c += 64) s += qr[c] * kr[c];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) sc[i][j] = s * scale + (mask ? mask[i * Tk + j] : 0.f);
+    if (lane == 0) sc[i][j] = s * scale + (mask ? mask[i * Tk + j] : 0.f) + (kpad ? kpad[b * Tk + j] : 0.f);
   }
   __syncthreads();
   if (threadIdx.x < Tq) {
@@ -354,7 +362,9 @@ __global__ void xf_embed_tokens_kernel(const int32_t* __restrict__ ids, const fl
 // batch-first causal self-attention for the CLIP text tower: qkv rows (b*T + t) hold [q | k | v] (ld = 3d), head dim <= 64,
 // T <= 128.  One workgroup per (b, head): K and V of the head in LDS; a wave owns query rows i = wid, wid+4, ...; lane j
 // scores key j (and j + 64), wave-shuffle max / sum, then lane c accumulates channel c.  q is scaled by hd^-1/2 (CLIPAttention).
-__global__ void __launch_bounds__(256) xf_attention_causal_kernel(const float* __restrict__ qkv, float* __restrict__ o, int T, int heads, int hd) {
+// causal = 0 with lens (B): bidirectional attention over the first lens[b] keys (BERT's padding mask: MiniLM sentence encoder).
+__global__ void __launch_bounds__(256) xf_attention_causal_kernel(const float* __restrict__ qkv, float* __restrict__ o, int T, int heads, int hd,
+                                                                   int causal, const int32_t* __restrict__ lens) {
   __shared__ float sk[128][65];
   __shared__ float sv[128][64];
   __shared__ float sp[4][128];
@@ -369,8 +379,10 @@ __global__ void __launch_bounds__(256) xf_attention_causal_kernel(const float* _
   }
   __syncthreads();
   const float scale = rsqrtf((float)hd);
-  for (int i = wid; i < T; i += 4) {
-    const float* qr = base + (int64_t)i * ld;
+  const int len = lens ? min(max(lens[b], 1), T) : T;
+  for (int i0 = wid; i0 < T; i0 += 4) {
+    const float* qr = base + (int64_t)i0 * ld;
+    const int i = causal ? i0 : len - 1;          // last visible key of query i0
     float s0 = -INFINITY, s1 = -INFINITY;
     if (lane <= i) {
       float a = 0.f;
@@ -394,7 +406,7 @@ __global__ void __launch_bounds__(256) xf_attention_causal_kernel(const float* _
     if (lane < hd) {
       float acc = 0.f;
       for (int j = 0; j <= i; ++j) acc += sp[wid][j] * sv[j][lane];
-      o[((int64_t)b * T + i) * d + hh * hd + lane] = acc;
+      o[((int64_t)b * T + i0) * d + hh * hd + lane] = acc;
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -412,15 +424,20 @@ template <int MT>
 static void xf2_launch(dim3 grid, hipStream_t s, const float* X, const float* W, const float* bias, const float* residual, float* Y,
                        int M, int N, int K, int act_in, int ksplit) {
   constexpr int NST = MT <= 4 ? 5 : (MT <= 8 ? 3 : 2);
-  constexpr int smem = NST * MT * 16 * 128 + 4096;
-  static bool attr[16] = {};                                // per device (smem <= 86 KB needs the opt-in above 64 KB)
-  int dev = 0;
-  HIP_OK(hipGetDevice(&dev));
-  if (smem > 65536 && dev < 16 && !attr[dev]) {
-    HIP_OK(hipFuncSetAttribute((const void*)xf_gemm2_kernel<MT, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr[dev] = true;
-  }
+  constexpr int smem = NST * MT * 16 * 128 + 4096;          // above 64 KB for MT = 16 / 21: opted in by xformer_init_device()
   hipLaunchKernelGGL((xf_gemm2_kernel<MT, NST>), grid, dim3(256), smem, s, X, W, bias, residual, Y, M, N, K, act_in, ksplit);
+}
+
+template <int MT>
+static void xf2_attr() {
+  constexpr int NST = MT <= 4 ? 5 : (MT <= 8 ? 3 : 2);
+  constexpr int smem = NST * MT * 16 * 128 + 4096;
+  HIP_OK(hipFuncSetAttribute((const void*)xf_gemm2_kernel<MT, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+}
+// per-device kernel attributes, set when a context is created on the device (svg_create): nothing but launches happens later,
+// in particular inside the stream capture of the training-step graph or on the sampling worker threads
+void xformer_init_device() {
+  xf2_attr<1>(); xf2_attr<2>(); xf2_attr<3>(); xf2_attr<4>(); xf2_attr<6>(); xf2_attr<8>(); xf2_attr<11>(); xf2_attr<16>(); xf2_attr<21>();
 }
 
 // column-block form (X shared through LDS): grid (N / 64, ksplit)
@@ -516,9 +533,9 @@ void xf_embed_post(const float* emb, const float* pe, const int32_t* pe_row, con
 }
 
 void xf_attention(const float* q, int ldq, const float* k, const float* v, int ldk, const float* mask, float* o, int Tq, int Tk,
-                  int B, int heads, int hd, hipStream_t s) {
+                  int B, int heads, int hd, hipStream_t s, const float* kpad) {
   SVG_CHECK(Tq <= 16 && Tk <= 16, "xf_attention: sequence length %d/%d > 16", Tq, Tk);
-  hipLaunchKernelGGL(xf_attention_kernel, dim3(B, heads), dim3(256), 0, s, q, ldq, k, v, ldk, mask, o, Tq, Tk, B, heads, hd);
+  hipLaunchKernelGGL(xf_attention_kernel, dim3(B, heads), dim3(256), 0, s, q, ldq, k, v, ldk, mask, kpad, o, Tq, Tk, B, heads, hd);
   check_launch("xf_attention");
 }
 
@@ -529,6 +546,56 @@ void xf_embed_tokens(const int32_t* ids, const float* tok, const float* pos, flo
 
 void xf_attention_causal(const float* qkv, float* o, int B, int T, int heads, int hd, hipStream_t s) {
   SVG_CHECK(T >= 1 && T <= 128 && hd >= 1 && hd <= 64, "xf_attention_causal: T=%d (<= 128) / head dim %d (<= 64) unsupported", T, hd);
-  hipLaunchKernelGGL(xf_attention_causal_kernel, dim3(B, heads), dim3(256), 0, s, qkv, o, T, heads, hd);
+  hipLaunchKernelGGL(xf_attention_causal_kernel, dim3(B, heads), dim3(256), 0, s, qkv, o, T, heads, hd, 1, (const int32_t*)nullptr);
   check_launch("xf_attention_causal");
+}
+
+void xf_attention_padded(const float* qkv, const int32_t* lens, float* o, int B, int T, int heads, int hd, hipStream_t s) {
+  SVG_CHECK(T >= 1 && T <= 128 && hd >= 1 && hd <= 64 && lens, "xf_attention_padded: T=%d (<= 128) / head dim %d (<= 64) unsupported", T, hd);
+  hipLaunchKernelGGL(xf_attention_causal_kernel, dim3(B, heads), dim3(256), 0, s, qkv, o, T, heads, hd, 0, lens);
+  check_launch("xf_attention_padded");
+}
+
+namespace {
+// BERT embeddings: y[b][t] = word[ids] + position[t] + token_type[0]   (LayerNorm follows as xf_add_ln)
+__global__ void xf_embed_bert_kernel(const int32_t* __restrict__ ids, const float* __restrict__ word, const float* __restrict__ pos,
+                                     const float* __restrict__ type0, float* __restrict__ y, int T, int d, int vocab) {
+  const int row = blockIdx.x;
+  int id = ids[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const float* wr = word + (int64_t)id * d;
+  const float* pr = pos + (int64_t)(row % T) * d;
+  for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4)
+    *(f32x4*)(y + (int64_t)row * d + c) = *(const f32x4*)(wr + c) + *(const f32x4*)(pr + c) + *(const f32x4*)(type0 + c);
+}
+// sentence-transformers Pooling(mean) + Normalize: out[b] = normalize(sum_{t < len_b} x[b][t] / max(len_b, 1e-9)), one workgroup per row
+__global__ void __launch_bounds__(256) xf_mean_pool_norm_kernel(const float* __restrict__ x, const int32_t* __restrict__ lens, float* __restrict__ out,
+                                                                 int T, int d) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const int len = min(max(lens[b], 0), T);
+  float sq = 0.f;
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float a = 0.f;
+    for (int t = 0; t < len; ++t) a += x[((int64_t)b * T + t) * d + c];
+    a /= fmaxf((float)len, 1e-9f);
+    out[(int64_t)b * d + c] = a;
+    sq += a * a;
+  }
+  for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+  __syncthreads();
+  const float nrm = fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), 1e-12f);      // F.normalize eps
+  for (int c = threadIdx.x; c < d; c += 256) out[(int64_t)b * d + c] /= nrm;
+}
+}  // namespace
+
+void xf_embed_bert(const int32_t* ids, const float* word, const float* pos, const float* type0, float* y, int rows, int T, int d, int vocab,
+                   hipStream_t s) {
+  hipLaunchKernelGGL(xf_embed_bert_kernel, dim3(rows), dim3(96), 0, s, ids, word, pos, type0, y, T, d, vocab);
+  check_launch("xf_embed_bert");
+}
+void xf_mean_pool_norm(const float* x, const int32_t* lens, float* out, int B, int T, int d, hipStream_t s) {
+  hipLaunchKernelGGL(xf_mean_pool_norm_kernel, dim3(B), dim3(256), 0, s, x, lens, out, T, d);
+  check_launch("xf_mean_pool_norm");
 }

@@ -148,17 +148,18 @@ class Transformer(LibraryTraining, nn.Module):
 
     # ---- forward (transformer.py:47-68) ---------------------------------------------------------------
     def forward(self, src, tgt, tgt_mask=None, src_pad_mask=None, tgt_pad_mask=None, pe_row=None):
-        if src_pad_mask is not None or tgt_pad_mask is not None:
-            raise NotImplementedError("key-padding masks: no caller of the reference passes one (predict.py:36, trainer.py:141)")
         if not src.is_cuda:
             raise RuntimeError("Transformer.forward runs on the HIP library and needs CUDA tensors; "
                                "there is no CPU fallback")
         if self.training and self.positional_encoder.dropout_p > 0:
             if pe_row is not None:
                 raise NotImplementedError("pe_row is a sampling-path argument (eval mode)")
+            if src_pad_mask is not None or tgt_pad_mask is not None:
+                raise NotImplementedError("key-padding masks are served in eval mode (no caller of the reference trains with one: trainer.py:141)")
             return self._forward_train(src, tgt, tgt_mask, None)
         ctx = self._sync_weights()
-        return ctx.transformer_forward(src, tgt, tgt_mask, pe_row)
+        # key-padding masks (transformer.py:64): bool (create_pad_mask) or float, (B,T)
+        return ctx.transformer_forward(src, tgt, tgt_mask, pe_row, src_pad_mask=src_pad_mask, tgt_pad_mask=tgt_pad_mask)
 
     def get_tgt_mask(self, size):
         """transformer.py:70-89."""

@@ -2,9 +2,11 @@
 BASELINE config 5): every token is ``cat(Linear(D_lat -> DIM_MODEL)(x), class_embedding_384) * sqrt(d)`` with
 ``d = DIM_MODEL + 384`` (transformer_text.py:33-35,82-92); the rest is the base model at width d.
 
-The class-name embedding comes from ``SentenceTransformer('all-MiniLM-L6-v2').encode(cls_list)`` in the reference —
-an INPUT of this path whose weights are hub-only.  ``encode_classes`` uses a caller-supplied encoder when given, else a
-seeded per-string stand-in (equal strings -> equal vectors, unit norm like MiniLM's normalised output)."""
+The class-name embedding comes from ``SentenceTransformer('all-MiniLM-L6-v2').encode(cls_list)`` in the reference
+(transformer_text.py:12,82-83): here ``self.sent_transformer`` is ``minilm.SentenceEncoder`` — the same BertModel + mean
+pooling + L2 normalisation, run in the library (``svg_minilm_encode``), its parameters under the reference's checkpoint names
+(``sent_transformer.0.auto_model.*``).  ``text_encoder=`` replaces it by a caller-supplied callable; ``text_encoder="hash"``
+is a seeded per-string stand-in for host-only tests (equal strings -> equal unit-norm vectors; no network behind it)."""
 import zlib
 
 import torch
@@ -12,6 +14,7 @@ import torch.nn as nn
 
 from . import _lib
 from .config import parse_config_args
+from .minilm import SentenceEncoder
 from .transformer import LibraryTraining, PositionalEncoding
 
 TEXT_EMBED_DIM = 384
@@ -19,7 +22,7 @@ TEXT_EMBED_DIM = 384
 
 class Transformer(LibraryTraining, nn.Module):
     def __init__(self, num_tokens=0, dim_model=256, num_heads=8, num_encoder_layers=6, num_decoder_layers=6,
-                 dropout_p=0.1, text_encoder=None):
+                 dropout_p=0.1, text_encoder=None, st_weights=None):
         super().__init__()
         self.config, self.args = parse_config_args()
         self.text_embed_dim = TEXT_EMBED_DIM
@@ -31,7 +34,10 @@ class Transformer(LibraryTraining, nn.Module):
         self.height = self.width = self.config.FRAME_SIZE
         self.compression = 8
         self.d_lat = self.height // 8 * self.width // 8 * 4
-        self.text_encoder = text_encoder          # callable(list[str]) -> (n, 384) array / tensor, or None
+        self.text_encoder = text_encoder          # callable(list[str]) -> (n, 384) array / tensor, "hash", or None = sent_transformer
+        # transformer_text.py:44: self.sent_transformer = SentenceTransformer('all-MiniLM-L6-v2') (hub weights there; here
+        # $SVG_MINILM_WEIGHTS, a checkpoint's sent_transformer.* entries, or the synthetic opt-in: minilm.SentenceEncoder)
+        self.sent_transformer = SentenceEncoder(weights=st_weights)
         # parameter containers in the reference's construction order (transformer_text.py:48-69)
         self.positional_encoder = PositionalEncoding(dim_model=self.dim_model, dropout_p=dropout_p, max_len=64)
         self.project_image_embedding = nn.Linear(self.d_lat, self.img_embed_dim)
@@ -42,8 +48,12 @@ class Transformer(LibraryTraining, nn.Module):
         self._uploaded_version = None
 
     def encode_classes(self, cls_list):
-        if self.text_encoder is not None:
+        if callable(self.text_encoder):
             return torch.as_tensor(self.text_encoder(list(cls_list)), dtype=torch.float32)
+        if self.text_encoder is None:
+            return self.sent_transformer.encode(list(cls_list))          # transformer_text.py:82
+        if self.text_encoder != "hash":
+            raise ValueError("text_encoder must be a callable, 'hash' or None")
         out = []
         for c in cls_list:
             g = torch.Generator().manual_seed(zlib.crc32(str(c).encode()) % (2 ** 31))
@@ -58,6 +68,8 @@ class Transformer(LibraryTraining, nn.Module):
 
     def use_context(self, ctx):
         self._bound_ctx = ctx
+        self.sent_transformer._ctx = ctx
+        self.sent_transformer._uploaded = None
         self._uploaded_version = None
         return self
 
@@ -75,34 +87,40 @@ class Transformer(LibraryTraining, nn.Module):
         ctx.configure(_lib.SVG_TRANSFORMER, d_lat=self.d_lat, d_model=self.dim_model, heads=self.num_heads,
                       enc_layers=self.num_encoder_layers, dec_layers=self.num_decoder_layers, text_dim=self.text_embed_dim,
                       ffn=self.transformer.encoder.layers[0].linear1.out_features if self.num_encoder_layers else 2048)
-        ctx.load_state_dict(_lib.SVG_TRANSFORMER, self.state_dict())
+        ctx.load_state_dict(_lib.SVG_TRANSFORMER, {n: t for n, t in self.state_dict().items() if not n.startswith("sent_transformer.")})
         self.n_params = ctx.finalize(_lib.SVG_TRANSFORMER)
         ctx.claim(_lib.SVG_TRANSFORMER, self)
         self._uploaded_version = self._weights_version()
         return ctx
 
-    def load_state_dict(self, state_dict, *a, **k):
-        """Reference checkpoints are ``model.state_dict()`` of models/transformer_text.py, whose ``sent_transformer``
-        attribute (transformer_text.py:44) is an nn.Module: they carry ``sent_transformer.*`` keys (the MiniLM weights).
-        Those belong to the class-name encoder — an input of this path — not to this module: they are dropped here
-        (hand them to a ``text_encoder=`` callable instead), so reference checkpoints load under strict=True."""
-        state_dict = {n: t for n, t in state_dict.items() if not n.startswith("sent_transformer.")}
-        r = super().load_state_dict(state_dict, *a, **k)
+    def load_state_dict(self, state_dict, strict=True):
+        """Reference checkpoints are ``model.state_dict()`` of models/transformer_text.py, whose ``sent_transformer`` attribute
+        (transformer_text.py:44) is an nn.Module: they carry the MiniLM weights as ``sent_transformer.0.auto_model.*``.  Those fill
+        ``self.sent_transformer`` (the class-name encoder); a checkpoint without them leaves the encoder as it is."""
+        st = {n[len("sent_transformer."):]: t for n, t in state_dict.items() if n.startswith("sent_transformer.")}
+        own = {n: t for n, t in state_dict.items() if not n.startswith("sent_transformer.")}
+        if st:
+            self.sent_transformer.load_state_dict(st)
+        want = {n for n in super().state_dict() if not n.startswith("sent_transformer.")}
+        missing, unexpected = sorted(want - set(own)), sorted(set(own) - want)
+        if strict and (missing or unexpected):
+            raise RuntimeError("Error(s) in loading state_dict for Transformer: missing keys %s, unexpected keys %s" % (missing, unexpected))
+        nn.Module.load_state_dict(self, own, strict=False)
         self._uploaded_version = None
         self._lib_ahead = False
-        return r
+        return nn.modules.module._IncompatibleKeys(missing, unexpected)
 
     def forward(self, src, cls_list, tgt, tgt_mask=None, src_pad_mask=None, tgt_pad_mask=None, pe_row=None):
         """transformer_text.py:71-111.  ``cls_list``: class names (one per batch row) or a (B,384) tensor."""
-        if src_pad_mask is not None or tgt_pad_mask is not None:
-            raise NotImplementedError("key-padding masks: no caller of the reference passes one")
         if not src.is_cuda:
             raise RuntimeError("Transformer.forward runs on the HIP library and needs CUDA tensors; there is no CPU fallback")
         txt = self._text_of(cls_list)
         if self.training and self.positional_encoder.dropout_p > 0:
+            if src_pad_mask is not None or tgt_pad_mask is not None:
+                raise NotImplementedError("key-padding masks are served in eval mode")
             return self._forward_train(src, tgt, tgt_mask, txt)
         ctx = self._sync_weights()
-        return ctx.transformer_forward(src, tgt, tgt_mask, pe_row, text=txt)
+        return ctx.transformer_forward(src, tgt, tgt_mask, pe_row, text=txt, src_pad_mask=src_pad_mask, tgt_pad_mask=tgt_pad_mask)
 
     def get_tgt_mask(self, size):
         mask = torch.tril(torch.ones(size, size) == 1).float()

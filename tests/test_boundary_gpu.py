@@ -198,7 +198,7 @@ def test_two_transformers_share_a_context():
     torch.manual_seed(2)
     b = Transformer(dim_model=64, num_heads=4, num_encoder_layers=1, num_decoder_layers=1).eval()
     torch.manual_seed(3)
-    c = TextTransformer(dim_model=64, num_heads=8, num_encoder_layers=1, num_decoder_layers=1).eval()
+    c = TextTransformer(dim_model=64, num_heads=8, num_encoder_layers=1, num_decoder_layers=1, st_weights="synthetic").eval()
     X = torch.randn(1, 5, 256)
     mask = a.get_tgt_mask(5)
     ra = TO.forward(a.state_dict(), X, X, 4, mask)

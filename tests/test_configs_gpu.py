@@ -232,7 +232,7 @@ def test_config4_text_loop_with_prompt_and_guidance(ctx, nets):
     sdu = SDUtils(weights={"vae": vsd, "unet": usd, "text_encoder": "synthetic"}, verbose=False, seed=2)
     torch.manual_seed(9)
     m = TextTransformer(dim_model=cfg.DIM_MODEL[0], num_heads=cfg.NUM_HEADS[0], num_encoder_layers=cfg.NUM_ENCODER_LAYERS[0],
-                        num_decoder_layers=cfg.NUM_DECODER_LAYERS[0]).eval()
+                        num_decoder_layers=cfg.NUM_DECODER_LAYERS[0], st_weights="synthetic").eval()
     names = ["WallPushups"]
     prompt = ["a person doing WallPushups"]
     emb = sdu.encode_text(prompt)                                   # (2,77,768) = [uncond(''); text(prompt)] from the HIP CLIP tower
@@ -259,7 +259,7 @@ def test_config4_text_transformer_full_size(ctx):
     cfg = svg_config.load_config("11_27_ucf_text_final")
     torch.manual_seed(4)
     m = TextTransformer(dim_model=cfg.DIM_MODEL[0], num_heads=cfg.NUM_HEADS[0], num_encoder_layers=cfg.NUM_ENCODER_LAYERS[0],
-                        num_decoder_layers=cfg.NUM_DECODER_LAYERS[0]).eval()
+                        num_decoder_layers=cfg.NUM_DECODER_LAYERS[0], st_weights="synthetic").eval()
     assert m.dim_model == 2432 and m.d_lat == 1024
     sd = m.state_dict()
     X = torch.randn(2, 6, 1024)

@@ -168,20 +168,29 @@ def test_save_frames_bytes(tmp_path):
 
 def test_text_model_loads_reference_checkpoint_layout():
     """a reference text-model checkpoint (state_dict of models/transformer_text.py) also holds the SentenceTransformer's
-    ``sent_transformer.*`` tensors: they are dropped, everything else loads strictly."""
-    from sd_video_gen_amd import config as svg_config
+    ``sent_transformer.0.auto_model.*`` tensors (MiniLM): they fill the class-name encoder, everything else loads strictly, and a
+    checkpoint saved here carries them again under the same names (loads in the reference under strict=True)."""
+    from sd_video_gen_amd import config as svg_config, minilm, sd_layout
     from sd_video_gen_amd.transformer_text import Transformer
     svg_config.set_args(["--dataset", "ball", "--config", "model_10_26"])
     torch.manual_seed(0)
     m = Transformer(dim_model=32, num_heads=4, num_encoder_layers=1, num_decoder_layers=1)
+    assert not m.sent_transformer.loaded and not any(k.startswith("sent_transformer.") for k in m.state_dict())
     sd = {k: v.clone() + 1.0 if v.is_floating_point() else v.clone() for k, v in m.state_dict().items()}
-    sd["sent_transformer.0.auto_model.embeddings.word_embeddings.weight"] = torch.zeros(4, 4)
-    sd["sent_transformer.0.auto_model.encoder.layer.0.attention.self.query.bias"] = torch.zeros(4)
+    tiny = dict(vocab=1200, d_model=384, heads=12, layers=1, ffn=64, max_pos=32)
+    m.sent_transformer.cfg.update(tiny)
+    bert = sd_layout.seeded_weights(minilm.bert_shapes(tiny), 9)
+    sd.update({"sent_transformer.0.auto_model." + k: v for k, v in bert.items()})
+    sd["sent_transformer.0.auto_model.embeddings.position_ids"] = torch.arange(32).unsqueeze(0)
     r = m.load_state_dict(sd)                                       # strict
     assert not r.missing_keys and not r.unexpected_keys
-    assert torch.equal(m.out.bias, sd["out.bias"])
+    assert torch.equal(m.out.bias, sd["out.bias"]) and m.sent_transformer.loaded
+    out = m.state_dict()
+    assert set(out) == set(sd) and all(torch.equal(out[k], sd[k]) for k in sd)          # round trip, MiniLM tensors included
     with pytest.raises(RuntimeError):
         m.load_state_dict({k: v for k, v in sd.items() if k != "out.bias"})
+    with pytest.raises(FileNotFoundError):                          # an encoder without weights refuses, like a failed from_pretrained
+        Transformer(dim_model=32, num_heads=4, num_encoder_layers=1, num_decoder_layers=1).encode_classes(["Archery"])
 
 
 def test_checkpoint_format_roundtrip(tmp_path):

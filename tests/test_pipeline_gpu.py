@@ -70,7 +70,7 @@ def test_text_conditioned_loop_matches_oracle(ctx):
     from sd_video_gen_amd.transformer_text import Transformer as TextTransformer
     sdu, _, vsd, _ = build(False)
     torch.manual_seed(8)
-    m = TextTransformer(dim_model=64, num_heads=8, num_encoder_layers=1, num_decoder_layers=1).eval()
+    m = TextTransformer(dim_model=64, num_heads=8, num_encoder_layers=1, num_decoder_layers=1, st_weights="synthetic").eval()
     clips = bouncing_ball_clips(2, 64, 5, seed=9)
     names = ["WallPushups", "PlayingGuitar"]
     seeds = [21, 22]

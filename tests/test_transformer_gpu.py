@@ -52,6 +52,34 @@ def test_tiny_against_reference_golden(ctx):
     assert rel_l2(batched.cpu(), rows.cpu()) < 1e-6
 
 
+def test_key_padding_masks_against_reference_golden(ctx):
+    """src_pad_mask / tgt_pad_mask (models/transformer.py:64) through svg_transformer_forward_padded vs the live reference's outputs"""
+    g = gold("transformer_pad.pt")
+    m = build("model_10_26", dict(dim_model=32, num_heads=4, num_encoder_layers=1, num_decoder_layers=2), gold("transformer_tiny.pt")["state_dict"])
+    src, tgt, m5 = g["src"].cuda(), g["tgt"].cuda(), m.get_tgt_mask(5).cuda()
+    sp = m.create_pad_mask(g["src_ids"], 0)
+    tp = m.create_pad_mask(g["tgt_ids"], 0)
+    assert rel_l2(m(src, tgt, m5, sp, tp).cpu(), g["out_both"]) < TOL
+    assert rel_l2(m(src, tgt, m5, sp.cuda(), None).cpu(), g["out_src"]) < TOL
+    assert rel_l2(m(src, tgt, None, None, tp).cpu(), g["out_tgt"]) < TOL
+    assert rel_l2(m(src, tgt, m5, g["float_src_pad"], None).cpu(), g["out_float_src"]) < TOL          # float mask: added to the scores
+    assert rel_l2(m(src, tgt, m5).cpu(), g["out_both"]) > 1e-2
+    with pytest.raises(ValueError):
+        m(src, tgt, m5, sp[:, :3], None)
+    # a batch larger than one weight-stream chunk (336 rows / 6 tokens = 56 batch rows): masks follow their rows through the chunks
+    B = 60
+    gS = torch.Generator().manual_seed(5)
+    S = torch.randn(B, 6, 256, generator=gS)
+    pad = torch.rand(B, 6, generator=gS) > 0.7
+    pad[:, 0] = False
+    pe0 = torch.zeros(B, dtype=torch.int32)
+    out = m(S.cuda(), S.cuda(), m.get_tgt_mask(6).cuda(), pad, pad, pe_row=pe0).cpu()
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    for b in (0, 29, 57, 59):
+        ref = TO.forward(sd, S[b:b + 1], S[b:b + 1], 4, TO.get_tgt_mask(6), src_pad_mask=pad[b:b + 1], tgt_pad_mask=pad[b:b + 1])
+        assert rel_l2(out[:, b:b + 1], ref) < TOL
+
+
 @pytest.mark.parametrize("cfg", ["config_test", "1_16_kitti_L1_64", "11_27_ucf_final"])
 def test_full_size_against_reference_golden(ctx, cfg):
     spot = gold("transformer_spot.pt")[cfg]
@@ -102,7 +130,7 @@ def test_text_conditioned_variant(ctx):
     from sd_video_gen_amd.transformer_text import Transformer as TextTransformer, predict as predict_text
     svg_config.set_args(["--dataset", "ucf", "--config", "model_10_26"])
     torch.manual_seed(4)
-    m = TextTransformer(dim_model=128, num_heads=8, num_encoder_layers=2, num_decoder_layers=2).eval()
+    m = TextTransformer(dim_model=128, num_heads=8, num_encoder_layers=2, num_decoder_layers=2, st_weights="synthetic").eval()
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     X = torch.randn(3, 6, 256)
     names = ["WallPushups", "PlayingGuitar", "WallPushups"]
