@@ -599,6 +599,8 @@ int grid_for(int64_t n, int per_block) { return (int)std::min<int64_t>(4096, (n 
 void xf_train_init_device() {
   HIP_OK(hipFuncSetAttribute((const void*)attn_train_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kAttnTrainLds));
   HIP_OK(hipFuncSetAttribute((const void*)attn_train_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kAttnTrainLds));
+  // BiPatchNCE keeps 8 * hw + 4 floats per row in LDS: hw = feat_h * feat_w up to 4096 (FRAME_SIZE 512) needs 128 KiB
+  HIP_OK(hipFuncSetAttribute((const void*)nce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (8 * 4096 + 4) * (int)sizeof(float)));
 }
 
 void xf_drop_mask(const XfDrop d, float* out, int64_t n, hipStream_t s) {

@@ -69,7 +69,10 @@ class Trainer:
             sd_utils = SDUtils()
         self.sd_utils = sd_utils
         self.SOS_token = torch.ones((1, 1, self.config.FRAME_SIZE ** 2 // 64 * 4), dtype=torch.float32, device=self.device) * 2
-        self.seed = 0           # dropout: one fresh seed per training iteration
+        # dropout: one fresh seed per training iteration.  The masks are a pure function of (seed, site, element), so the starting
+        # point carries the entropy: torch's initial seed (torch.manual_seed makes a run reproducible, as in the reference), the
+        # rank and the run index — a --resume run, the next sweep point and every replica rank get their own mask sequence
+        self.seed = (int(torch.initial_seed()) * 1000003 + int(os.environ.get("RANK", "0")) * 7919 + self.index * 104729) & (2 ** 62 - 1)
         self._stream = torch.cuda.Stream() if torch.cuda.is_available() else None   # capturable: the library replays a step as one hipGraph
         self.log = lambda rec: print(json.dumps(rec), flush=True)
 

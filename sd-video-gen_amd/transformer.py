@@ -72,6 +72,8 @@ class LibraryTraining:
             raise RuntimeError("the library slot that held this module's trained weights was taken by another model before pull_weights()")
         with torch.no_grad():
             for name, p in self.named_parameters():
+                if name.startswith("sent_transformer."):      # the frozen class-name encoder of the text variant: not trained
+                    continue
                 p.copy_(ctx.transformer_tensor(name, p).to(p.device))
         self._lib_ahead = False
         self._uploaded_version = self._weights_version()      # the copy in the library IS these parameters: no re-upload

@@ -203,7 +203,7 @@ def test_two_transformers_share_a_context():
     mask = a.get_tgt_mask(5)
     ra = TO.forward(a.state_dict(), X, X, 4, mask)
     rb = TO.forward(b.state_dict(), X, X, 4, mask)
-    txt = c.encode_classes(["Archery"])
+    txt = c.encode_classes(["Archery"]).cpu()
     rc = TO.forward(c.state_dict(), X, X, 8, mask, txt=txt)
     assert rel_l2(ra, rb) > 1e-2
     xc, mc = X.cuda(), mask.cuda()

@@ -245,7 +245,7 @@ def test_config4_text_loop_with_prompt_and_guidance(ctx, nets):
                        guidance_scale=7.5, cls_list=names, cpu_noise=True).cpu()
     noise = GG.loop_noise(GG.NOISE_SEED, cfg.FRAME_SIZE, N, S)
     ref = loop_oracle.sample_clip({k: v for k, v in m.state_dict().items()}, cfg.NUM_HEADS[0], vsd, clip[0], N, noise, denoise=True, start_step=S,
-                                  unet_sd=usd, text_emb=emb_ref, txt=m.encode_classes(names), guidance_scale=7.5)
+                                  unet_sd=usd, text_emb=emb_ref, txt=m.encode_classes(names).cpu(), guidance_scale=7.5)
     assert lat.shape == ref.shape == (1, 4 + N, 1024)
     margin("cfg4 conditioning latents (VAE encode @128)", rel_l2(lat[:, :4], ref[:, :4]), 1.5e-2)
     margin("cfg4 text + guidance 7.5 loop, generated frames", rel_l2(lat[:, 4:], ref[:, 4:]), 1.0e-1)
@@ -264,7 +264,7 @@ def test_config4_text_transformer_full_size(ctx):
     sd = m.state_dict()
     X = torch.randn(2, 6, 1024)
     names = ["WallPushups", "PlayingGuitar"]
-    txt = m.encode_classes(names)
+    txt = m.encode_classes(names).cpu()
     out = m(X.cuda(), names, X.cuda(), m.get_tgt_mask(6).cuda(), pe_row=torch.zeros(2, dtype=torch.int32)).cpu()
     for b in range(2):
         ref = TO.forward(sd, X[b:b + 1], X[b:b + 1], 8, TO.get_tgt_mask(6), txt=txt[b:b + 1])

@@ -5,6 +5,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -112,3 +113,59 @@ def test_trainer_loaders_batches(tmp_path, monkeypatch):
         T.make_loaders(SimpleNamespace(dataset="ucf", folder=None), cfg, 5, 5, 1, 2, 1, 0)
     with pytest.raises(ValueError):
         T.make_loaders(SimpleNamespace(dataset="nope", folder=None), cfg, 5, 5, 1, 2, 1, 0)
+
+
+# ---- UCF-101 (prediction/predict.py:60-109) ----------------------------------------------------------------------------------------
+def _fake_ucf(tmp_path):
+    root = tmp_path / "UCF-101"
+    lab = tmp_path / "ucfTrainTestlist"
+    lab.mkdir()
+    rng = np.random.default_rng(0)
+    vids = {"ApplyEyeMakeup": [("v_ApplyEyeMakeup_g01_c01", 50), ("v_ApplyEyeMakeup_g08_c02", 12)],
+            "WallPushups": [("v_WallPushups_g02_c01", 31)], "YoYo": [("v_YoYo_g03_c04", 20)]}
+    for c, lst in vids.items():
+        (root / c).mkdir(parents=True)
+        for name, n in lst:
+            np.save(root / c / (name + ".npy"), rng.integers(0, 256, (n, 24, 32, 3), dtype=np.uint8))
+    (lab / "testlist01.txt").write_text("ApplyEyeMakeup/v_ApplyEyeMakeup_g01_c01.avi\nWallPushups/v_WallPushups_g02_c01.avi\nNoSuch/v_x.avi\n")
+    (lab / "trainlist01.txt").write_text("ApplyEyeMakeup/v_ApplyEyeMakeup_g08_c02.avi 1\nYoYo/v_YoYo_g03_c04.avi 101\n")
+    return str(root), str(lab)
+
+
+def test_ucf101_clip_indexing_like_torchvision(tmp_path):
+    from sd_video_gen_amd import loaders
+    # VideoClips.compute_clips_for_video, by hand: 50 frames @25 fps resampled to 3 fps -> floor(50*3/25) = 6 frames at
+    # floor(k * 25/3) = 0, 8, 16, 25, 33, 41 -> two clips of 5 with step 1
+    assert loaders.clips_for_video(50, 5, 1, 25.0, 3) == [[0, 8, 16, 25, 33], [8, 16, 25, 33, 41]]
+    assert loaders.clips_for_video(12, 5, 1, 25.0, None) == [list(range(i, i + 5)) for i in range(8)]      # native rate: a slice
+    assert loaders.clips_for_video(12, 5, 4) == [[0, 1, 2, 3, 4], [4, 5, 6, 7, 8]]
+    assert loaders.clips_for_video(20, 16, 1, 25.0, 5) == []                                              # 4 resampled frames < 16
+    # integer step 5: VideoClips slices the pts ([::5] -> 7 frames, not floor(31 * 5 / 25) = 6)
+    assert loaders.clips_for_video(31, 5, 1, 25.0, 5) == [[0, 5, 10, 15, 20], [5, 10, 15, 20, 25], [10, 15, 20, 25, 30]]
+    root, lab = _fake_ucf(tmp_path)
+    ds = loaders.UCF101Frames(root, lab, frames_per_clip=5, train=False, transform=loaders.ucf_transform(16))
+    assert ds.classes == ["ApplyEyeMakeup", "WallPushups", "YoYo"]
+    assert [os.path.basename(ds.samples[i][0]) for i in ds.indices] == ["v_ApplyEyeMakeup_g01_c01.npy", "v_WallPushups_g02_c01.npy"]
+    assert len(ds) == (50 - 5 + 1) + (31 - 5 + 1)
+    video, audio, label = ds[46]                  # first clip of the second selected video
+    assert audio is None and label == 1 and video.shape == (5, 16, 16, 3) and video.dtype == np.uint8
+    raw = np.load(os.path.join(root, "WallPushups", "v_WallPushups_g02_c01.npy"))
+    want = torch.nn.functional.interpolate(torch.from_numpy(raw[:5]).permute(0, 3, 1, 2), (16, 16)).permute(0, 2, 3, 1).numpy()[..., ::-1]
+    assert np.array_equal(video, want)            # F.interpolate's nearest on uint8, then RGB -> BGR (predict.py:83-85)
+    tr = loaders.UCF101Frames(root, lab, frames_per_clip=5, train=True, frame_rate=3)
+    assert [len([1 for v, _ in tr.clips if v == k]) for k in range(2)] == [0, 0] and len(tr) == 0     # 12 / 20 frames at 3 fps: < 5 frames
+    tr = loaders.UCF101Frames(root, lab, frames_per_clip=2, train=True, frame_rate=3)
+    assert len(tr) == 1 and tr[0][2] == 2 and tr.clips[0][1] == [0, 8]          # only YoYo (20 frames -> 2 at 3 fps) yields a clip
+    labels, vids = loaders.UCF101Frames.collate([ds[0], ds[46]])
+    assert labels.tolist() == [0, 1] and vids.shape == (2, 5, 16, 16, 3)
+    with pytest.raises(ValueError):
+        loaders.UCF101Frames(root, lab, 5, fold=4)
+
+
+def test_ucf_names_and_dirs():
+    from sd_video_gen_amd import loaders
+    assert loaders.split_class_names(["WallPushups", "ApplyEyeMakeup", "YoYo", "Archery"]) == ["Wall Pushups", "Apply Eye Makeup", "Yo Yo", "Archery"]
+    assert loaders.ucf_dirs("ucf") == ("data/UCF-101/UCF-101", "data/UCF101TrainTestSplits-RecognitionTask/ucfTrainTestlist")
+    assert loaders.ucf_dirs("ucf-wallpushups")[0].endswith("UCF-101-wallpushups") and loaders.ucf_dirs("ucf_workout")[0].endswith("-workout")
+    with pytest.raises(ValueError, match="Invalid dataset name"):
+        loaders.ucf_dirs("ucf-other")

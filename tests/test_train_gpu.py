@@ -265,9 +265,9 @@ def test_text_variant_training_step(ctx):
     svg_config.set_args(["--dataset", "ball", "--config", "model_10_26"])
     torch.manual_seed(31)
     m = TextTransformer(dim_model=16, num_heads=4, num_encoder_layers=1, num_decoder_layers=1, dropout_p=0.0, st_weights="synthetic").use_context(ctx)
-    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items() if not k.startswith("sent_transformer.")}
     names = ["Archery", "WallPushups", "Archery"]
-    txt = m.encode_classes(names)
+    txt = m.encode_classes(names).cpu()
     nb = torch.cat([2.0 * torch.ones(3, 1, 256), torch.randn(3, 5, 256)], dim=1)
     w = dict(w_mse=1.0, w_gdl=1.0, alpha=2)
     leaves = TR.leaf_state(sd)

@@ -134,7 +134,7 @@ def test_text_conditioned_variant(ctx):
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     X = torch.randn(3, 6, 256)
     names = ["WallPushups", "PlayingGuitar", "WallPushups"]
-    txt = m.encode_classes(names)
+    txt = m.encode_classes(names).cpu()
     out = m(X.cuda(), names, X.cuda(), m.get_tgt_mask(6).cuda()).cpu()
     assert out.shape == (6, 3, 256)
     assert rel_l2(out, TO.forward(sd, X, X, 8, TO.get_tgt_mask(6), txt=txt)) < TOL
