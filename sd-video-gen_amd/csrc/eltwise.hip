@@ -201,6 +201,25 @@ __global__ void ddim_step_kernel(const float* __restrict__ z, const float* __res
     zo[i] = sap * x0 + s1ap * e;
   }
 }
+// The same step with its scalars read from a device table row chosen by a device counter, so that a captured graph of one DDIM
+// step replays for every timestep without new kernel arguments: tab[i] = {t, sqrt(a_t), sqrt(1 - a_t), sqrt(a_prev), sqrt(1 - a_prev)}
+__global__ void ddim_step_tab_kernel(const float* __restrict__ z, const float* __restrict__ eu, const float* __restrict__ ec, float guidance,
+                                     float* __restrict__ zo, int64_t n, const float* __restrict__ tab, const int* __restrict__ idx) {
+  const float* r = tab + 5 * idx[0];
+  const float sa = r[1], s1a = r[2], sap = r[3], s1ap = r[4];
+  GRID_STRIDE(i, n) {
+    float e = eu[i];
+    if (ec) e = e + guidance * (ec[i] - e);
+    float x0 = (z[i] - s1a * e) / sa;
+    x0 = fminf(fmaxf(x0, -1.f), 1.f);
+    zo[i] = sap * x0 + s1ap * e;
+  }
+}
+__global__ void ddim_tvec_kernel(float* __restrict__ tvec, int nb, const float* __restrict__ tab, const int* __restrict__ idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nb) tvec[i] = tab[5 * idx[0]];
+}
+__global__ void ddim_bump_kernel(int* __restrict__ idx) { idx[0] += 1; }
 __global__ void add_noise_kernel(const float* __restrict__ x0, const float* __restrict__ nz, float* __restrict__ out, int64_t n, float sa, float s1a) {
   GRID_STRIDE(i, n) out[i] = sa * x0[i] + s1a * nz[i];
 }
@@ -295,6 +314,20 @@ void ddim_step(const float* z, const float* eu, const float* ec, float guidance,
   hipLaunchKernelGGL(ddim_step_kernel, grid_for(n), dim3(256), 0, s, z, eu, ec, guidance, zo, n, sa, s1a, sap, s1ap);
   check_launch("ddim_step");
 }
+void ddim_step_tab(const float* z, const float* eu, const float* ec, float guidance, float* zo, int64_t n, const float* tab, const int* idx,
+                   hipStream_t s) {
+  hipLaunchKernelGGL(ddim_step_tab_kernel, grid_for(n), dim3(256), 0, s, z, eu, ec, guidance, zo, n, tab, idx);
+  check_launch("ddim_step_tab");
+}
+void ddim_tvec(float* tvec, int nb, const float* tab, const int* idx, hipStream_t s) {
+  hipLaunchKernelGGL(ddim_tvec_kernel, dim3((nb + 63) / 64), dim3(64), 0, s, tvec, nb, tab, idx);
+  check_launch("ddim_tvec");
+}
+void ddim_bump(int* idx, hipStream_t s) {
+  hipLaunchKernelGGL(ddim_bump_kernel, dim3(1), dim3(1), 0, s, idx);
+  check_launch("ddim_bump");
+}
+
 namespace {
 __global__ void fill_f32_kernel(float* __restrict__ p, int64_t n, float v) {
   GRID_STRIDE(i, n) p[i] = v;

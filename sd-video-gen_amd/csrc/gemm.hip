@@ -23,6 +23,9 @@ bool conv_halo_supported(const GemmArgs& g);
 int conv_halo_bn(const GemmArgs& g);
 void launch_conv_halo(const GemmArgs& g, dim3 grid, hipStream_t s);
 bool gemm_pp_supported(const GemmArgs& g);
+bool gemm_ws_supported(const GemmArgs& g);
+int gemm_ws_groups(const GemmArgs& g);
+void launch_gemm_ws(svg_ctx* ctx, const GemmArgs& g, hipStream_t s);
 int gemm_pp_bn(const GemmArgs& g);
 void launch_gemm_pp(const GemmArgs& g, hipStream_t s);
 
@@ -406,6 +409,7 @@ int gemm_emits_gn(const GemmArgs& g0) {
   if (plan_splitk(g) > 1) return 0;
   g.splitk = 1;
   if (conv_halo_supported(g)) return 256;
+  if (gemm_ws_supported(g)) return 128;
   if (gemm_pp_supported(g)) return 256;
   return pick_bn(g) >= 32 ? BM : 0;
 }
@@ -416,6 +420,7 @@ int gemm_ln_tiles(const GemmArgs& g0) {
   if (g.out_f32 || g.act == ACT_GEGLU || g.N > g.ldc || g.amode != A_DENSE || g.bias_row) return 0;
   if (plan_splitk(g) > 1) return 0;
   g.splitk = 1;
+  if (gemm_ws_supported(g)) return gemm_ws_groups(g);      // one partial per row and column group
   if (gemm_pp_supported(g)) return cdiv(g.N, gemm_pp_bn(g));
   const int bn = pick_bn(g);
   return bn >= 128 ? cdiv(g.N, bn) : 0;
@@ -458,7 +463,7 @@ void launch_gemm(svg_ctx* ctx, const GemmArgs& g, hipStream_t s, int prof_kind) 
   const double a_elems = g.amode == A_DENSE ? (double)g.M * g.K : (double)(g.M / (g.Ho * g.Wo)) * g.H * g.W * g.Cin;
   char tag[160] = "";
   if (ctx->prof_detail) {
-    const char* kern = conv_halo_supported(a) ? "halo" : (gemm_pp_supported(a) ? "pp" : "igemm");
+    const char* kern = conv_halo_supported(a) ? "halo" : (gemm_ws_supported(a) ? "ws" : (gemm_pp_supported(a) ? "pp" : "igemm"));
     if (g.amode == A_DENSE)
       snprintf(tag, sizeof(tag), "M%d_N%d_K%d_b%d_act%d_res%d_ln%d_sk%d_%s", g.M, g.N, g.K, g.batch, g.act, g.residual ? 1 : 0, g.ln_rs ? 1 : 0, a.splitk, kern);
     else
@@ -470,6 +475,8 @@ void launch_gemm(svg_ctx* ctx, const GemmArgs& g, hipStream_t s, int prof_kind) 
     // 16 x 16 pixel blocks x channel tiles; splitk partitions the 64-channel chunks
     const int blocks = (a.M / 256) * cdiv(a.N, conv_halo_bn(a));
     launch_conv_halo(a, dim3(blocks, 1, a.splitk), s);
+  } else if (gemm_ws_supported(a)) {
+    launch_gemm_ws(ctx, a, s);
   } else if (gemm_pp_supported(a)) {
     launch_gemm_pp(a, s);
   } else {
@@ -501,7 +508,7 @@ static int plan_splitk(const GemmArgs& g) {
     if (blocks < 192 && CC >= 4) return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((tgt + blocks - 1) / blocks, CC / 2), 8));
     return 1;
   }
-  if (gemm_pp_supported(g)) return 1;
+  if (gemm_ws_supported(g) || gemm_pp_supported(g)) return 1;
   const int bn = pick_bn(g);
   const int64_t blocks = (int64_t)cdiv(g.M, BM) * cdiv(g.N, bn) * g.batch;
   const int KT = cdiv(g.K, BK);

@@ -78,6 +78,7 @@ int gemm_emits_gn(const GemmArgs& g);
 // per-device kernel attributes (dynamic LDS limits) of every instantiation; called by svg_create after hipSetDevice
 void gemm_init_device();
 void gemm_pp_init_device();
+void gemm_ws_init_device();
 void conv_halo_init_device();
 void ff_fused_init_device();
 void gemm_fp8_init_device();
@@ -185,6 +186,11 @@ void silu_h16(const h16* x, h16* y, int64_t n, hipStream_t s);
 // DDIM: z <- step(z, eps) with clip_sample; coefficients from the device table `coef` row `*step_idx`
 void ddim_step(const float* z, const float* eps_u, const float* eps_c, float guidance, float* z_out,
                int64_t n, float sqrt_at, float sqrt_1mat, float sqrt_ap, float sqrt_1map, hipStream_t s);
+// the step with (t, coefficients) read from row idx[0] of a device table of 5-float rows; tvec[i] = tab[idx][0]; idx[0] += 1
+void ddim_step_tab(const float* z, const float* eps_u, const float* eps_c, float guidance, float* z_out, int64_t n, const float* tab,
+                   const int* idx, hipStream_t s);
+void ddim_tvec(float* tvec, int nb, const float* tab, const int* idx, hipStream_t s);
+void ddim_bump(int* idx, hipStream_t s);
 void add_noise(const float* x0, const float* noise, float* out, int64_t n, float sa, float s1a, hipStream_t s);
 void fill_f32(float* p, int64_t n, float v, hipStream_t s);
 

@@ -184,6 +184,7 @@ void linear(svg_ctx* ctx, const h16* A, int lda, const PackedLinear& pl, void* C
 void sd_init_device() {
   gemm_init_device();
   gemm_pp_init_device();
+  gemm_ws_init_device();
   conv_halo_init_device();
   ff_fused_init_device();
   gemm_fp8_init_device();

@@ -564,24 +564,49 @@ void UnetModel::ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const flo
   const int64_t emb_n = (int64_t)N * ctx_len * ctx_dim;
   auto timestep_at = [&](int i) { return (num_steps - 1 - i) * ratio; };   // (arange(n)*ratio)[::-1]
 
+  // One DDIM step as a hipGraph: the first step runs as direct launches (it fills the cross-attention K / V^T cache), the second is
+  // CAPTURED on the caller's stream and the remaining ones replay it.  Everything a step needs that changes from step to step —
+  // the timestep of the embedding and the four scheduler coefficients — is read from a device table row selected by a device
+  // counter (ddim_step_tab / ddim_tvec / ddim_bump), so a replay needs no new kernel arguments.  The graph bakes arena pointers:
+  // it lives for this call only (the arena is planned just above and cannot move until the loop ends).  Off: SVG_DDIM_GRAPH=0,
+  // the legacy null stream (not capturable), the profiler's event brackets, and the latent history (a per-step copy target).
+  const int graph_env = getenv("SVG_DDIM_GRAPH") ? atoi(getenv("SVG_DDIM_GRAPH")) : 1;      // read per call: the tests toggle it in-process
+  const bool use_graph = graph_env && s != nullptr && !ctx->prof && !hist && (num_steps - start_step) >= 3;
+
   // planned once for the whole loop: every step has the same shapes
   auto body = [&]() {
     kv.valid = false;   // the context is constant over the loop: K / V^T of the cross-attentions are computed once
     float* tvec = ctx->arena.get<float>(NB);
     float* zin = cfg ? ctx->arena.get<float>(2 * n) : nullptr;
     float* eps = ctx->arena.get<float>((int64_t)NB * n / N);
+    float* tab = ctx->arena.get<float>((int64_t)5 * num_steps);
+    int* idx = ctx->arena.get<int>(1);
     if (SVG_LAUNCHING(ctx)) {
       if (start_step > 0 && start_step < num_steps) {
         const float a = alphas_cumprod[timestep_at(start_step)];
         add_noise(z, noise, z, n, sqrtf(a), sqrtf(1.f - a), s);
       }
       if (hist) HIP_OK(hipMemcpyAsync(hist, z, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+      if (use_graph) {
+        std::vector<float> h((size_t)5 * num_steps);
+        for (int i = 0; i < num_steps; ++i) {
+          const int t = timestep_at(i);
+          h[5 * i] = (float)t;
+          ddim_coefs(t, t - ratio, &h[5 * i + 1], &h[5 * i + 2], &h[5 * i + 3], &h[5 * i + 4]);
+        }
+        // pageable host memory: the copy is staged before the call returns
+        HIP_OK(hipMemcpyAsync(tab, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        const int first = start_step;
+        HIP_OK(hipMemcpyAsync(idx, &first, sizeof(int), hipMemcpyHostToDevice, s));
+        HIP_OK(hipStreamSynchronize(s));
+      }
     }
-    for (int i = start_step; i < num_steps; ++i) {
+    auto one_step = [&](int i, bool tabled) {
       const int t = timestep_at(i);
       ctx->arena.push();
       if (SVG_LAUNCHING(ctx)) {
-        fill_f32(tvec, NB, (float)t, s);
+        if (tabled) ddim_tvec(tvec, NB, tab, idx, s);
+        else fill_f32(tvec, NB, (float)t, s);
         if (cfg) {
           HIP_OK(hipMemcpyAsync(zin, z, n * sizeof(float), hipMemcpyDeviceToDevice, s));
           HIP_OK(hipMemcpyAsync(zin + n, z, n * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -592,16 +617,52 @@ void UnetModel::ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const flo
       if (SVG_LAUNCHING(ctx)) step_scope.reset(new ProfScope(ctx, PK_UNET_STEP, s, 0, 0));
       run(ctx, cfg ? zin : z, NB, h, w, tvec, text_emb, ctx_len, eps, s, &kv);
       if (SVG_LAUNCHING(ctx)) {
-        float sa, s1a, sap, s1ap;
-        ddim_coefs(t, t - ratio, &sa, &s1a, &sap, &s1ap);
-        ProfScope ps(ctx, PK_ELT, s, 0, 0);
-        ddim_step(z, eps, cfg ? eps + n : nullptr, guidance, z, n, sa, s1a, sap, s1ap, s);
-        if (hist) HIP_OK(hipMemcpyAsync(hist + (int64_t)(i - start_step + 1) * n, z, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (tabled) {
+          ddim_step_tab(z, eps, cfg ? eps + n : nullptr, guidance, z, n, tab, idx, s);
+          ddim_bump(idx, s);
+        } else {
+          float sa, s1a, sap, s1ap;
+          ddim_coefs(t, t - ratio, &sa, &s1a, &sap, &s1ap);
+          ProfScope ps(ctx, PK_ELT, s, 0, 0);
+          ddim_step(z, eps, cfg ? eps + n : nullptr, guidance, z, n, sa, s1a, sap, s1ap, s);
+          if (hist) HIP_OK(hipMemcpyAsync(hist + (int64_t)(i - start_step + 1) * n, z, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
       }
       step_scope.reset();
       ctx->arena.pop();
-      if (ctx->arena.dry && i > start_step) break;   // one step is enough to size the arena
+    };
+    if (!use_graph || !SVG_LAUNCHING(ctx)) {
+      for (int i = start_step; i < num_steps; ++i) {
+        one_step(i, false);
+        if (ctx->arena.dry && i > start_step) break;   // two steps are enough to size the arena (the second reuses the K / V^T cache)
+      }
+      return;
     }
+    one_step(start_step, true);                        // direct launches: fills the K / V^T cache, bumps the counter
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    try {
+      one_step(start_step + 1, true);
+    } catch (...) {
+      hipStreamEndCapture(s, &graph);
+      if (graph) hipGraphDestroy(graph);
+      throw;
+    }
+    HIP_OK(hipStreamEndCapture(s, &graph));
+    hipError_t ge = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (ge != hipSuccess) { hipGraphDestroy(graph); HIP_OK(ge); }
+    for (int i = start_step + 1; i < num_steps; ++i) {
+      ge = hipGraphLaunch(exec, s);
+      if (ge != hipSuccess) break;
+    }
+    // the executable graph is released once the stream has run it (the call stays asynchronous otherwise: the destroy is deferred
+    // through a host callback would need a thread-safe queue; a DDIM loop is 1.5 s of GPU work, the sync costs nothing measurable)
+    hipError_t se = hipStreamSynchronize(s);
+    hipGraphExecDestroy(exec);
+    hipGraphDestroy(graph);
+    HIP_OK(ge);
+    HIP_OK(se);
   };
   (void)emb_n;
   run_planned(ctx, body);

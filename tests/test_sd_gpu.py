@@ -168,6 +168,31 @@ def test_ddim_loop(ctx, guidance, start):
     assert torch.equal(out.cpu(), hist[-N:])
 
 
+@pytest.mark.parametrize("cfg,guidance,start,N", [(TINY_UNET, 0.0, 0, 2), (MID_UNET, 7.5, 40, 3), (MID_UNET, 0.0, 47, 1)])
+def test_ddim_graph_replay_equals_direct_launches(ctx, monkeypatch, cfg, guidance, start, N):
+    """On a capturable stream the loop captures its second step into a hipGraph and replays it (timestep and scheduler
+    coefficients from a device table): the same bits as the direct launches, and as the null-stream path."""
+    load_unet(ctx, cfg, 29)
+    g = torch.Generator().manual_seed(7)
+    h, L = 16, 9
+    lat = (torch.randn(N, 4, h, h, generator=g) * 0.5).cuda()
+    noise = torch.randn(N, 4, h, h, generator=g).cuda()
+    emb = torch.randn(2 * N, L, cfg["ctx_dim"], generator=g).cuda()
+    ref = ctx.ddim_loop(lat, emb, num_steps=50, start_step=start, guidance=guidance, noise=noise)        # null stream: direct launches
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    outs = {}
+    for mode in ("1", "0", "1"):
+        monkeypatch.setenv("SVG_DDIM_GRAPH", mode)
+        with torch.cuda.stream(side):
+            outs.setdefault(mode, []).append(ctx.ddim_loop(lat, emb, num_steps=50, start_step=start, guidance=guidance, noise=noise))
+        side.synchronize()
+    assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][1], outs["0"][0])
+    if start < 48:
+        assert torch.equal(outs["1"][0], ref)
+    assert torch.isfinite(ref).all()
+
+
 def test_ddim_start_step_identities(ctx):
     load_unet(ctx, TINY_UNET, 24)
     lat = torch.randn(1, 4, 16, 16)
