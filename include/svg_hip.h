@@ -53,7 +53,7 @@ extern "C" {
 
 typedef struct svg_ctx svg_ctx;
 
-enum svg_model { SVG_TRANSFORMER = 0, SVG_VAE = 1, SVG_UNET = 2, SVG_CLIP_TEXT = 3, SVG_MINILM = 4 };
+enum svg_model { SVG_TRANSFORMER = 0, SVG_VAE = 1, SVG_UNET = 2, SVG_CLIP_TEXT = 3, SVG_MINILM = 4, SVG_I3D = 5 };
 enum svg_status { SVG_OK = 0, SVG_ERR_RUNTIME = -1, SVG_ERR_INVALID = -2 };
 
 /* ---- context ------------------------------------------------------------------------------ */
@@ -76,7 +76,9 @@ const char* svg_version(void);
  *   transformers names without the "text_model." prefix (embeddings.token_embedding.weight, encoder.layers.N.*, ...).
  * MiniLM keys: vocab (30522), d_model (384), heads (12), layers (6), ffn (1536), max_pos (512); tensors by their transformers
  *   BertModel names (embeddings.word_embeddings.weight, encoder.layer.N.attention.self.query.weight, ...; the reference's text
- *   checkpoints carry them as sent_transformer.0.auto_model.<name>). */
+ *   checkpoints carry them as sent_transformer.0.auto_model.<name>).
+ * I3D keys: num_classes (400); tensors by the names of evaluation/pytorch_i3d.py's state_dict (Conv3d_1a_7x7.conv3d.weight,
+ *   Mixed_3b.b1b.bn.running_var, logits.conv3d.bias, ...; num_batches_tracked entries are accepted and ignored). */
 int svg_model_configure(svg_ctx* ctx, int model, const char* kv);
 /* data: f32, host or device memory (hipMemcpyDefault); shape/ndim as in the state_dict. */
 int svg_load_weight(svg_ctx* ctx, int model, const char* name, const float* data,
@@ -84,7 +86,7 @@ int svg_load_weight(svg_ctx* ctx, int model, const char* name, const float* data
 /* packs fused layouts, checks that every expected tensor arrived (error names the first
  * missing key), returns the model's parameter count through *n_params if non-NULL. */
 int svg_finalize(svg_ctx* ctx, int model, int64_t* n_params);
-/* storage type of a configured model: "bf16" / "fp16" (SVG_VAE, SVG_UNET), "f32" (SVG_TRANSFORMER, SVG_CLIP_TEXT, SVG_MINILM); NULL if absent */
+/* storage type of a configured model: "bf16" / "fp16" (SVG_VAE, SVG_UNET), "f32" (SVG_TRANSFORMER, SVG_CLIP_TEXT, SVG_MINILM, SVG_I3D); NULL if absent */
 const char* svg_model_dtype(svg_ctx* ctx, int model);
 
 /* ---- latent Transformer -------------------------------------------------------------------- */
@@ -152,6 +154,18 @@ int svg_clip_text_forward(svg_ctx* ctx, const int32_t* input_ids, int B, int T, 
  * hidden (optional, may be NULL): (B,T,d_model) last_hidden_state.  T <= 128.  Tokenisation (WordPiece) stays on the host. */
 int svg_minilm_encode(svg_ctx* ctx, const int32_t* input_ids, const int32_t* lengths, int B, int T, float* out, float* hidden,
                       void* stream);
+
+/* ---- FVD evaluation (evaluation/pytorch_i3d.py, evaluation/fvd_2.py; called at the end of prediction/predict_text.py) ---------- */
+/* InceptionI3d.forward (pytorch_i3d.py:303-312): x (B,3,T,224,224) f32 in [-1,1] -> logits (B,num_classes) f32 (mean over time). */
+int svg_i3d_forward(svg_ctx* ctx, const float* x, int B, int T, int H, int W, float* logits, void* stream);
+/* fvd_2.get_fvd_logits (fvd_2.py:16-19): videos (B,T,H,W,3) uint8 -> preprocess (fvd_2.py:7-14,109-136: /255, bilinear resize of the
+ * shorter side to 224, centre crop, [-1,1]) -> I3D logits (B,num_classes). */
+int svg_fvd_logits(svg_ctx* ctx, const uint8_t* videos, int B, int T, int H, int W, float* logits, void* stream);
+/* the preprocessing alone: out (B,3,T,224,224) f32 */
+int svg_fvd_preprocess(svg_ctx* ctx, const uint8_t* videos, int B, int T, int H, int W, float* out, void* stream);
+/* fvd_2.frechet_distance (fvd_2.py:66-78): x1 (n1,d), x2 (n2,d) f32 device embeddings -> *out (HOST double; synchronises the stream).
+ * Means / unbiased covariances in f64, the two symmetric square roots (fvd_2.py:22-33, SVD there) by a Jacobi eigen-decomposition. */
+int svg_frechet_distance(svg_ctx* ctx, const float* x1, int n1, const float* x2, int n2, int d, double* out, void* stream);
 
 /* ---- VAE ------------------------------------------------------------------------------------ */
 /* img: u8 NHWC (N,srcH,srcW,3); nearest-resized to (H,W) on the fly when they differ.

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVG_LIB") or os.path.join(_HERE, "libsvg_hip.so")   # $SVG_LIB: A/B another build of the same ABI
 
-SVG_TRANSFORMER, SVG_VAE, SVG_UNET, SVG_CLIP_TEXT, SVG_MINILM = 0, 1, 2, 3, 4
+SVG_TRANSFORMER, SVG_VAE, SVG_UNET, SVG_CLIP_TEXT, SVG_MINILM, SVG_I3D = 0, 1, 2, 3, 4, 5
 SVG_ERR_RUNTIME, SVG_ERR_INVALID = -1, -2        # enum svg_status
 
 _lib = None
@@ -48,6 +48,10 @@ SIGNATURES = {
     "svg_transformer_tensor": [_vp, _i, C.c_char_p, _vp, _i64, _vp],
     "svg_clip_text_forward": [_vp, _vp, _i, _i, _vp, _vp],
     "svg_minilm_encode": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
+    "svg_i3d_forward": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "svg_fvd_logits": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "svg_fvd_preprocess": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "svg_frechet_distance": [_vp, _vp, _i, _vp, _i, _i, C.POINTER(C.c_double), _vp],
     "svg_vae_encode": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "svg_vae_decode": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp],
     "svg_unet_forward": [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp],
@@ -301,6 +305,41 @@ class Context:
         hid = torch.empty((B, T, d_model), device=self.device, dtype=torch.float32) if return_hidden else None
         self.check(self.lib.svg_minilm_encode(self.h, _ptr(ids), _ptr(lens), B, T, _ptr(out), _ptr(hid), _stream()), "svg_minilm_encode")
         return (out, hid) if return_hidden else out
+
+    # ---- FVD evaluation ---------------------------------------------------------------------------
+    def i3d_forward(self, x, num_classes=400):
+        """x (B,3,T,224,224) f32 in [-1,1] -> I3D logits (B,num_classes)"""
+        x = x.to(self.device).contiguous().float()
+        B, c, T, H, W = x.shape
+        assert c == 3
+        out = torch.empty((B, num_classes), device=self.device, dtype=torch.float32)
+        self.check(self.lib.svg_i3d_forward(self.h, _ptr(x), B, T, H, W, _ptr(out), _stream()), "svg_i3d_forward")
+        return out
+
+    def fvd_logits(self, videos_u8, num_classes=400):
+        """videos (B,T,H,W,3) uint8 -> I3D logits (B,num_classes) (fvd_2.get_fvd_logits: preprocess + network)"""
+        v = torch.as_tensor(videos_u8).to(self.device).contiguous()
+        assert v.dtype == torch.uint8 and v.dim() == 5 and v.shape[-1] == 3
+        B, T, H, W, _ = v.shape
+        out = torch.empty((B, num_classes), device=self.device, dtype=torch.float32)
+        self.check(self.lib.svg_fvd_logits(self.h, _ptr(v), B, T, H, W, _ptr(out), _stream()), "svg_fvd_logits")
+        return out
+
+    def fvd_preprocess(self, videos_u8):
+        v = torch.as_tensor(videos_u8).to(self.device).contiguous()
+        B, T, H, W, _ = v.shape
+        out = torch.empty((B, 3, T, 224, 224), device=self.device, dtype=torch.float32)
+        self.check(self.lib.svg_fvd_preprocess(self.h, _ptr(v), B, T, H, W, _ptr(out), _stream()), "svg_fvd_preprocess")
+        return out
+
+    def frechet_distance(self, x1, x2):
+        """(n1,d), (n2,d) embeddings -> float (fvd_2.frechet_distance)"""
+        x1 = x1.to(self.device).flatten(1).contiguous().float()
+        x2 = x2.to(self.device).flatten(1).contiguous().float()
+        out = C.c_double(0.0)
+        self.check(self.lib.svg_frechet_distance(self.h, _ptr(x1), x1.shape[0], _ptr(x2), x2.shape[0], x1.shape[1], C.byref(out), _stream()),
+                   "svg_frechet_distance")
+        return float(out.value)
 
     def vae_encode(self, img_u8, H=None, W=None, eps=None, return_moments=False):
         """img_u8: (N,h,w,3) uint8 on device; nearest-resized to (H,W) when given."""

@@ -10,6 +10,7 @@ void destroy_models(svg_ctx* ctx) {
   if (ctx->unet) { ctx->unet->ws.clear(); delete ctx->unet; ctx->unet = nullptr; }
   if (ctx->clip) { ctx->clip->ws.clear(); delete ctx->clip; ctx->clip = nullptr; }
   if (ctx->minilm) { ctx->minilm->ws.clear(); delete ctx->minilm; ctx->minilm = nullptr; }
+  if (ctx->i3d) { ctx->i3d->ws.clear(); delete ctx->i3d; ctx->i3d = nullptr; }
 }
 
 static WeightStore* store_of(svg_ctx* ctx, int model, bool create) {
@@ -19,6 +20,7 @@ static WeightStore* store_of(svg_ctx* ctx, int model, bool create) {
     case SVG_UNET: if (!ctx->unet && create) ctx->unet = new_unet_bf16(); return ctx->unet ? &ctx->unet->ws : nullptr;
     case SVG_CLIP_TEXT: if (!ctx->clip && create) ctx->clip = new ClipTextModel(); return ctx->clip ? &ctx->clip->ws : nullptr;
     case SVG_MINILM: if (!ctx->minilm && create) ctx->minilm = new MiniLmModel(); return ctx->minilm ? &ctx->minilm->ws : nullptr;
+    case SVG_I3D: if (!ctx->i3d && create) ctx->i3d = new I3dModel(); return ctx->i3d ? &ctx->i3d->ws : nullptr;
     default: throw SvgError("unknown model id " + std::to_string(model));
   }
 }
@@ -45,6 +47,7 @@ int svg_model_configure(svg_ctx* ctx, int model, const char* kv) {
     else if (model == SVG_VAE) ctx->vae->configure(kv);
     else if (model == SVG_CLIP_TEXT) ctx->clip->configure(kv);
     else if (model == SVG_MINILM) ctx->minilm->configure(kv);
+    else if (model == SVG_I3D) ctx->i3d->configure(kv);
     else ctx->unet->configure(kv);
     return 0;
   } catch (const std::exception& e) { return svg_fail(ctx, e); }
@@ -60,6 +63,7 @@ int svg_load_weight(svg_ctx* ctx, int model, const char* name, const float* data
     else if (model == SVG_VAE) ctx->vae->ready = false;
     else if (model == SVG_CLIP_TEXT) ctx->clip->ready = false;
     else if (model == SVG_MINILM) ctx->minilm->ready = false;
+    else if (model == SVG_I3D) ctx->i3d->ready = false;
     else ctx->unet->ready = false;
     return 0;
   } catch (const std::exception& e) { return svg_fail(ctx, e); }
@@ -76,6 +80,7 @@ int svg_finalize(svg_ctx* ctx, int model, int64_t* n_params) {
       else if (model == SVG_VAE) ctx->vae->finalize(ctx, n_params);
       else if (model == SVG_CLIP_TEXT) ctx->clip->finalize(ctx, n_params);
       else if (model == SVG_MINILM) ctx->minilm->finalize(ctx, n_params);
+      else if (model == SVG_I3D) ctx->i3d->finalize(ctx, n_params);
       else ctx->unet->finalize(ctx, n_params);
     } catch (...) { ctx->cur_model = svg_ctx::kCtxSlot; throw; }
     ctx->cur_model = svg_ctx::kCtxSlot;
@@ -134,6 +139,7 @@ const char* svg_model_dtype(svg_ctx* ctx, int model) {
   if (model == SVG_TRANSFORMER) return ctx->xf ? "f32" : nullptr;
   if (model == SVG_CLIP_TEXT) return ctx->clip ? "f32" : nullptr;
   if (model == SVG_MINILM) return ctx->minilm ? "f32" : nullptr;
+  if (model == SVG_I3D) return ctx->i3d ? "f32" : nullptr;
   return nullptr;
 }
 

@@ -128,8 +128,9 @@ struct svg_ctx {
   struct UnetIface* unet = nullptr;
   struct ClipTextModel* clip = nullptr;
   struct MiniLmModel* minilm = nullptr;
-  static constexpr int kCtxSlot = 5;                 // owned[] index of allocations that belong to the context itself
-  std::vector<void*> owned[6];   // device allocations per model id (kCtxSlot = context) freed at reconfigure / destroy
+  struct I3dModel* i3d = nullptr;
+  static constexpr int kCtxSlot = 6;                 // owned[] index of allocations that belong to the context itself
+  std::vector<void*> owned[7];   // device allocations per model id (kCtxSlot = context) freed at reconfigure / destroy
   int cur_model = kCtxSlot;
   uint64_t* seed_scratch = nullptr;   // device word for svg_op_dropout_mask
   void* dalloc(int64_t bytes);

@@ -75,6 +75,22 @@ struct MiniLmModel {
   void encode(svg_ctx* ctx, const int32_t* ids, const int32_t* lens, int B, int T, float* out, float* hidden, hipStream_t s);
 };
 
+// ---- I3D (FVD evaluation: evaluation/pytorch_i3d.py, evaluation/fvd_2.py; f32, channels-last, BatchNorm folded at finalize) ----
+struct I3dModel {
+  WeightStore ws;
+  int num_classes = 400;
+  bool ready = false;
+  struct Unit { float* w = nullptr; float* b = nullptr; int cin = 0, cin_pad = 0, cout = 0, k = 1; };
+  struct Mixed { Unit b0, b1a, b1b, b2a, b2b, b3b; };
+  Unit conv1a, conv2b, conv2c, logits;
+  std::vector<Mixed> mixed;
+  void configure(const char* kv);
+  void finalize(svg_ctx* ctx, int64_t* n_params);
+  Unit load_unit(svg_ctx* ctx, const std::string& prefix, int cin, int cout, int k, bool bn);
+  // x (B,3,T,H,W) f32 in [-1,1] (H = W = 224), or video_u8 (B,T,H,W,3) uint8 (preprocessed inside) -> logits (B,num_classes)
+  void forward(svg_ctx* ctx, const float* x_ncthw, const uint8_t* video_u8, int B, int T, int H, int W, float* logits, hipStream_t s);
+};
+
 void xf_train_free(XfModel* m);
 void destroy_models(svg_ctx* ctx);
 

@@ -62,3 +62,27 @@ def gather_clips_packed(tensors, n_clips):
         res.append(piece)
         off += w
     return res
+
+
+def gather_rows(local):
+    """evaluation/fvd_2.py:103-107 all_gather: every rank's (n, ...) rows concatenated in rank order (equal n per rank there;
+    here ragged counts are allowed: one small all_gather of the counts, then the padded payloads)."""
+    rank, ws = world()
+    if ws == 1:
+        return local
+    dev = local.device
+    host = dist.get_backend() == "gloo"
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device="cpu" if host else dev)
+    counts = [torch.zeros_like(n) for _ in range(ws)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    cmax = max(counts)
+    pad = local
+    if local.shape[0] < cmax:
+        pad = torch.cat([local, local.new_zeros((cmax - local.shape[0],) + tuple(local.shape[1:]))])
+    pad = pad.contiguous()
+    if host and pad.is_cuda:
+        pad = pad.cpu()
+    out = [torch.empty_like(pad) for _ in range(ws)]
+    dist.all_gather(out, pad)
+    return torch.cat([o[:c] for o, c in zip(out, counts)]).to(dev)

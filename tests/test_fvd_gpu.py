@@ -1,0 +1,57 @@
+"""GPU: the FVD evaluation in the library — I3D forward (implicit-GEMM 3-D convolutions on f32 MFMA), the uint8 -> I3D input
+preprocessing and the Fréchet distance (Jacobi eigen-decomposition, f64) — against the golden outputs of the LIVE reference modules
+(tests/golden/i3d_fvd.pt: evaluation/pytorch_i3d.py, evaluation/fvd_2.py) and the CPU oracle on the same seeded weights."""
+import os
+import sys
+
+import pytest
+import torch
+
+from conftest import margin, rel_l2
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import i3d_oracle as IO  # noqa: E402
+from sd_video_gen_amd import fvd  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLD = torch.load(os.path.join(ROOT, "tests", "golden", "i3d_fvd.pt"), weights_only=False)
+
+
+@pytest.fixture(scope="module")
+def i3d(ctx):
+    assert fvd.i3d_shapes() == IO.i3d_shapes()
+    m = fvd.I3D(IO.seeded_i3d_weights(GOLD["w_seed"]), ctx)
+    assert m.n_params == 12_711_881 - 57
+    return m
+
+
+def test_preprocess_against_reference_golden(ctx):
+    x = ctx.fvd_preprocess(GOLD["video"]).cpu()
+    assert x.shape == (2, 3, 16, 224, 224)
+    margin("fvd preprocess vs the reference's (bilinear resize, crop, [-1,1])", rel_l2(x[:, :, ::5, ::37, ::41], GOLD["pre_slice"]), 2e-6)
+    assert rel_l2(x, IO.preprocess(GOLD["video"])) < 2e-6
+
+
+def test_i3d_logits_against_reference_golden(ctx, i3d):
+    logits = fvd.get_fvd_logits(torch.cat([GOLD["video"]] * 8), i3d).cpu()          # 16 clips: one get_logits batch
+    assert logits.shape == (16, 400) and torch.isfinite(logits).all()
+    margin("I3D logits (12.7 M parameters, 16 x 224 x 224 clips) vs the live reference module", rel_l2(logits[:2], GOLD["logits"]), 2e-5)
+    assert torch.equal(logits[:2], logits[14:16])                                    # rows of a batch are independent
+    # the float-input entry point on the oracle's preprocessing
+    lg2 = i3d(IO.preprocess(GOLD["video"]).cuda()).cpu()
+    assert rel_l2(lg2, GOLD["logits"]) < 2e-5
+
+
+def test_frechet_distance_against_reference_golden(ctx):
+    e1, e2, e3 = IO.fvd_test_embeddings(GOLD["emb_seed"])
+    for a, b, key in ((e1, e2, "fd_12"), (e1, e3, "fd_13"), (e3, e3[:300], "fd_33")):
+        got = ctx.frechet_distance(a.cuda(), b.cuda())
+        margin("frechet distance %s vs the reference's (f32 SVD there, f64 Jacobi here)" % key, abs(got - GOLD[key]) / abs(GOLD[key]), 5e-4, unit="rel")
+    assert abs(ctx.frechet_distance(e1.cuda(), e1.cuda())) < 1e-6 * 3000          # identical sets: exactly symmetric arithmetic -> ~0
+    # against the float64 closed form on a small full-rank case
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(500, 16, generator=g)
+    b = torch.randn(400, 16, generator=g) * 1.7 + 0.2
+    ref = float(IO.frechet_distance(a.double(), b.double()))
+    assert abs(ctx.frechet_distance(a.cuda(), b.cuda()) - ref) < 1e-5 * abs(ref)
