@@ -55,7 +55,7 @@ int svg_model_configure(svg_ctx* ctx, int model, const char* kv) {
 
 int svg_load_weight(svg_ctx* ctx, int model, const char* name, const float* data, const int64_t* shape, int ndim) {
   try {
-    SVG_CHECK(ctx && name && data && shape && ndim >= 1 && ndim <= 4, "svg_load_weight: bad arguments");
+    SVG_CHECK(ctx && name && data && shape && ndim >= 1 && ndim <= 5, "svg_load_weight: bad arguments");
     WeightStore* ws = store_of(ctx, model, true);
     HIP_OK(hipSetDevice(ctx->device));
     ws->put(ctx, name, data, shape, ndim);

@@ -11,6 +11,7 @@
 // An evaluation tool, not the hot path: written for exactness and reasonable speed (a few TFLOP/s), not for the roofline.
 #include "kernels.h"
 #include <algorithm>
+#include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -278,6 +279,20 @@ __global__ void __launch_bounds__(1024) jacobi_eig_kernel(double* __restrict__ A
       }
       __syncthreads();
     }
+    // converged?  sum of squares off the diagonal against the diagonal's (every thread computes the same decision)
+    __shared__ double red[2][16];
+    double off = 0.0, dg = 0.0;
+    for (int i = tid; i < d * d; i += nt) {
+      const double v = A[i];
+      if (i / d == i % d) dg += v * v; else off += v * v;
+    }
+    for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o); dg += __shfl_xor(dg, o); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = off; red[1][tid >> 6] = dg; }
+    __syncthreads();
+    off = 0.0; dg = 0.0;
+    for (int w = 0; w < nt / 64; ++w) { off += red[0][w]; dg += red[1][w]; }
+    __syncthreads();
+    if (off <= 1e-30 * dg) break;
   }
 }
 // s[k] = f(A[k][k]) with f = the reference's thresholded square root (fvd_2.py:24-26: s < eps ? s : sqrt(s)) on max(lambda, 0)
@@ -348,18 +363,19 @@ void frechet_distance(const float* x1, int n1, const float* x2, int n2, int d, d
   double* S1 = cs + 2 * d; double* S2 = S1 + (int64_t)d * d; double* Wk = S2 + (int64_t)d * d; double* V = Wk + (int64_t)d * d;
   double* R = V + (int64_t)d * d; double* T2 = R + (int64_t)d * d;
   const dim3 g1((d + 127) / 128), g2((d + 127) / 128, d);
+  const int sweeps = getenv("SVG_JACOBI_SWEEPS") ? atoi(getenv("SVG_JACOBI_SWEEPS")) : 40;      // an upper bound: the kernel stops when the off-diagonal mass is below 1e-30 of the diagonal's (10-12 sweeps full rank, ~20 rank-deficient)
   hipLaunchKernelGGL(col_mean_kernel, g1, dim3(128), 0, s, x1, m1, n1, d);
   hipLaunchKernelGGL(col_mean_kernel, g1, dim3(128), 0, s, x2, m2, n2, d);
   hipLaunchKernelGGL(cov_kernel, g2, dim3(128), 0, s, x1, m1, S1, n1, d);
   hipLaunchKernelGGL(cov_kernel, g2, dim3(128), 0, s, x2, m2, S2, n2, d);
   // sqrt(S1) = V f(L) V^T  (fvd_2.py:22-26 takes it from the SVD: for a symmetric PSD matrix the same factors)
   HIP_OK(hipMemcpyAsync(Wk, S1, (size_t)d * d * sizeof(double), hipMemcpyDeviceToDevice, s));
-  hipLaunchKernelGGL(jacobi_eig_kernel, dim3(1), dim3(1024), 0, s, Wk, V, d, 12, cs);
+  hipLaunchKernelGGL(jacobi_eig_kernel, dim3(1), dim3(1024), 0, s, Wk, V, d, sweeps, cs);
   hipLaunchKernelGGL(diag_sqrt_kernel, g1, dim3(128), 0, s, Wk, sq, d, 1e-10);
   hipLaunchKernelGGL(matmul_f64_kernel, g2, dim3(128), 0, s, V, sq, V, 1, R, d);          // R = V diag(sq) V^T = sqrt(S1)
   hipLaunchKernelGGL(matmul_f64_kernel, g2, dim3(128), 0, s, R, (const double*)nullptr, S2, 0, T2, d);
   hipLaunchKernelGGL(matmul_f64_kernel, g2, dim3(128), 0, s, T2, (const double*)nullptr, R, 0, Wk, d);   // sqrt(S1) S2 sqrt(S1)
-  hipLaunchKernelGGL(jacobi_eig_kernel, dim3(1), dim3(1024), 0, s, Wk, V, d, 12, cs);
+  hipLaunchKernelGGL(jacobi_eig_kernel, dim3(1), dim3(1024), 0, s, Wk, V, d, sweeps, cs);
   hipLaunchKernelGGL(diag_sqrt_kernel, g1, dim3(128), 0, s, Wk, sq, d, 1e-10);           // trace of the square root = sum of sqrt(eigenvalues)
   hipLaunchKernelGGL(fd_finish_kernel, dim3(1), dim3(1), 0, s, S1, S2, sq, m1, m2, out, d);
   check_launch("frechet_distance");

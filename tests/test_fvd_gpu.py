@@ -47,7 +47,10 @@ def test_frechet_distance_against_reference_golden(ctx):
     e1, e2, e3 = IO.fvd_test_embeddings(GOLD["emb_seed"])
     for a, b, key in ((e1, e2, "fd_12"), (e1, e3, "fd_13"), (e3, e3[:300], "fd_33")):
         got = ctx.frechet_distance(a.cuda(), b.cuda())
-        margin("frechet distance %s vs the reference's (f32 SVD there, f64 Jacobi here)" % key, abs(got - GOLD[key]) / abs(GOLD[key]), 5e-4, unit="rel")
+        # the reference evaluates in f32 (SVD + a difference of traces of ~3000): its own value carries ~1e-3 of noise
+        margin("frechet distance %s vs the reference's value (f32 SVD there, f64 Jacobi here)" % key, abs(got - GOLD[key]) / abs(GOLD[key]), 3e-3, unit="rel")
+        ref64 = float(IO.frechet_distance(a.double(), b.double()))                 # the same formula (the pinned oracle) in float64
+        margin("frechet distance %s vs the oracle in float64" % key, abs(got - ref64) / abs(ref64), 1e-6, unit="rel")
     assert abs(ctx.frechet_distance(e1.cuda(), e1.cuda())) < 1e-6 * 3000          # identical sets: exactly symmetric arithmetic -> ~0
     # against the float64 closed form on a small full-rank case
     g = torch.Generator().manual_seed(3)
