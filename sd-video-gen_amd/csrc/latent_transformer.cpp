@@ -163,7 +163,7 @@ void XfModel::forward(svg_ctx* ctx, const float* src, const float* tgt, int B, i
                       const int32_t* pe_row, float* out, hipStream_t s, const float* text, const float* src_pad, const float* tgt_pad) {
   SVG_CHECK(ready, "transformer: svg_finalize has not been called");
   SVG_CHECK((text_dim > 0) == (text != nullptr), "transformer: the text-conditioned variant needs (and only it takes) a text embedding");
-  SVG_CHECK(B >= 1 && Ts >= 1 && Tt >= 1 && Ts <= 16 && Tt <= 16, "transformer: B=%d Ts=%d Tt=%d unsupported", B, Ts, Tt);
+  SVG_CHECK(B >= 1 && Ts >= 1 && Tt >= 1 && Ts <= 32 && Tt <= 32, "transformer: B=%d Ts=%d Tt=%d unsupported (sequences up to 32 tokens)", B, Ts, Tt);
   SVG_CHECK(pe_row || B <= 64, "transformer: batch %d > max_len 64 of the positional table", B);
   const int Tmax = std::max(Ts, Tt);
   const int Bc = std::max(1, 336 / Tmax);       // xf_gemm streams W once for up to 336 rows (56 clips x 6 tokens)

@@ -308,13 +308,13 @@ __global__ void xf_embed_post_kernel(const float* __restrict__ emb, const float*
   }
 }
 
-// one workgroup per (batch row, head); Tq, Tk <= 16
+// one workgroup per (batch row, head); Tq, Tk <= 32 (the text loop of prediction/predict_text.py conditions on 16 frames + SOS)
 // kpad (B,Tk) or null: additive key-padding bias of batch row b (nn.Transformer's *_key_padding_mask: 0 / -inf, or a float bias)
 __global__ void __launch_bounds__(256) xf_attention_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                                                             const float* __restrict__ v, int ldk, const float* __restrict__ mask,
                                                             const float* __restrict__ kpad,
                                                             float* __restrict__ o, int Tq, int Tk, int B, int heads, int hd) {
-  __shared__ float sc[16][17];
+  __shared__ float sc[32][33];
   const int b = blockIdx.x, hh = blockIdx.y;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const float scale = rsqrtf((float)hd);
@@ -534,7 +534,7 @@ void xf_embed_post(const float* emb, const float* pe, const int32_t* pe_row, con
 
 void xf_attention(const float* q, int ldq, const float* k, const float* v, int ldk, const float* mask, float* o, int Tq, int Tk,
                   int B, int heads, int hd, hipStream_t s, const float* kpad) {
-  SVG_CHECK(Tq <= 16 && Tk <= 16, "xf_attention: sequence length %d/%d > 16", Tq, Tk);
+  SVG_CHECK(Tq <= 32 && Tk <= 32, "xf_attention: sequence length %d/%d > 32", Tq, Tk);
   hipLaunchKernelGGL(xf_attention_kernel, dim3(B, heads), dim3(256), 0, s, q, ldq, k, v, ldk, mask, kpad, o, Tq, Tk, B, heads, hd);
   check_launch("xf_attention");
 }

@@ -35,7 +35,8 @@ def sample_clips(model, sd_utils, clips_u8, pred_frames, denoise=False, start_st
                  cls_list=None, cpu_noise=False, latent_denoise=False):
     """The per-clip loop of prediction/predict.py:117-197 for C independent clips in lock step, device resident.
 
-    clips_u8: (C,5,F,F,3) uint8 conditioning frames on the device.  Every stage is batched over clips; a clip's
+    clips_u8: (C,T,F,F,3) uint8 conditioning frames on the device (T = 5 in prediction/predict.py; the FVD loop of
+    prediction/predict_text.py conditions on 16-frame UCF clips: the first forward sees SOS + T tokens, T <= 31).  Every stage is batched over clips; a clip's
     result equals running it alone (PE row 0 per clip, per-clip noise generators seeded ``seeds[c]``).  The noise
     draws follow the reference's order: VAE sample of the 5 conditioning frames; then per predicted frame the VAE
     sample @512, add_noise (start_step>0), the VAE sample @F.  The four host crossings per frame of the reference
@@ -53,7 +54,7 @@ def sample_clips(model, sd_utils, clips_u8, pred_frames, denoise=False, start_st
         assert sd_utils.unet is not None and sd_utils.unet.ctx is ctx, "sample_clips(denoise=True) needs SDUtils built with --denoise"
     dev = clips_u8.device
     C, T, F = clips_u8.shape[0], clips_u8.shape[1], clips_u8.shape[2]
-    assert T == 5, "the reference conditions on 5 frames (predict.py:57, window hard-coded at :196)"
+    assert 2 <= T <= 31, "conditioning frames: 5 in predict.py:57, 16 in predict_text.py:133 (the library serves sequences up to 32 tokens)"
     L = F // 8
     D = 4 * L * L
     if seeds is None:

@@ -58,3 +58,40 @@ def test_frechet_distance_against_reference_golden(ctx):
     b = torch.randn(400, 16, generator=g) * 1.7 + 0.2
     ref = float(IO.frechet_distance(a.double(), b.double()))
     assert abs(ctx.frechet_distance(a.cuda(), b.cuda()) - ref) < 1e-5 * abs(ref)
+
+
+def test_predict_text_main_end_to_end(tmp_path, monkeypatch):
+    """`python -m prediction.predict_text` on a made-up UCF-101 tree of pre-extracted frames: class names -> MiniLM -> text-conditioned
+    Transformer -> generated frames -> I3D logits of 16 real and 16 generated clips -> Fréchet distance (prediction/predict_text.py:76-321)."""
+    import numpy as np
+    from sd_video_gen_amd import predict_text as PT
+    import test_boundary_gpu as TB                                # tiny SD networks in a diffusers-format directory
+    from oracle import sd_oracle as SO
+    TB.write_diffusers_dir(str(tmp_path / "sd"), SO.seeded_weights(SO.vae_shapes(TB.VCFG), 3), SO.seeded_weights(SO.unet_shapes(TB.UCFG), 4))
+    monkeypatch.setenv("SVG_SD_WEIGHTS", str(tmp_path / "sd"))
+    monkeypatch.setenv("SVG_ALLOW_SYNTHETIC_WEIGHTS", "1")        # Transformer / MiniLM / I3D: seeded parameters (no checkpoints offline)
+    monkeypatch.setenv("SVG_FVD_CLIPS", "16")
+    monkeypatch.chdir(tmp_path)
+    root = tmp_path / "data" / "UCF-101" / "UCF-101-wallpushups"
+    lab = tmp_path / "data" / "UCF101TrainTestSplits-RecognitionTask" / "ucfTrainTestlist"
+    os.makedirs(lab)
+    rng = np.random.default_rng(1)
+    lines = []
+    for cls, n in (("WallPushups", 2), ("PlayingGuitar", 1)):
+        os.makedirs(root / cls)
+        for v in range(n):
+            name = "v_%s_g01_c%02d" % (cls, v + 1)
+            base = rng.integers(0, 256, (1, 30, 40, 3))
+            np.save(root / cls / (name + ".npy"), np.clip(base + rng.integers(-20, 20, (200, 30, 40, 3)), 0, 255).astype(np.uint8))
+            lines.append("%s/%s.avi" % (cls, name))
+    (lab / "testlist01.txt").write_text("\n".join(lines) + "\n")
+    argv = ["--dataset", "ucf-wallpushups", "--config", "model_10_26", "--mode", "test", "--pred_frames", "16", "--save_output", "True"]         # 16 generated frames per clip: what I3D takes
+    torch.manual_seed(11)                                         # the Transformer's initial parameters stand for a checkpoint
+    val = PT.main(argv)
+    # 200 frames at 25 -> 3 fps: 24 frames per video -> 9 clips of 16 each, 27 in all; 16 sampled: one group of real, one of generated clips
+    assert val is not None and np.isfinite(val) and val > 0
+    assert os.path.isdir(tmp_path / "outputs_pred" / "model_10_26_0_test")
+    torch.manual_seed(11)
+    assert PT.main(argv) == val                                   # seeded end to end
+    with pytest.raises(ValueError, match="Invalid dataset name"):
+        PT.main(["--dataset", "ucf-cooking", "--config", "model_10_26"])
