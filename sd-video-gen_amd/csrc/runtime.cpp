@@ -150,7 +150,7 @@ std::unordered_map<std::string, std::vector<int64_t>> parse_kv(const char* kv) {
 
 extern "C" {
 
-const char* svg_version(void) { return "svg_hip 0.2 (gfx950, h16) src " SVG_SRC_HASH; }
+const char* svg_version(void) { return "svg_hip 0.3 (gfx950, bf16+fp16) src " SVG_SRC_HASH; }
 
 int svg_create(int device_id, svg_ctx** out) {
   svg_ctx* ctx = nullptr;

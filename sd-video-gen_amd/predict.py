@@ -288,13 +288,20 @@ def main(argv=None):
         clips = torch.from_numpy(np.stack(items))
         if clips.shape[2] != F or clips.shape[3] != F:
             raise ValueError("frames are %dx%d but config %s has FRAME_SIZE %d" % (clips.shape[2], clips.shape[3], args.config, F))
-    elif "ucf" in args.dataset:
-        if args.dataset not in ("ucf", "ucf-wallpushups", "ucf-workout", "ucf-instruments") and not args.dataset.endswith(("wallpushups", "workout", "instruments")):
-            raise ValueError("Invalid dataset name")                                                      # predict.py:70
-        if not args.folder:
-            raise ValueError("UCF-101 clips are read from video files by torchvision / PyAV in the reference (predict.py:60-109); "
-                             "extract frames to PNG folders and pass --folder")
-        clips = _png_clips(args.folder, F)
+    elif "ucf" in args.dataset:                                                                           # predict.py:60-109
+        from .loaders import UCF101Frames, ucf_dirs, ucf_transform
+        ucf_data_dir, ucf_label_dir = ucf_dirs(args.dataset)              # ValueError('Invalid dataset name') like :70
+        if args.folder:                                                   # pre-extracted frames under <folder>/<the reference's layout>
+            ucf_data_dir, ucf_label_dir = os.path.join(args.folder, ucf_data_dir), os.path.join(args.folder, ucf_label_dir)
+        if rank == 0:
+            print("Loading UCF dataset from", ucf_data_dir)
+        train = args.mode == "train"
+        ucf = UCF101Frames(ucf_data_dir, ucf_label_dir, frames_per_clip=5, train=train, transform=ucf_transform(F),
+                           frame_rate=3 if train else None)               # :99-106
+        if len(ucf) == 0:
+            raise ValueError("no 5-frame clips under %s for the %s fold" % (ucf_data_dir, args.mode))
+        n_clips = min(len(ucf), int(os.environ.get("SVG_MAX_CLIPS", "256")))
+        clips = torch.from_numpy(np.stack([ucf[i][0] for i in range(n_clips)]))          # unshuffled: clip c keeps its seed
     elif args.folder:
         clips = _png_clips(args.folder, F)
     else:

@@ -1,0 +1,55 @@
+// Host-memory stand-in for the HIP runtime, for ONE purpose: running the library's host C++ (context, workspace arena and its
+// dry-pass planner, model slots, weight store, graph builders, split / chunk logic, the C ABI's error paths) under
+// AddressSanitizer + UndefinedBehaviorSanitizer in the build container, which has no GPU.  "Device" memory is malloc'ed host
+// memory, copies are memcpy, kernel launches do nothing (the sources are compiled --cuda-host-only, so a launch is a call to
+// hipLaunchKernel below), streams / events / graphs are inert tokens.  Never linked into libsvg_hip.so.
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
+
+extern "C" {
+hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t) {
+  for (size_t r = 0; r < h; ++r) memmove((char*)d + r * dp, (const char*)s + r * sp, w);
+  return hipSuccess;
+}
+hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+hipError_t hipGetDevicePropertiesR0600(hipDeviceProp_t* p, int) {
+  memset(p, 0, sizeof(*p));
+  strcpy(p->gcnArchName, "gfx950:sramecc+:xnack-");
+  p->multiProcessorCount = 256;
+  return hipSuccess;
+}
+const char* hipGetErrorString(hipError_t) { return "stub"; }
+hipError_t hipGetLastError() { return hipSuccess; }
+hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)malloc(8); return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e) { free((void*)e); return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipSuccess; }
+hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = (hipGraph_t)malloc(8); return hipSuccess; }
+hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t, hipGraphNode_t*, char*, size_t) { *e = (hipGraphExec_t)malloc(8); return hipSuccess; }
+hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipSuccess; }
+hipError_t hipGraphExecDestroy(hipGraphExec_t e) { free((void*)e); return hipSuccess; }
+hipError_t hipGraphDestroy(hipGraph_t g) { free((void*)g); return hipSuccess; }
+hipError_t hipLaunchKernel(const void*, dim3, dim3, void**, size_t, hipStream_t) { return hipSuccess; }
+// launch plumbing of the host-side kernel stubs
+static thread_local struct { dim3 g, b; size_t s; hipStream_t st; } g_cfg;
+hipError_t __hipPushCallConfiguration(dim3 g, dim3 b, size_t s, hipStream_t st) { g_cfg.g = g; g_cfg.b = b; g_cfg.s = s; g_cfg.st = st; return hipSuccess; }
+hipError_t __hipPopCallConfiguration(dim3* g, dim3* b, size_t* s, hipStream_t* st) { *g = g_cfg.g; *b = g_cfg.b; *s = g_cfg.s; *st = g_cfg.st; return hipSuccess; }
+void** __hipRegisterFatBinary(const void*) { static void* h; return &h; }
+void __hipRegisterFunction(void**, const void*, char*, const char*, unsigned, void*, void*, void*, void*, int*) {}
+void __hipUnregisterFatBinary(void**) {}
+}
