@@ -522,8 +522,11 @@ static int plan_splitk(const GemmArgs& g) {
   return 1;
 }
 
+bool gemm_fused_qkv_supported(const GemmArgs& g) { return g.vt_out != nullptr && gemm_ws_supported(g); }
+
 void gemm_auto(svg_ctx* ctx, GemmArgs g, hipStream_t s, int prof_kind) {
   if (g.n_valid <= 0) g.n_valid = g.N;
+  SVG_CHECK(!g.vt_out || gemm_ws_supported(g), "gemm: a fused q | k | V^T problem (vt_out) needs the weight-stationary kernel (ask gemm_fused_qkv_supported)");
   g.splitk = 1;
   const int sk = plan_splitk(g);
   g.splitk = sk;

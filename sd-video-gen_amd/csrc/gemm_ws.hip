@@ -31,8 +31,8 @@ constexpr int WS_ROWS = 128;
 constexpr int WS_PIECES = 100;                 // (n-tile, k-step) pieces of a column group: 10 x 10 at K = 320, 5 x 20 at K = 640
 constexpr int WS_W_BYTES = WS_PIECES * 1024;
 
-// KS = K / 32; RES: residual present
-template <int KS, bool RES>
+// KS = K / 32; RES: residual present; QKV: the fused q | k | V^T projection (column groups from GemmArgs::vt_n0 on write V^T)
+template <int KS, bool RES, bool QKV = false>
 __global__ void __launch_bounds__(512, 2) gemm_ws_kernel(const GemmArgs g, int n_groups, int n_slices) {
   constexpr int NTG = WS_PIECES / KS;           // n-tiles (16 columns) per column group
   constexpr int GC = NTG * 16;                  // columns per group
@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(512, 2) gemm_ws_kernel(const GemmArgs g, int n
   const int slice = xcd + 8 * (idx / n_groups);
   if (slice >= n_slices) return;
   const int n0 = grp * GC;
+  const bool is_vt = QKV && n0 >= g.vt_n0;                      // workgroup-uniform: a V^T column group of a fused q | k | V^T launch
   const int tiles = (g.M + WS_ROWS - 1) / WS_ROWS;
   const bool fold = g.ln_rs != nullptr, emit_ln = g.ln_part != nullptr, emit_gn = g.gn_part != nullptr;
 
@@ -82,7 +83,8 @@ __global__ void __launch_bounds__(512, 2) gemm_ws_kernel(const GemmArgs g, int n
   const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (unsigned)((((int64_t)g.M - 1) * g.lda + g.K) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t srdR = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? g.residual : g.A), 0,
                                                                         RES ? (unsigned)((((int64_t)g.M - 1) * g.ldr + g.N) * 2) : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t srdC = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (unsigned)((((int64_t)g.M - 1) * g.ldc + g.N) * 2), 0x00020000);
+  const int n_c = QKV ? g.vt_n0 : g.N;                           // columns that go to C
+  const __amdgpu_buffer_rsrc_t srdC = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (unsigned)((((int64_t)g.M - 1) * g.ldc + n_c) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t srdS = __builtin_amdgcn_make_buffer_rsrc((void*)(fold ? g.ln_rs : (const float*)g.A), 0, fold ? (unsigned)g.M * 4u : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t srdT = __builtin_amdgcn_make_buffer_rsrc((void*)(fold ? g.ln_rm : (const float*)g.A), 0, fold ? (unsigned)g.M * 4u : 0u, 0x00020000);
   auto load_tile = [&](int t, h16x8 (&af)[KS], uint2 (&rf)[NTG], float& lrs, float& lrm) {
@@ -124,6 +126,37 @@ __global__ void __launch_bounds__(512, 2) gemm_ws_kernel(const GemmArgs g, int n
     const char* wl = smem + lane * 16;
     float ln1 = 0.f, ln2 = 0.f;
     float* sc = s_gn + parity * (8 * GC * 2);
+    if (QKV && is_vt) {
+      // V^T group: the same fragments with the MFMA operand roles swapped — D[i = token][j = column]: a lane holds 4 consecutive
+      // tokens of ONE V column, which is 8 contiguous bytes of a V^T row
+      const int mq = t * WS_ROWS + wid * 16 + lq * 4;                // first of this lane's 4 tokens
+      const int smp = mq / g.vt_rows, tok = mq - smp * g.vt_rows;
+      // LayerNorm fold needs the statistics of the lane's 4 tokens (not of row l15): fetched from the wave's registers by shuffle
+      float rs4[4], rm4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { rs4[e] = __shfl(lrs, lq * 4 + e); rm4[e] = __shfl(lrm, lq * 4 + e); }
+#pragma unroll
+      for (int j = 0; j < NTG; ++j) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const h16x8 wf = *(const h16x8*)(wl + (j * KS + ks) * 1024);
+          acc = MFMA_16x16x32(af[ks], wf, acc);
+        }
+        const int c = j * 16 + l15;                                  // this lane's column inside the group
+        const float bv = s_bias[c], sv = s_lns[c];
+        h16x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[e] * g.alpha;
+          if (fold) v = v * rs4[e] - sv * rm4[e];
+          w[e] = (h16)(v + bv);
+        }
+        if (mq < g.M) *(h16x4*)(g.vt_out + (int64_t)smp * g.vt_bs + (int64_t)(n0 - g.vt_n0 + c) * g.vt_ld + tok) = w;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NTG; ++j) {
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -217,6 +250,7 @@ bool gemm_ws_supported(const GemmArgs& g) {
   if (g.N % gc != 0 || g.N > 1280 || (g.n_valid > 0 && g.n_valid < g.N)) return false;
   if (g.residual && (g.ldr & 3)) return false;
   if ((g.lda & 7) || (g.ldc & 3) || (g.ldb & 7)) return false;
+  if (g.vt_out && (g.vt_n0 % gc != 0 || g.vt_rows % 16 != 0 || (g.vt_ld & 3) || g.residual || g.gn_part || g.ln_part || g.act != ACT_NONE)) return false;
   if (g.M < 16384) return false;                        // the tiled kernel's territory: too few 128-row tiles per CU to amortise the W load
   return true;
 }
@@ -224,6 +258,7 @@ bool gemm_ws_supported(const GemmArgs& g) {
 void gemm_ws_init_device() {
   const int smem = ws_smem(160);
   HIP_OK(hipFuncSetAttribute((const void*)gemm_ws_kernel<10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  HIP_OK(hipFuncSetAttribute((const void*)gemm_ws_kernel<10, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   HIP_OK(hipFuncSetAttribute((const void*)gemm_ws_kernel<10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   HIP_OK(hipFuncSetAttribute((const void*)gemm_ws_kernel<20, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   HIP_OK(hipFuncSetAttribute((const void*)gemm_ws_kernel<20, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -245,7 +280,9 @@ void launch_gemm_ws(svg_ctx* ctx, const GemmArgs& g, hipStream_t s) {
   dim3 grid(n_slices * ng);
   const int smem = ws_smem(gc);
   const bool res = g.residual != nullptr;
-  if (g.K == 320) {
+  if (g.vt_out) {
+    hipLaunchKernelGGL((gemm_ws_kernel<10, false, true>), grid, dim3(512), smem, s, g, ng, n_slices);
+  } else if (g.K == 320) {
     if (res) hipLaunchKernelGGL((gemm_ws_kernel<10, true>), grid, dim3(512), smem, s, g, ng, n_slices);
     else hipLaunchKernelGGL((gemm_ws_kernel<10, false>), grid, dim3(512), smem, s, g, ng, n_slices);
   } else {

@@ -67,6 +67,12 @@ struct GemmArgs {
   float* ln_part = nullptr;
   int ln_tiles = 0;
   int64_t bias_zs = 0;               // batched problems: element stride of `bias` per batch (0 = shared)
+  // fused q | k | V^T projection (gemm_ws only): output columns >= vt_n0 are the V projection and go, TRANSPOSED, to
+  // vt_out[sample][n - vt_n0][token] (row m = sample * vt_rows + token; row stride vt_ld, sample stride vt_bs elements): the layout
+  // the attention kernel reads V in.  ldc / C cover the columns below vt_n0 only.
+  h16* vt_out = nullptr;
+  int vt_n0 = 0, vt_rows = 0, vt_ld = 0;
+  int64_t vt_bs = 0;
   int tn_major = 0;                  // tile order inside an XCD's run: 0 = tiles sharing the A rows adjacent, 1 = tiles sharing the weights adjacent
   int dbg = 0;                       // ablation switch (SVG_GEMM_DBG): 1 no stores, 2 no MFMA, 3 no DMA, 5 LDS-staged epilogue
 };
@@ -96,6 +102,8 @@ void ff_fused(svg_ctx* ctx, const h16* X, int ldx, const h16* W1, const float* b
               const h16* W2p, const float* b2, const h16* residual, int ldr, h16* out, int ldo, int M, hipStream_t s);
 // picks split-K from the shape, allocates slabs from the arena, launches
 void gemm_auto(svg_ctx* ctx, GemmArgs g, hipStream_t s, int prof_kind);
+// a GemmArgs with vt_out set can only be served by the weight-stationary kernel: ask before launching
+bool gemm_fused_qkv_supported(const GemmArgs& g);
 
 // weight packing (device): f32 OIHW -> bf16 [Opad][ky][kx][Ipad]; f32 [N][K] -> bf16 [Npad][K]
 void pack_conv3x3(const float* w_oihw, h16* out, int O, int I, int Opad, int Ipad, hipStream_t s);

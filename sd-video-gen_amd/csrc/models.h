@@ -172,6 +172,7 @@ struct VaeModel : VaeIface {
 struct XfBlockW {   // SpatialTransformer with one BasicTransformerBlock
   NormW gn, ln1, ln2, ln3;
   PackedLinear proj_in, proj_out, qk1, v1, o1, q2, k2, v2, o2, ff1, ff2;
+  PackedLinear qkv1;               // [Wq; Wk; Wv] of the self-attention stacked (C = 320 only): the fused q | k | V^T projection
   float* proj_in_f32 = nullptr;   // [C][C] f32: source of the per-sample GroupNorm-folded weights
   h16* ff2p = nullptr;           // ff.net.2 weights with the k order of the fused GEGLU feed-forward (ff_fused.hip), C = 320 only
   int C = 0;

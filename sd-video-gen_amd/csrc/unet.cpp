@@ -44,7 +44,7 @@ ResW load_res_t(svg_ctx* ctx, WeightStore& ws, const std::string& p, int cin, in
 
 // rows [W0; W1; ...] of same K packed into one bf16 matrix
 PackedLinear load_stacked(svg_ctx* ctx, WeightStore& ws, const std::vector<std::string>& names, const std::vector<int>& ns, int K,
-                          bool bias, hipStream_t s, const NormW* fold = nullptr) {
+                          bool bias, hipStream_t s, const NormW* fold = nullptr, bool release = true) {
   PackedLinear pl;
   int N = 0;
   for (int n : ns) N += n;
@@ -70,7 +70,8 @@ PackedLinear load_stacked(svg_ctx* ctx, WeightStore& ws, const std::vector<std::
     rowsum_h16(pl.w, pl.ln_s, pl.N, K, s);
   }
   HIP_OK(hipStreamSynchronize(s));
-  for (auto& n : names) ws.release(n + ".weight");
+  if (release)
+    for (auto& n : names) ws.release(n + ".weight");
   return pl;
 }
 
@@ -106,6 +107,18 @@ XfBlockW load_xf(svg_ctx* ctx, WeightStore& ws, const std::string& p, int C, int
   b.ln1 = load_norm(ctx, ws, t + ".norm1", C);
   b.ln2 = load_norm(ctx, ws, t + ".norm2", C);
   b.ln3 = load_norm(ctx, ws, t + ".norm3", C);
+  // C = 320 (the 64 x 64 level): q | k | v stacked for the fused projection of gemm_ws.hip (one read of the tokens instead of two).
+  // fold_ln_weights scales the f32 copy in place, so the stacked copy is packed from a scratch duplicate of the three matrices
+  if (fold && C == 320) {
+    WeightStore tmp;
+    for (const char* n : {".attn1.to_q", ".attn1.to_k", ".attn1.to_v"}) {
+      const Weight& w = ws.get(t + n + ".weight", {C, C});
+      std::vector<int64_t> shp{C, C};
+      tmp.put(ctx, t + n + ".weight", w.f32, shp.data(), 2);
+    }
+    b.qkv1 = load_stacked(ctx, tmp, {t + ".attn1.to_q", t + ".attn1.to_k", t + ".attn1.to_v"}, {C, C, C}, C, false, s, &b.ln1);
+    tmp.clear();
+  }
   b.qk1 = load_stacked(ctx, ws, {t + ".attn1.to_q", t + ".attn1.to_k"}, {C, C}, C, false, s, fold ? &b.ln1 : nullptr);
   b.v1 = load_linear(ctx, ws, t + ".attn1.to_v", C, C, false, s, fold ? &b.ln1 : nullptr);
   b.o1 = load_linear(ctx, ws, t + ".attn1.to_out.0", C, C, true, s);
@@ -400,8 +413,24 @@ struct UnetRun {
       ctx->arena.push();
       const int HWp = (int)align_up(HW, 8);
       h16* qk = ctx->arena.get<h16>(P * 2 * C);
-      linear(ctx, a1, C, b.qk1, qk, 2 * C, M, ACT_NONE, nullptr, 0, 0, s, rs, rm);
-      h16* vt = vt_proj(b.v1, a1, HW, HWp, C, rs, rm);
+      h16* vt = nullptr;
+      bool fused = false;
+      if (b.qkv1.w && HWp == HW && HW % 16 == 0) {
+        // q | k | V^T in ONE weight-stationary launch: the V column groups write V^T directly (GemmArgs::vt_out)
+        GemmArgs g;
+        g.ln_rs = rs; g.ln_rm = rm; g.ln_s = b.qkv1.ln_s;
+        g.A = a1; g.lda = C; g.Wt = b.qkv1.w; g.ldb = C; g.M = M; g.N = 3 * C; g.K = C; g.n_valid = 3 * C;
+        g.bias = b.qkv1.b; g.C = qk; g.ldc = 2 * C;
+        g.vt_n0 = 2 * C; g.vt_rows = HW; g.vt_ld = HWp; g.vt_bs = (int64_t)C * HWp;
+        vt = ctx->arena.get<h16>((int64_t)N * C * HWp);
+        g.vt_out = vt;
+        static const int qkv_env = getenv("SVG_QKV_FUSED") ? atoi(getenv("SVG_QKV_FUSED")) : 1;
+        if (qkv_env && gemm_fused_qkv_supported(g)) { gemm_auto(ctx, g, s, PK_GEMM); fused = true; }
+      }
+      if (!fused) {
+        linear(ctx, a1, C, b.qk1, qk, 2 * C, M, ACT_NONE, nullptr, 0, 0, s, rs, rm);
+        vt = vt_proj(b.v1, a1, HW, HWp, C, rs, rm);
+      }
       attn_core(qk, 2 * C, qk + C, 2 * C, (int64_t)HW * 2 * C, vt, HWp, (int64_t)C * HWp, ao, C, HW, HW);
       ctx->arena.pop();
     }
