@@ -159,6 +159,11 @@ struct AttnArgs {
   float scale;
 };
 void attention(svg_ctx* ctx, const AttnArgs& a, hipStream_t s);
+// single-head d = 512 attention of the VAE mid blocks, fused (attn_vae.hip): q, k rows of stride ldqk, vt = V transposed (B, C, ldvt)
+bool vae_attention_supported(int S, int C, int ldqk, int ldvt, int ldo);
+void vae_attention(svg_ctx* ctx, const h16* q, const h16* k, int ldqk, int64_t qkb, const h16* vt, int ldvt, int64_t vtb, h16* out, int ldo,
+                   int64_t ob, int B, int S, int C, hipStream_t s);
+void vae_attn_init_device();
 
 // ------------------------------------------------------------------------------------------------
 // element-wise / layout

@@ -185,6 +185,7 @@ void sd_init_device() {
   gemm_init_device();
   gemm_pp_init_device();
   gemm_ws_init_device();
+  vae_attn_init_device();
   conv_halo_init_device();
   ff_fused_init_device();
   gemm_fp8_init_device();

@@ -148,7 +148,7 @@ struct VaeRun {
     return out;
   }
 
-  // single-head attention over HW tokens, unfused (d = C = 512): S and P go through HBM
+  // single-head attention over HW tokens (d = C = 512): fused (attn_vae.hip) when HW is a multiple of 64, else three GEMMs + row softmax
   Act attn(const Act& xa, const VaeAttnW& a, int H, int W) {
     const h16* x = xa.p;
     const int HW = H * W, C = a.C;
@@ -170,23 +170,28 @@ struct VaeRun {
       g.bias = a.v.b; g.bias_row = 1; g.C = vt; g.ldc = HWp;
       gemm_auto(ctx, g, s, PK_GEMM);
     }
-    float* S = ctx->arena.get<float>((int64_t)N * HW * HWp);
-    {
-      GemmArgs g;
-      g.A = qk; g.lda = 2 * C; g.Wt = qk + C; g.ldb = 2 * C; g.M = HW; g.N = HWp; g.n_valid = HW; g.K = C;
-      g.batch = N; g.sA = (int64_t)HW * 2 * C; g.sB = (int64_t)HW * 2 * C; g.sC = (int64_t)HW * HWp;
-      g.C = S; g.ldc = HWp; g.out_f32 = 1;
-      gemm_auto(ctx, g, s, PK_GEMM);
-    }
-    h16* Pm = ctx->arena.get<h16>((int64_t)N * HW * HWp);
-    softmax_rows(ctx, S, Pm, (int64_t)N * HW, HW, HWp, HWp, 1.f / sqrtf((float)C), s);
     h16* o = ctx->arena.get<h16>(P * C);
-    {
-      GemmArgs g;
-      g.A = Pm; g.lda = HWp; g.Wt = vt; g.ldb = HWp; g.M = HW; g.N = C; g.n_valid = C; g.K = HWp;
-      g.batch = N; g.sA = (int64_t)HW * HWp; g.sB = (int64_t)C * HWp; g.sC = (int64_t)HW * C;
-      g.C = o; g.ldc = C;
-      gemm_auto(ctx, g, s, PK_GEMM);
+    if (vae_attention_supported(HW, C, 2 * C, HWp, C)) {
+      // flash-style, the head dimension split over the waves of a workgroup (attn_vae.hip): no S x S matrix in HBM
+      vae_attention(ctx, qk, qk + C, 2 * C, (int64_t)HW * 2 * C, vt, HWp, (int64_t)C * HWp, o, C, (int64_t)HW * C, N, HW, C, s);
+    } else {
+      float* S = ctx->arena.get<float>((int64_t)N * HW * HWp);
+      {
+        GemmArgs g;
+        g.A = qk; g.lda = 2 * C; g.Wt = qk + C; g.ldb = 2 * C; g.M = HW; g.N = HWp; g.n_valid = HW; g.K = C;
+        g.batch = N; g.sA = (int64_t)HW * 2 * C; g.sB = (int64_t)HW * 2 * C; g.sC = (int64_t)HW * HWp;
+        g.C = S; g.ldc = HWp; g.out_f32 = 1;
+        gemm_auto(ctx, g, s, PK_GEMM);
+      }
+      h16* Pm = ctx->arena.get<h16>((int64_t)N * HW * HWp);
+      softmax_rows(ctx, S, Pm, (int64_t)N * HW, HW, HWp, HWp, 1.f / sqrtf((float)C), s);
+      {
+        GemmArgs g;
+        g.A = Pm; g.lda = HWp; g.Wt = vt; g.ldb = HWp; g.M = HW; g.N = C; g.n_valid = C; g.K = HWp;
+        g.batch = N; g.sA = (int64_t)HW * HWp; g.sB = (int64_t)C * HWp; g.sC = (int64_t)HW * C;
+        g.C = o; g.ldc = C;
+        gemm_auto(ctx, g, s, PK_GEMM);
+      }
     }
     linear(ctx, o, C, a.proj, out, C, (int)P, ACT_NONE, x, C, 0, s, nullptr, nullptr, &eo, HW);
     ctx->arena.pop();

@@ -112,6 +112,24 @@ def test_vae_full_size_512(ctx, full_vae):
     margin("full-size VAE decoder @512 uint8 frame mean |diff|", d.mean(), 1.5, unit="LSB")
 
 
+def test_vae_fused_mid_attention_512(ctx, full_vae, monkeypatch):
+    """the flash-style d = 512 mid-block attention (attn_vae.hip, head dimension split over the waves; off by default — slower than the
+    three-GEMM path) gives the same networks: encoder moments and decoder output at 512 x 512 against the default path and the oracle"""
+    g = torch.Generator().manual_seed(12)
+    img = torch.randint(0, 256, (1, 512, 512, 3), dtype=torch.uint8, generator=g)
+    zz = torch.randn(1, 4, 64, 64, generator=g) * 0.4
+    _, mom0 = ctx.vae_encode(img.cuda(), return_moments=True)
+    _, fl0 = ctx.vae_decode(zz.cuda(), return_float=True)
+    monkeypatch.setenv("SVG_VAE_ATTN_FUSED", "1")
+    _, mom1 = ctx.vae_encode(img.cuda(), return_moments=True)
+    _, fl1 = ctx.vae_decode(zz.cuda(), return_float=True)
+    assert not torch.equal(mom0, mom1)                                     # another kernel ran
+    margin("VAE @512, fused mid-block attention vs the three-GEMM path: encoder moments", rel_l2(mom1.cpu(), mom0.cpu()), 1.5e-2)
+    margin("VAE @512, fused mid-block attention vs the three-GEMM path: decoder output", rel_l2(fl1.cpu(), fl0.cpu()), 1.5e-2)
+    x = 2 * ((img / 255.0).float().permute(0, 3, 1, 2) - 0.5)
+    margin("VAE @512, fused mid-block attention vs oracle: encoder moments", rel_l2(mom1.cpu(), SO.vae_encode_moments(full_vae, x)), 4.5e-2)
+
+
 def test_vae_512_properties(ctx, full_vae):
     """512x512 (the denoise resolution): finite, deterministic, and the fused resize == explicit resize."""
     g = torch.Generator().manual_seed(3)
