@@ -86,11 +86,39 @@ _RESTYPES = {"svg_destroy": None, "svg_model_dtype": C.c_char_p, "svg_last_error
              "svg_workspace_bytes": _i64}
 
 
+def host_cpu_quota():
+    """CPUs this process may burn: the affinity mask capped by the cgroup's CFS bandwidth (cpu.max = "quota period")."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            q, p = open(path).read().split()
+            if q != "max":
+                n = min(n, max(1, int(q) // int(p)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def fit_host_threads():
+    """Caps torch's intra-op pool to a quarter of the CPU quota.  torch sizes the pool from the VISIBLE cores (128 threads on the
+    256-core GPU host) while the cgroup grants 16 CPUs per 100 ms CFS period; the pool's idle workers spin, the group burns its
+    1.6 CPU-seconds in ~37 ms and the kernel then parks EVERY thread of the process — including the one inside hipLaunchKernel —
+    until the next 100-ms period (profiles/r03_stall_trace.json, r03_throttle.txt: the round-2 "100-ms-tick stall", 28 -> 94
+    training it/s).  An explicit OMP_NUM_THREADS / $SVG_HOST_THREADS wins."""
+    if os.environ.get("OMP_NUM_THREADS"):
+        return torch.get_num_threads()
+    want = int(os.environ.get("SVG_HOST_THREADS", "0")) or max(1, host_cpu_quota() // 4)
+    if torch.get_num_threads() > want:
+        torch.set_num_threads(want)
+    return torch.get_num_threads()
+
+
 def load():
     """dlopen the library and declare every symbol of the header; raises if anything is missing."""
     global _lib
     if _lib is not None:
         return _lib
+    fit_host_threads()
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "libsvg_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
