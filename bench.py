@@ -461,6 +461,8 @@ def main():
             "ranks_seen": (dist.get_world_size() if world > 1 else 1),
             "config": {"workload": "configs[2]: %s F=%d, --denoise --denoise_start_step %d (%d DDIM steps of the SD-v1.4 UNet at 64x64 latents, "
                                    "VAE enc/dec at 512x512), guidance_scale 0" % (args.config, F, args.start_step, 50 - args.start_step)
+                                   + ("; the UNet's qualifying dense projections in MX block-scaled fp8 — the ARITHMETIC of configs[4], on configs[2]'s "
+                                      "workload (not configs[4]'s text-conditioned guidance-7.5 batch-2 UNet: tests/test_configs_gpu.py covers that one)" if fp8 else "")
                        if denoise else "%s F=%d no --denoise (latent Transformer only)" % (args.config, F),
                        "clips_per_gpu": C, "streams_per_gpu": args.streams, "pred_frames": args.pred_frames, "global_clips": n_global, "parallelism": "clip-sharded dp%d" % world,
                        "weights": "seeded random init (SD v1.4 architecture, %s)" % args.config}}

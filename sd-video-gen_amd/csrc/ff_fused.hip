@@ -22,7 +22,10 @@ constexpr int FC = 320;                 // channels
 constexpr int FH = 1280;                // hidden units (4C)
 constexpr int F_SLAB = 16384;           // 128 rows x 128 B
 constexpr int F_RING = 8;
-constexpr int F_DEPTH = 4;              // slabs in flight
+#ifndef FF_DEPTH
+#define FF_DEPTH 4
+#endif
+constexpr int F_DEPTH = FF_DEPTH;       // slabs in flight
 constexpr int F_KS = FC / 32;           // k-steps of GEMM1
 constexpr int F_NCH = FH / 64;          // hidden chunks
 constexpr int F_SPC = 5 + 3;            // slabs per chunk: 5 of W1 (k slabs), 3 of W2 (row blocks of 128 covering 320 rows)
@@ -136,11 +139,25 @@ __global__ void __launch_bounds__(512, 2) ff_fused_kernel(const FfArgs a) {
   // fragment feeding two MFMAs, one wave per SIMD): 304 accumulator / operand registers, i.e. 142 of them parked in AGPRs with copies
   // around the MFMAs — 0.132-0.136 ms against 0.125-0.126 ms for 32768 rows.
   int q = 0;
-  auto step_begin = [&]() {                                // retire slab q, barrier, refill the slot F_DEPTH ahead
+#ifndef FF_PAIR
+#define FF_PAIR 0
+#endif
+#ifndef FF_ABL            // timing ablations (results are garbage): 1 no ring DMA after the prologue, 2 no MFMAs, 3 no fragment reads
+#define FF_ABL 0
+#endif
+  auto step_begin = [&](int sidx) {                        // retire slab q, barrier, refill the slot F_DEPTH ahead
+    if (FF_PAIR) {                                         // experiment: one barrier per TWO slabs (sidx = slab index inside the chunk)
+      if (sidx & 1) return;
+      if (q + F_DEPTH <= NQ) wait_vm(2 * (F_DEPTH - 2));
+      else wait_vm(NQ - q - 2 > 0 ? (NQ - q - 2) * 2 : 0);
+      bar();
+      if (q + F_DEPTH < NQ && FF_ABL != 1) { dma_slab(q + F_DEPTH); dma_slab(q + F_DEPTH + 1); }
+      return;
+    }
     if (q + F_DEPTH - 1 < NQ) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // 2 * (F_DEPTH - 1): the steady state
     else wait_vm((NQ - 1 - q) * 2);
     bar();
-    if (q + F_DEPTH < NQ) dma_slab(q + F_DEPTH);
+    if (q + F_DEPTH < NQ && FF_ABL != 1) dma_slab(q + F_DEPTH);
   };
 
   for (int c = 0; c < F_NCH; ++c) {
@@ -150,15 +167,15 @@ __global__ void __launch_bounds__(512, 2) ff_fused_kernel(const FfArgs a) {
     for (int t = 0; t < 8; ++t) acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
-      step_begin();
+      step_begin(s);
       const char* sl = smem + (q & (F_RING - 1)) * F_SLAB;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         h16x8 wf[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) wf[t] = *(const h16x8*)(sl + t * 2048 + fsw[kk]);
+        for (int t = 0; t < 8; ++t) { if (FF_ABL != 3) wf[t] = *(const h16x8*)(sl + t * 2048 + fsw[kk]); else asm volatile("" : "=v"(wf[t])); }
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc1[t] = MFMA_16x16x32(wf[t], xf[s * 2 + kk], acc1[t]);
+        for (int t = 0; t < 8; ++t) { if (FF_ABL != 2) acc1[t] = MFMA_16x16x32(wf[t], xf[s * 2 + kk], acc1[t]); else asm volatile("" :: "v"(wf[t])); }
       }
       ++q;
     }
@@ -171,21 +188,23 @@ __global__ void __launch_bounds__(512, 2) ff_fused_kernel(const FfArgs a) {
       const f32x4 bh = *(const f32x4*)(sB1 + n), bg = *(const f32x4*)(sB1 + n + 16);
       const f32x4 h = acc1[2 * pr] * rs - sh * rm + bh;
       const f32x4 gt = acc1[2 * pr + 1] * rs - sg * rm + bg;
+      const f32x4 pv = h * gelu_erf4(gt);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) pf[pr >> 1][(pr & 1) * 4 + e] = (h16)(h[e] * gelu_erf(gt[e]));
+      for (int e = 0; e < 4; ++e) pf[pr >> 1][(pr & 1) * 4 + e] = (h16)pv[e];
     }
     // ---- GEMM2: acc2[320 columns] += P (16 x 64) W2p[:, chunk]^T, 3 slabs of 128 W2 rows
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-      step_begin();
+      step_begin(5 + s);
       const char* sl = smem + (q & (F_RING - 1)) * F_SLAB;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           if (s * 8 + t < FC / 16) {
-            const h16x8 wf = *(const h16x8*)(sl + t * 2048 + fsw[kk]);
-            acc2[s * 8 + t] = MFMA_16x16x32(wf, pf[kk], acc2[s * 8 + t]);
+            h16x8 wf;
+            if (FF_ABL != 3) wf = *(const h16x8*)(sl + t * 2048 + fsw[kk]); else asm volatile("" : "=v"(wf));
+            if (FF_ABL != 2) acc2[s * 8 + t] = MFMA_16x16x32(wf, pf[kk], acc2[s * 8 + t]); else asm volatile("" :: "v"(wf));
           }
         }
       }
@@ -199,6 +218,215 @@ __global__ void __launch_bounds__(512, 2) ff_fused_kernel(const FfArgs a) {
     for (int t = 0; t < FC / 16; ++t) {
       const int n = t * 16 + lq * 4;
       f32x4 v = acc2[t] + *(const f32x4*)(a.b2 + n);
+      if (a.residual) {
+        const h16x4 r = *(const h16x4*)(a.residual + (int64_t)m * a.ldr + n);
+        v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+      }
+      *(h16x4*)(a.out + (int64_t)m * a.ldo + n) = to_h16x4(v);
+    }
+  }
+}
+
+// ---- the PAIRED form: two waves share 32 rows -----------------------------------------------------------------------------------
+// Ablations of ff_fused_kernel on MI355X (114688 rows, 0.455 ms): no MFMAs 0.274, no fragment reads 0.321, no ring DMA 0.419, a GELU
+// at 8 instead of 18 issue slots -3 %, half the barriers 0 %, a deeper ring 0 %.  At 16 rows per wave a weight fragment feeds ONE
+// MFMA (16 FLOP per LDS byte: the LDS pipe and the matrix pipe both have to run at 100 %), and the two take turns instead of
+// overlapping.  32 rows per wave with the whole 320-wide output needs 304 registers per lane (one wave per SIMD, accumulators in
+// AGPRs: built, 0.555 ms — the compiler shuttles the x fragments through AGPRs and scratch).  Here the waves of a pair (2p, 2p + 1)
+// own the same 32 rows and split the COLUMNS: of a hidden chunk's 128 packed GEMM1 columns each takes 64 (so each runs GEGLU on 32
+// hidden units = one k-step of GEMM2), they swap their P tiles through 2 KiB of LDS, and each accumulates 160 of the 320 output
+// columns.  Every fragment read feeds two MFMAs (60 reads + 4 swap accesses per 120 MFMAs), 80 + 32 + 80 accumulator / operand
+// registers per lane, still two waves per SIMD.  W2's rows are dealt to the slabs so that each slab carries 64 rows of either half
+// (slab j: rows 64 j .. of columns 0-159 in LDS rows 0-63, of columns 160-319 in LDS rows 64-127) — a DMA source map, no repacking.
+constexpr int P_RING = 7;                // 7 x 16 KiB slabs + s1/b1 (20 KiB) + the swap buffer (16 KiB) = 148 KiB
+constexpr int P_OFF_S1 = P_RING * F_SLAB;
+constexpr int P_OFF_EX = P_OFF_S1 + 2 * 2 * FH * 4;
+constexpr int P_LDS = P_OFF_EX + 8 * 2 * 64 * 16;
+
+__global__ void __launch_bounds__(512, 2) ff_pair_kernel(const FfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wid);
+  const int pair_u = wave_u >> 1, half_u = wave_u & 1;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int m0 = blockIdx.x * 128;
+  const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+  constexpr unsigned INVALID = 0x80000000u;
+
+  const uint64_t p1 = (uint64_t)a.W1, p2 = (uint64_t)a.W2p;
+  const v4i srd1 = {(int)(unsigned)p1, (int)((p1 >> 32) & 0xffff), (int)(2u * FH * FC * 2u), 0x00020000};
+  const v4i srd2 = {(int)(unsigned)p2, (int)((p2 >> 32) & 0xffff), (int)((unsigned)FC * FH * 2u), 0x00020000};
+
+  const int prow = lane >> 3;
+  auto dma_slab = [&](int q, int slot) {                   // slab q = (chunk q / 8, piece q % 8) into ring slot `slot`
+    const int c = q >> 3, s = q & 7;
+    const unsigned dst = lds0 + slot * F_SLAB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int blk = i * 8 + wave_u;
+      const int row = blk * 8 + prow;                      // LDS row of the slab
+      const int ch = (lane & 7) ^ (row & 7);
+      if (s < 5) {
+        const unsigned voff = (unsigned)((128 * c + row) * FC + ch * 8) * 2u;
+        dma16(srd1, voff, s * 128, dst + blk * 1024);
+      } else {
+        const int rr = 64 * (s - 5) + (row & 63);          // row inside the column half
+        const int r = (row >> 6) * 160 + rr;
+        const unsigned voff = rr < 160 ? (unsigned)(r * FH + ch * 8) * 2u : INVALID;
+        dma16(srd2, voff, c * 128, dst + blk * 1024);
+      }
+    }
+  };
+  constexpr int NQ = F_NCH * F_SPC;
+#pragma unroll
+  for (int q = 0; q < F_DEPTH; ++q) dma_slab(q, q);
+
+  {
+    float* ss = (float*)(smem + P_OFF_S1);
+    for (int i = tid; i < 2 * FH; i += 512) { ss[i] = a.s1[i]; ss[2 * FH + i] = a.b1[i]; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  int mrow[2]; bool m_ok[2];
+  h16x8 xf[2][F_KS];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    mrow[rt] = m0 + pair_u * 32 + rt * 16 + l15;
+    m_ok[rt] = mrow[rt] < a.M;
+#pragma unroll
+    for (int ks = 0; ks < F_KS; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (m_ok[rt]) v = *(const uint4*)(a.X + (int64_t)mrow[rt] * a.ldx + ks * 32 + lq * 8);
+      xf[rt][ks] = *(h16x8*)&v;
+    }
+  }
+  float rs[2], rm[2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    if (a.rs) {
+      rs[rt] = m_ok[rt] ? a.rs[mrow[rt]] : 0.f; rm[rt] = m_ok[rt] ? a.rm[mrow[rt]] : 0.f;
+    } else {
+      float sum = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < F_KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += (float)xf[rt][ks][j];
+      sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+      const float mean = sum * (1.f / FC);
+      float sq = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < F_KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float dlt = (float)xf[rt][ks][j] - mean; sq += dlt * dlt; }
+      sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
+      rs[rt] = m_ok[rt] ? rsqrtf(sq * (1.f / FC) + 1e-5f) : 0.f;
+      rm[rt] = rs[rt] * mean;
+    }
+  }
+
+  f32x4 acc2[2][10];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int t = 0; t < 10; ++t) acc2[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment address inside a slab: row tile (4 half + j) of 16 rows, chunk (kk * 4 + lq) ^ (l15 & 7)
+  int fsw[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) fsw[kk] = (half_u * 64 + l15) * 128 + (((kk * 4 + lq) ^ (l15 & 7)) << 4);
+  const float* const sS1 = (const float*)(smem + P_OFF_S1);
+  const float* const sB1 = sS1 + 2 * FH;
+  char* const ex_own = smem + P_OFF_EX + ((wave_u * 2) * 64 + lane) * 16;            // [wave][rt][lane] 16 B
+  const char* const ex_other = smem + P_OFF_EX + (((wave_u ^ 1) * 2) * 64 + lane) * 16;
+
+  int q = 0, slot = 0, slot_in = F_DEPTH;                  // slot of slab q; slot the next DMA goes to
+  auto step_begin = [&]() {
+    if (q + F_DEPTH - 1 < NQ) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else wait_vm((NQ - 1 - q) * 2);
+    bar();
+    if (q + F_DEPTH < NQ) dma_slab(q + F_DEPTH, slot_in);
+    slot_in = slot_in + 1 == P_RING ? 0 : slot_in + 1;
+  };
+  auto step_end = [&]() { ++q; slot = slot + 1 == P_RING ? 0 : slot + 1; };
+
+  for (int c = 0; c < F_NCH; ++c) {
+    // ---- GEMM1: 32 rows x 64 packed columns (h g h g of this half), K = 320 in 5 slabs
+    f32x4 acc1[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc1[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      step_begin();
+      const char* sl = smem + slot * F_SLAB;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        h16x8 wf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wf[t] = *(const h16x8*)(sl + t * 2048 + fsw[kk]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) acc1[rt][t] = MFMA_16x16x32(wf[t], xf[rt][s * 2 + kk], acc1[rt][t]);
+      }
+      step_end();
+    }
+    // ---- folded LayerNorm + bias, GEGLU on this half's 32 hidden units: the B operand of GEMM2's k-step `half`
+    h16x8 pown[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const int n = 128 * c + 64 * half_u + 32 * pr + 4 * lq;
+        const f32x4 sh = *(const f32x4*)(sS1 + n), sg = *(const f32x4*)(sS1 + n + 16);
+        const f32x4 bh = *(const f32x4*)(sB1 + n), bg = *(const f32x4*)(sB1 + n + 16);
+        const f32x4 h = acc1[rt][2 * pr] * rs[rt] - sh * rm[rt] + bh;
+        const f32x4 gt = acc1[rt][2 * pr + 1] * rs[rt] - sg * rm[rt] + bg;
+        const f32x4 pv = h * gelu_erf4(gt);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pown[rt][pr * 4 + e] = (h16)pv[e];
+      }
+      *(h16x8*)(ex_own + rt * 1024) = pown[rt];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the swap writes have landed before the barrier of the next step
+    // ---- GEMM2: acc2[160 columns of this half] += P (32 x 64) W2p[:, chunk]^T, 3 slabs of 64 + 64 W2 rows
+    h16x8 pf[2][2];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      step_begin();
+      if (s == 0) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const h16x8 po = *(const h16x8*)(ex_other + rt * 1024);
+          pf[rt][0] = half_u ? po : pown[rt];
+          pf[rt][1] = half_u ? pown[rt] : po;
+        }
+      }
+      const char* sl = smem + slot * F_SLAB;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (s * 4 + t < 10) {
+            const h16x8 wf = *(const h16x8*)(sl + t * 2048 + fsw[kk]);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) acc2[rt][s * 4 + t] = MFMA_16x16x32(wf, pf[rt][kk], acc2[rt][s * 4 + t]);
+          }
+        }
+      }
+      step_end();
+    }
+  }
+
+  // ---- epilogue: + b2 + residual, h16 store (4 consecutive columns per lane)
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    if (!m_ok[rt]) continue;
+    const int m = mrow[rt];
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+      const int n = half_u * 160 + t * 16 + lq * 4;
+      f32x4 v = acc2[rt][t] + *(const f32x4*)(a.b2 + n);
       if (a.residual) {
         const h16x4 r = *(const h16x4*)(a.residual + (int64_t)m * a.ldr + n);
         v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
@@ -222,6 +450,7 @@ __global__ void pack_ff2_perm_kernel(const float* __restrict__ w, h16* __restric
 
 void ff_fused_init_device() {
   HIP_OK(hipFuncSetAttribute((const void*)ff_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
+  HIP_OK(hipFuncSetAttribute((const void*)ff_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS));
 }
 
 bool ff_fused_supported(int C, int M) {
@@ -244,7 +473,9 @@ void ff_fused(svg_ctx* ctx, const h16* X, int ldx, const h16* W1, const float* b
   ProfScope ps(ctx, PK_GEMM, s, 2.0 * M * (double)FC * (2 * FH) + 2.0 * M * (double)FH * FC,
                2.0 * ((double)M * FC * 3 + 3.0 * FC * FH), tag);
   FfArgs a{X, ldx, W1, b1, s1, rs, rm, W2p, b2, residual, ldr, out, ldo, M};
-  hipLaunchKernelGGL(ff_fused_kernel, dim3(cdiv(M, 128)), dim3(512), F_LDS, s, a);
+  const char* ep = getenv("SVG_FF_PAIR");                  // read per call: 1 (default) the paired 32-row form, 0 the 16-rows-per-wave form
+  if (ep ? atoi(ep) != 0 : true) hipLaunchKernelGGL(ff_pair_kernel, dim3(cdiv(M, 128)), dim3(512), P_LDS, s, a);
+  else hipLaunchKernelGGL(ff_fused_kernel, dim3(cdiv(M, 128)), dim3(512), F_LDS, s, a);
   check_launch("ff_fused");
 }
 

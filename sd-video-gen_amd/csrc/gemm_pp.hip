@@ -44,7 +44,20 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs g) {
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  // Tile order inside an XCD's contiguous run: groups of g.group_m row tiles, the column tile walking slowest inside a group
+  // and the row tile fastest, so the ~32 workgroups an XCD runs at a time cover a compact group_m x (32 / group_m) rectangle
+  // whose A and W panels fit its 4 MiB L2 (row-major order at N = 10240 keeps 33 panels live per XCD: 780 MB per launch
+  // from beyond L2 against 26 + 18 MB of operands).  group_m <= 1: plain row-major order.
+  int tm, tn;
+  if (g.group_m > 1) {
+    const int tiles_m = (g.M + BMP - 1) / BMP;
+    const int per = g.group_m * tiles_n;
+    const int grp_i = tile / per, in = tile - grp_i * per;
+    const int gm = min(g.group_m, tiles_m - grp_i * g.group_m);
+    tn = in / gm; tm = grp_i * g.group_m + (in - tn * gm);
+  } else {
+    tm = tile / tiles_n; tn = tile - tm * tiles_n;
+  }
   const int m0 = tm * BMP, n0 = tn * BN;
   const int KT = g.K >> 6;
 
@@ -191,7 +204,10 @@ bool gemm_pp_supported(const GemmArgs& g) {
   return (int64_t)cdiv(g.M, 256) * cdiv(g.N, gemm_pp_bn(g)) >= 192;
 }
 
-void launch_gemm_pp(const GemmArgs& g, hipStream_t s) {
+void launch_gemm_pp(const GemmArgs& g0, hipStream_t s) {
+  static const int gm_env = getenv("SVG_PP_GROUPM") ? atoi(getenv("SVG_PP_GROUPM")) : 4;
+  GemmArgs g = g0;
+  g.group_m = gm_env;
   if (gemm_pp_bn(g) == 160) launch_pp<160>(g, s);
   else launch_pp<128>(g, s);
 }

@@ -13,18 +13,46 @@ namespace {
 constexpr int BM = 128;
 constexpr int BK = 64;
 
-// exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 output rounding):
-// ~12 VALU + exp + rcp per element instead of the ~40-instruction libm erff — the GEGLU epilogue applies it to
-// 64 values per thread.
+// exact (erf) GELU without erf: gelu(x) = x Phi(x) = max(x, 0) - |x| Phi(-|x|), and the normal tail is smooth in the log domain:
+// log2 Phi(-a) is fitted on [0, 6] by a degree-6 polynomial (weighted for the error of a Phi(-a); |x| > 6 reuses the value at 6,
+// where |x| Phi(-|x|) < 1e-8 |x|).  |gelu - exact| <= 2.7e-7 in f32 (Abramowitz-Stegun 7.1.26, the previous form: 4.7e-7), and
+// the whole thing is one min, six FMAs (v_pk_fma_f32: two elements per instruction), one v_exp_f32, one max and one FMA —
+// 8 issue slots per element against 18 (rcp + exp + 14 VALU).  The GEGLU epilogues run it on 16-64 values per lane: at K = 320
+// (ff_fused) that was three quarters of the matrix time.  Coefficients: tools/fit_gelu.py.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 gelu_erf4(f32x4 x) {
+#ifdef GELU_ABL
+  return x;
+#endif
+#ifdef GELU_AS      // A/B switch: the Abramowitz-Stegun form of rounds 1-2 (tools/build_variant.sh as "-DGELU_AS")
+  f32x4 o;
+  for (int i = 0; i < 4; ++i) {
+    const float z = fabsf(x[i]) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    o[i] = 0.5f * x[i] * (1.f + copysignf(1.f - poly * __expf(-z * z), x[i]));
+  }
+  return o;
+#endif
+  f32x4 a, out;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = fminf(fabsf(x[i]), 6.f);
+  f32x4 p = f32x4{3.4645448e-05f, 3.4645448e-05f, 3.4645448e-05f, 3.4645448e-05f};
+  auto step = [&](float c) { p = __builtin_elementwise_fma(p, a, f32x4{c, c, c, c}); };
+  step(-0.000782622703f); step(0.00812418268f); step(-0.0534785727f); step(-0.458721816f); step(-1.15121768f); step(-0.999991402f);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[i] = fmaf(-fabsf(x[i]), __builtin_amdgcn_exp2f(p[i]), fmaxf(x[i], 0.f));
+  return out;
+}
 __device__ __forceinline__ float gelu_erf(float x) {
 #ifdef GELU_ABL
   return x;
 #endif
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float e = 1.f - poly * __expf(-z * z);
-  return 0.5f * x * (1.f + copysignf(e, x));
+  const float a = fminf(fabsf(x), 6.f);
+  float p = 3.4645448e-05f;
+  p = fmaf(p, a, -0.000782622703f); p = fmaf(p, a, 0.00812418268f); p = fmaf(p, a, -0.0534785727f);
+  p = fmaf(p, a, -0.458721816f); p = fmaf(p, a, -1.15121768f); p = fmaf(p, a, -0.999991402f);
+  return fmaf(-fabsf(x), __builtin_amdgcn_exp2f(p), fmaxf(x, 0.f));
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
 
@@ -115,7 +143,7 @@ __device__ __forceinline__ f32x4 epi_value(const GemmArgs& g, int z, int m, int 
   if (g.act == ACT_SILU) {
     for (int i = 0; i < 4; ++i) v[i] = silu_f(v[i]);
   } else if (g.act == ACT_GELU) {
-    for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
+    v = gelu_erf4(v);
   }
   return v;
 }
@@ -135,9 +163,7 @@ __device__ __forceinline__ f32x4 geglu_value(const GemmArgs& g, int m, int nh, f
     h += *(const f32x4*)(g.bias + nh);
     gt += *(const f32x4*)(g.bias + nh + 16);
   }
-  f32x4 v;
-  for (int i = 0; i < 4; ++i) v[i] = h[i] * gelu_erf(gt[i]);
-  return v;
+  return h * gelu_erf4(gt);
 }
 
 // sum over the 16 lanes of a DPP row (lanes sharing lane >> 4), result in every lane: four v_add_f32 with DPP operand
@@ -240,9 +266,7 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int m
             const int nh = nc + 16 * j;                       // packed column of the h tile; the gate tile follows
             if (nh >= g.N) continue;
             const f32x4 h = acc[i][j] * alpha + bj[j], gt = acc[i][j + 1] * alpha + bj[j + 1];
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = h[e] * gelu_erf(gt[e]);
+            const f32x4 v = h * gelu_erf4(gt);
             const int oc = (nh >> 5) * 16 + (nh & 15);
             *(h16x4*)((h16*)g.C + (int64_t)z * g.sC + (int64_t)m * g.ldc + oc) = to_h16x4(v);
           }
@@ -258,8 +282,7 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int m
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
           } else if (g.act == ACT_GELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            v = gelu_erf4(v);
           }
           const int64_t o = (int64_t)z * g.sC + (int64_t)m * g.ldc + n;
           if (g.out_f32) *(f32x4*)((float*)g.C + o) = v;
@@ -380,7 +403,12 @@ __device__ __forceinline__ void wait_vm(int n) {
     case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
     case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
     case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
   }
 }
 
