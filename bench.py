@@ -42,9 +42,9 @@ def parse():
     p.add_argument("--start_step", type=int, default=0)
     p.add_argument("--config", type=str, default="1_16_kitti_L1_64")
     p.add_argument("--no-denoise", action="store_true")
-    p.add_argument("--dtype", choices=["bf16", "fp16", "fp8"], default=os.environ.get("SVG_BENCH_DTYPE", "bf16"),
-                   help="storage type of the SD networks (f32 accumulation): bf16 (BASELINE configs[1]), fp16 (the reference's autocast "
-                        "arithmetic, sd_utils.py:246; tighter parity), fp8 = BASELINE configs[4]: qualifying dense projections of the UNet in MX "
+    p.add_argument("--dtype", choices=["bf16", "fp16", "fp8"], default=os.environ.get("SVG_BENCH_DTYPE", "fp16"),
+                   help="storage type of the SD networks (f32 accumulation): fp16 (default: the reference's autocast arithmetic, "
+                        "sd_utils.py:246; UNet call 1.2e-3 from the fp32 oracle), bf16 (BASELINE configs[1] names it; 1e-2, ~3.6 %% faster), fp8 = BASELINE configs[4]: qualifying dense projections of the UNet in MX "
                         "block-scaled fp8 (the rest stays bf16)")
     p.add_argument("--train", action="store_true",
                    help="SURVEY 8(f1): optimisation steps of the latent Transformer (trainers/trainer.py:141-165) instead of the sampling loop; "

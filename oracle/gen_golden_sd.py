@@ -3,7 +3,7 @@ as small fixtures so that the GPU parity tests need not spend minutes of CPU per
 THIS repository's oracle (oracle/sd_oracle.py — parity unpinned, see its header: the reference holds no SD fixtures and
 diffusers is not installable here), on seeded weights and CPU-generator noise; nothing of the reference is involved.
 
-    python oracle/gen_golden_sd.py [cfg2] [cfg2c] [cfg1] [cfg3]          (~45 min of 8 CPU threads in total)
+    python oracle/gen_golden_sd.py [cfg2] [cfg2c] [cfg1] [cfg3] [cfg3c]          (~45 min of 8 CPU threads in total)
 
   sd_cfg2_frame.pt    configs[2]: 1_16_kitti_L1_64, F=64, one clip, ONE predicted frame, --denoise_start_step 0:
                       50 DDIM steps of the SD-v1.4 UNet at 64x64 latents between the 512x512 VAE passes; keeps the
@@ -15,8 +15,9 @@ diffusers is not installable here), on seeded weights and CPU-generator noise; n
                       profiles/r03_ddim_regimes.json) while the network still moves the result by 0.28 rel-L2, so the
                       FREE-RUNNING 50-step latent and the generated frame can be asserted at an arithmetic tolerance
   sd_cfg1_rollout.pt  configs[1]: same model, 8 predicted frames, --denoise_start_step 25 (25 steps per frame)
-  sd_cfg3_rollout.pt  configs[3]: 11_27_ucf_final, F=128, 16 predicted frames, start step 48 (2 steps per frame: the
-                      full 50 would be 800 UNet calls)
+  sd_cfg3_rollout.pt  configs[3]: 11_27_ucf_final, F=128, 16 predicted frames, start step 48 (2 steps per frame)
+  sd_cfg3_full_contractive.pt  configs[3] at its full length: 16 predicted frames x 50 DDIM steps (800 UNet calls at 16x16 latents),
+                      on the non-chaotic weights of sd_cfg2_contractive.pt (`cfg3c`, ~25 min of 6 CPU threads)
 
 Conventions shared with tests/test_configs_gpu.py (which rebuilds the same inputs from the same seeds):
   UNet / VAE weights   SO.seeded_weights(shapes, 31) / (…, 32)
@@ -127,3 +128,5 @@ if __name__ == "__main__":
         run("11_27_ucf_final", 16, 48, "sd_cfg3_rollout.pt", False)
     if "cfg1" in which:
         run("1_19_ball_complex_L1_64", 8, 25, "sd_cfg1_rollout.pt", False)
+    if "cfg3c" in which:      # configs[3] at FULL length: 16 frames x 50 DDIM steps (800 UNet calls), non-chaotic weights
+        run("11_27_ucf_final", 16, 0, "sd_cfg3_full_contractive.pt", False, contractive=True)

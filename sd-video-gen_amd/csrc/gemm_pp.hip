@@ -10,6 +10,7 @@
 //   waves 4 (M) x 2 (N); wave tile 64 x BN/2; v_mfma_f32_16x16x32_bf16 with the W fragment as the A operand.
 //   LDS rows are 128 B, chunk c of row r at c ^ (r & 7) (swizzle applied on the DMA source side).
 #include "igemm_epi.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace SDNS {
@@ -199,7 +200,10 @@ int gemm_pp_bn(const GemmArgs& g) {
 bool gemm_pp_supported(const GemmArgs& g) {
   static const int on = getenv("SVG_GEMM_PP") ? atoi(getenv("SVG_GEMM_PP")) : 1;
   static const int min_kt = getenv("SVG_GEMM_PP_MINKT") ? atoi(getenv("SVG_GEMM_PP_MINKT")) : 16;
-  if (!on || g.amode != A_DENSE || g.batch != 1 || g.splitk > 1 || g.out_f32 || (g.K & 63) != 0 || (g.K >> 6) < min_kt || g.A2) return false;
+  // wide outputs (the GEGLU projection at 32 x 32: N = 5120, K = 640) amortise the tile's unhidden prologue over enough columns at
+  // 10 slabs already: 0.248 against 0.258-0.262 ms on the 128-row kernel, same box; N = 1280 at K = 640 loses (0.081 against 0.073)
+  const int need_kt = g.N >= 2560 ? std::min(min_kt, 10) : min_kt;
+  if (!on || g.amode != A_DENSE || g.batch != 1 || g.splitk > 1 || g.out_f32 || (g.K & 63) != 0 || (g.K >> 6) < need_kt || g.A2) return false;
   if (g.lda % 8 != 0 || g.ldb % 8 != 0 || g.bias_row) return false;
   return (int64_t)cdiv(g.M, 256) * cdiv(g.N, gemm_pp_bn(g)) >= 192;
 }

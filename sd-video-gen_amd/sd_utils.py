@@ -249,9 +249,10 @@ class SDUtils():
         self._text_embeddings = text_embeddings
         # BASELINE configs[4]: MX block-scaled fp8 for the qualifying dense projections of the UNet (svg_hip.h, key fp8)
         self.fp8 = bool(int(os.environ.get("SVG_UNET_FP8", "0"))) if fp8 is None else bool(fp8)
-        # storage type of the SD networks: 'fp16' is what the reference's autocast executes in the UNet loop (sd_utils.py:246);
-        # 'bf16' (default, BASELINE configs[1]) has 3 fewer mantissa bits and a stated, looser tolerance
-        self.dtype = (dtype or os.environ.get("SVG_SD_DTYPE", "bf16")).lower().replace("float16", "fp16").replace("half", "fp16")
+        # storage type of the SD networks: 'fp16' (default) is what the reference's autocast executes in the UNet loop
+        # (sd_utils.py:246); 'bf16' (BASELINE configs[1] names it) has 3 fewer mantissa bits and a stated, looser tolerance
+        #  and runs ~3.6 % faster on random data (the chip holds a higher clock on bf16 operands)
+        self.dtype = (dtype or os.environ.get("SVG_SD_DTYPE", "fp16")).lower().replace("float16", "fp16").replace("half", "fp16")
         if self.dtype not in ("bf16", "fp16"):
             raise ValueError("SDUtils dtype must be 'bf16' or 'fp16', got %r" % (self.dtype,))
         # `arch` overrides the SD v1.4 widths (reduced-size parity tests): {'vae': {...}, 'unet': {...}}

@@ -8,6 +8,7 @@ through conftest.margin (printed, and collected into gpurun_out/parity_margins.j
   configs[1]  1_19_ball_complex_L1_64, F=64, 8 predicted frames, --denoise --denoise_start_step 25      sd_cfg1_rollout.pt
   configs[2]  1_16_kitti_L1_64, F=64, 50-step DDIM at 64x64 latents, 512x512 VAE passes                 sd_cfg2_frame.pt
   configs[3]  11_27_ucf_final, F=128, 16 predicted frames (start step 48: 2 of the 50 steps per frame)  sd_cfg3_rollout.pt
+              and at full length (all 50 steps per frame, non-chaotic weights)                          sd_cfg3_full_contractive.pt
   configs[4]  11_27_ucf_text_final: d = 2432 text-conditioned Transformer; guidance_scale 7.5 => the batch-2 UNet call of
               evaluation/predict_fvd2_denoise.py:227-229 is genuinely needed (in-test oracle, a few UNet calls)
 Tolerances are <= 3x what was measured on MI355X (bf16 storage with f32 accumulation against the fp32 oracle); the
@@ -192,6 +193,23 @@ def test_config3_rollout_16_frames_f128(ctx, nets):
     margin("cfg3 16-frame rollout, first generated frame", rel_l2(lat[:, 4], g["all_latents"][:, 4]), 7e-2)       # measured 2.6e-2
     margin("cfg3 16-frame rollout, all generated latents", rel_l2(lat[:, 4:], g["all_latents"][:, 4:]), 2.2e-1)   # measured 7.8e-2
     margin("cfg3 16-frame rollout, last frame (16 autoregressive steps)", rel_l2(lat[:, -1], g["all_latents"][:, -1]), 3e-1)   # 1.1e-1
+
+
+@pytest.mark.parametrize("dtype,tol_first,tol_all,tol_last", [("fp16", 1.5e-2, 4e-2, 6e-2), ("bf16", 7e-2, 2.2e-1, 3e-1)])
+def test_config3_full_length_contractive(ctx, nets, dtype, tol_first, tol_all, tol_last):
+    """configs[3] at its FULL length: 11_27_ucf_final, 16 autoregressive frames, each with all 50 DDIM steps of the full-size UNet
+    between the 512 x 512 VAE passes (800 UNet calls in the oracle fixture, oracle/gen_golden_sd.py cfg3c), free-running, in the
+    non-chaotic weight regime of test_config2_free_running_contractive."""
+    g = gold("sd_cfg3_full_contractive.pt")
+    assert g["pred_frames"] == 16 and g["start_step"] == 0 and g["unet_calls"] == 800
+    usd, vsd = nets
+    lat, sdu = _rollout("11_27_ucf_final", g, (GG.contractive_unet(usd), vsd), dtype)
+    assert sdu.ctx.model_dtype(_lib.SVG_UNET) == dtype
+    per = [rel_l2(lat[:, 4 + k], g["all_latents"][:, 4 + k]) for k in range(16)]
+    print("[parity] cfg3 full length (%s) per-frame rel-L2: " % dtype + " ".join("%.2e" % e for e in per))
+    margin("cfg3 FULL length (16 frames x 50 steps, %s): first generated frame" % dtype, per[0], tol_first)
+    margin("cfg3 FULL length (%s): all generated latents" % dtype, rel_l2(lat[:, 4:], g["all_latents"][:, 4:]), tol_all)
+    margin("cfg3 FULL length (%s): last frame (16 autoregressive steps)" % dtype, per[-1], tol_last)
 
 
 def test_config4_guidance_7p5_full_size(ctx, nets):

@@ -16,6 +16,10 @@ rm -rf gpurun_out/pmc
 echo "== default bench"
 timeout -k 10 900 python3 bench.py > $out/${tag}_bench_default.log 2>&1 || { echo "FAILED bench"; exit 1; }
 grep "^{" $out/${tag}_bench_default.log > $out/${tag}_bench_line.json
+echo "== bf16 line (the default is fp16 storage), training line, shape profile"
+timeout -k 10 600 python3 bench.py --dtype bf16 --no-cpu-baseline > $out/${tag}_bench_bf16.log 2>&1; grep "^{" $out/${tag}_bench_bf16.log > $out/${tag}_bench_line_bf16.json
+timeout -k 10 600 python3 bench.py --train --steps 200 > $out/${tag}_bench_train.log 2>&1; grep "^{" $out/${tag}_bench_train.log > $out/${tag}_bench_line_train.json
+timeout -k 10 300 python3 tools/shape_profile.py --clips $clips --steps 2 --out $out/${tag}_shape_profile.json > $out/${tag}_shape_profile.log 2>&1
 echo "== no-denoise and fp8 lines"
 timeout -k 10 300 python3 bench.py --no-denoise --steps 20 --warmup 3 > $out/${tag}_bench_nodenoise.log 2>&1; grep "^{" $out/${tag}_bench_nodenoise.log > $out/${tag}_bench_line_nodenoise.json
 timeout -k 10 600 python3 bench.py --dtype fp8 --no-cpu-baseline > $out/${tag}_bench_fp8.log 2>&1; grep "^{" $out/${tag}_bench_fp8.log > $out/${tag}_bench_line_fp8.json
