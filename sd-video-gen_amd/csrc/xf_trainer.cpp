@@ -32,7 +32,13 @@ struct XfTrain {
   std::vector<Plan> plans;
   uint64_t* d_seed = nullptr;     // device seed word read by every dropout site
   uint64_t* h_seed = nullptr;     // pinned ring of 16 seeds (a call that does not synchronise must not race the next one's seed)
+  hipEvent_t seed_ev[16] = {};    // recorded behind each slot's upload: the 17th unsynchronised call waits for the 1st one's copy
   int seed_slot = 0;
+  // The training step's own workspace.  The captured graph bakes workspace addresses: if it lived in the context-wide arena, a
+  // VAE / UNet / CLIP call of the same context on ANOTHER stream (or a forward that regrows the arena) could reuse or move the
+  // memory while the graph is still running.  loss_pass swaps these in for the duration of its planning and launches.
+  Arena ws;
+  DevBuf ws_buf;
   std::vector<void*> bufs;       // device allocations of the training state (freed with it)
   void* dalloc(int64_t bytes) {
     void* p = nullptr;
@@ -45,6 +51,8 @@ struct XfTrain {
     for (void* p : bufs) hipFree(p);
     if (h_losses) hipHostFree(h_losses);
     if (h_seed) hipHostFree(h_seed);
+    for (auto e : seed_ev) if (e) hipEventDestroy(e);
+    if (ws_buf.p) hipFree(ws_buf.p);
   }
 };
 
@@ -316,6 +324,11 @@ void loss_pass(svg_ctx* ctx, XfModel* m, const svg_train_cfg& cfg, const float* 
     r.embed_bwd(e_tgt, d_tgt, dxt, Tt, true);                 // the embedding layer is shared: second contribution accumulates
   };
   // ---- the plan of this call signature ----------------------------------------------------------------------------------------
+  struct ArenaSwap {       // the training workspace stands in for the context arena until this call returns (or throws)
+    svg_ctx* c; XfTrain* t;
+    ArenaSwap(svg_ctx* c_, XfTrain* t_) : c(c_), t(t_) { std::swap(c->arena, t->ws); std::swap(c->arena_buf, t->ws_buf); }
+    ~ArenaSwap() { std::swap(c->arena, t->ws); std::swap(c->arena_buf, t->ws_buf); }
+  } arena_swap(ctx, tr);
   const int mode = expected ? 0 : 2;
   XfTrain::Plan* pl = nullptr;
   for (auto& c : tr->plans)
@@ -336,8 +349,11 @@ void loss_pass(svg_ctx* ctx, XfModel* m, const svg_train_cfg& cfg, const float* 
   }
   ctx->ensure_arena(pl->high);
   tr->seed_slot = (tr->seed_slot + 1) & 15;
+  if (!tr->seed_ev[tr->seed_slot]) HIP_OK(hipEventCreateWithFlags(&tr->seed_ev[tr->seed_slot], hipEventDisableTiming));
+  else HIP_OK(hipEventSynchronize(tr->seed_ev[tr->seed_slot]));       // the slot's previous upload (16 calls ago) has been read
   tr->h_seed[tr->seed_slot] = cfg.seed;
   HIP_OK(hipMemcpyAsync(tr->d_seed, tr->h_seed + tr->seed_slot, sizeof(uint64_t), hipMemcpyHostToDevice, s));
+  HIP_OK(hipEventRecord(tr->seed_ev[tr->seed_slot], s));
   static const bool graph_env = !(getenv("SVG_TRAIN_GRAPH") && atoi(getenv("SVG_TRAIN_GRAPH")) == 0);
   // hipGraph replay of the whole step: needs a capturable (non-null) stream; the inputs go through fixed staging buffers
   if (graph_env && expected && s != nullptr && !ctx->prof) {

@@ -174,7 +174,8 @@ __global__ void __launch_bounds__(256) xf_gemm2_kernel(const float* __restrict__
   if (st0 < st1) {
     // prologue: stages and W fragments of steps st0 .. st0 + D - 1, in the steady-state issue order
 #pragma unroll
-    for (int d = 0; d < D; ++d) { stage_x(st0 + d); load_w(st0 + d, wq[d]); }
+    // (the compiler barriers pin the issue order DMAs -> W loads of a step: the counted waits below count on it)
+    for (int d = 0; d < D; ++d) { stage_x(st0 + d); asm volatile("" ::: "memory"); load_w(st0 + d, wq[d]); asm volatile("" ::: "memory"); }
     if (D > 1) {
       // stage st0 must have landed: younger than its DMAs are load_w(st0) and the (D - 1) later stage / W pairs
       constexpr int C0 = (D - 1) * (NPW + 2) + 2;
@@ -191,8 +192,10 @@ __global__ void __launch_bounds__(256) xf_gemm2_kernel(const float* __restrict__
         if (step < st1) {
           const int buf = (step - st0) % NST;
           stage_x(step + D);                                 // into the stage last read in step - 1 (a barrier ago)
+          asm volatile("" ::: "memory");
           const f32x4 w0 = wq[d][0], w1 = wq[d][1];
           load_w(step + D, wq[d]);
+          asm volatile("" ::: "memory");
           const char* xb = xs + buf * STAGE;
 #pragma unroll
           for (int t = 0; t < MT; ++t) {
@@ -443,6 +446,7 @@ void xformer_init_device() {
 // column-block form (X shared through LDS): grid (N / 64, ksplit)
 static void xf_gemm_v2(svg_ctx* ctx, const float* X, const float* W, const float* bias, float* Y, int M, int N, int K, int act_in,
                        hipStream_t s, const float* residual) {
+  SVG_CHECK(K >= 32 && K % 4 == 0, "xf_gemm (column-block form): K = %d must be a multiple of 4 and at least one 32-wide step (masked W loads read row offset 0)", K);
   const int nb = cdiv(N, 64);
   const int steps = cdiv(K, 32);
   // enough workgroups for two per CU while each keeps >= 8 steps (two rounds of its 4-deep pipeline)
@@ -485,7 +489,7 @@ void xf_gemm(svg_ctx* ctx, const float* X, const float* W, const float* bias, fl
   // X straight from L2: 1.6-3.1 TB/s at 6 rows) is ahead; from 48 rows on X re-reads bound it and the column-block form (X
   // shared through LDS) wins: 71 vs 53 TFLOP/s at 168 x 6144 x 2048.  SVG_XF_V forces one.
   static const int ver = getenv("SVG_XF_V") ? atoi(getenv("SVG_XF_V")) : 0;
-  if (ver == 2 || (ver == 0 && M >= 48)) { xf_gemm_v2(ctx, X, W, bias, Y, M, N, K, act_in, s, residual); return; }
+  if (ver == 2 || (ver == 0 && M >= 48 && K >= 32)) { xf_gemm_v2(ctx, X, W, bias, Y, M, N, K, act_in, s, residual); return; }
   const int nb = cdiv(N, 16);
   // K split: enough workgroups to put >= 2 on every CU while every wave keeps >= 2 steps of 32 (its load pipeline)
   const int steps = cdiv(K, 32);

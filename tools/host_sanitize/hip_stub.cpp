@@ -35,8 +35,10 @@ const char* hipGetErrorString(hipError_t) { return "stub"; }
 hipError_t hipGetLastError() { return hipSuccess; }
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)malloc(8); return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (hipEvent_t)malloc(8); return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) { free((void*)e); return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipSuccess; }
 hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = (hipGraph_t)malloc(8); return hipSuccess; }

@@ -5,7 +5,7 @@ import collections, csv, glob, json, os, sys
 
 d, out = sys.argv[1], sys.argv[2]
 res = {}
-for name in ("ff", "gemmres", "attn", "conv"):
+for name in ("ff", "gemmres", "attn", "conv", "gemm"):
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(float)
     for f in glob.glob(os.path.join(d, name + "_*", "**", "*counter_collection.csv"), recursive=True):
@@ -27,12 +27,18 @@ for name in ("ff", "gemmres", "attn", "conv"):
         e["mfma_busy_per_simd_over_gpu_cycles"] = g("SQ_VALU_MFMA_BUSY_CYCLES") / 1024.0 / (g("GRBM_GUI_ACTIVE") / 8.0)
     if g("GRBM_GUI_ACTIVE") and g("SQ_LDS_IDX_ACTIVE"):
         e["lds_active_per_cu_over_gpu_cycles"] = g("SQ_LDS_IDX_ACTIVE") / 256.0 / (g("GRBM_GUI_ACTIVE") / 8.0)
+    if g("SQ_VALU_MFMA_COEXEC_CYCLES") and g("SQ_VALU_MFMA_BUSY_CYCLES"):
+        e["mfma_coexec_over_mfma_busy"] = g("SQ_VALU_MFMA_COEXEC_CYCLES") / g("SQ_VALU_MFMA_BUSY_CYCLES")
+    if g("SQ_INST_CYCLES_VMEM_RD") and g("SQ_INSTS_VMEM_RD"):
+        e["issue_cycles_per_vmem_rd"] = g("SQ_INST_CYCLES_VMEM_RD") / g("SQ_INSTS_VMEM_RD")
     if g("SQ_INSTS_LDS") and g("SQ_INSTS_MFMA"):
         e["lds_insts_per_mfma"] = g("SQ_INSTS_LDS") / g("SQ_INSTS_MFMA")
     if g("SQ_INSTS_VALU") and g("SQ_INSTS_MFMA"):
         e["valu_insts_per_mfma"] = (g("SQ_INSTS_VALU") - g("SQ_INSTS_MFMA")) / g("SQ_INSTS_MFMA")
     if g("SQ_WAVE_CYCLES"):
-        for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"):
+        for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_INST_CYCLES_VMEM_RD", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_MISC",
+                  "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_VMEM_TA_ADDR_FIFO_FULL", "SQ_VMEM_TA_CMD_FIFO_FULL", "SQ_LDS_CMD_FIFO_FULL",
+                  "SQ_LDS_DATA_FIFO_FULL", "SQ_INST_LEVEL_VMEM", "SQ_INST_LEVEL_LDS"):
             if g(n) is not None:
                 e[n.lower() + "_over_wave_cycles"] = g(n) / g("SQ_WAVE_CYCLES")
     res[name] = e
