@@ -39,6 +39,12 @@ struct XfTrain {
   // memory while the graph is still running.  loss_pass swaps these in for the duration of its planning and launches.
   Arena ws;
   DevBuf ws_buf;
+  // Backward runs dW (xf_gemm_tn) of a layer on a side stream beside its dX chain (they only share the read-only dY): inside the
+  // captured step this becomes a fork / join in the graph.  Events are pooled (created before any capture).
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> fork_ev;
+  int fork_next = 0;
+  hipEvent_t next_event() { hipEvent_t e = fork_ev[fork_next]; fork_next = (fork_next + 1) % (int)fork_ev.size(); return e; }
   std::vector<void*> bufs;       // device allocations of the training state (freed with it)
   void* dalloc(int64_t bytes) {
     void* p = nullptr;
@@ -52,6 +58,8 @@ struct XfTrain {
     if (h_losses) hipHostFree(h_losses);
     if (h_seed) hipHostFree(h_seed);
     for (auto e : seed_ev) if (e) hipEventDestroy(e);
+    for (auto e : fork_ev) if (e) hipEventDestroy(e);
+    if (side) hipStreamDestroy(side);
     if (ws_buf.p) hipFree(ws_buf.p);
   }
 };
@@ -78,7 +86,16 @@ struct Run {
   svg_ctx* ctx; XfModel* m; XfTrain* tr; hipStream_t s; int B; const uint64_t* seed; float p; bool grads;
   const float* text = nullptr;
   uint32_t site = 0;
+  bool fork = false;             // dW on the side stream (set by loss_pass)
+  bool tn_pending = false;
   bool go() const { return SVG_LAUNCHING(ctx); }
+  void join() {                  // the side stream's work so far is ordered before whatever `s` launches next
+    if (!tn_pending) return;
+    hipEvent_t e = tr->next_event();
+    HIP_OK(hipEventRecord(e, tr->side));
+    HIP_OK(hipStreamWaitEvent(s, e, 0));
+    tn_pending = false;
+  }
   XfDrop drop() { return XfDrop{seed, site++, p}; }
   const float* W(const std::string& n) { return m->ws.get(n).f32; }
   float* G(const std::string& n) { return tr->slots.at(n).g; }
@@ -97,7 +114,18 @@ struct Run {
                bool accumulate = false) {
     float* slabs = dx ? get<float>(xf_gemm_nn_slab_floats(t.M, t.N, t.K)) : nullptr;
     if (!go()) return;
-    xf_gemm_tn(dy, t.N, t.x, t.K, G(t.w) + t.woff, G(t.b) + t.boff, t.M, t.N, t.K, accumulate, s);
+    if (fork) {
+      // at most one dW in flight beside the main chain: the previous one is joined first, so nothing launched from here on can
+      // touch a buffer it still reads; this one waits for dY and then runs beside the dX GEMM and what follows it
+      join();
+      hipEvent_t e = tr->next_event();
+      HIP_OK(hipEventRecord(e, s));
+      HIP_OK(hipStreamWaitEvent(tr->side, e, 0));
+      xf_gemm_tn(dy, t.N, t.x, t.K, G(t.w) + t.woff, G(t.b) + t.boff, t.M, t.N, t.K, accumulate, tr->side);
+      tn_pending = true;
+    } else {
+      xf_gemm_tn(dy, t.N, t.x, t.K, G(t.w) + t.woff, G(t.b) + t.boff, t.M, t.N, t.K, accumulate, s);
+    }
     if (dx) xf_gemm_nn(dy, t.N, W(t.w) + t.woff, slabs, dx, t.M, t.N, t.K, gate, gate_scale, add, s);
   }
 
@@ -223,6 +251,9 @@ void ensure_train(svg_ctx* ctx, XfModel* m) {
   tr->d_losses = (float*)tr->dalloc(5 * sizeof(float));
   HIP_OK(hipHostMalloc((void**)&tr->h_losses, 5 * sizeof(float), hipHostMallocDefault));
   tr->d_seed = (uint64_t*)tr->dalloc(sizeof(uint64_t));
+  HIP_OK(hipStreamCreateWithFlags(&tr->side, hipStreamNonBlocking));
+  tr->fork_ev.resize(64);
+  for (auto& e : tr->fork_ev) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIP_OK(hipHostMalloc((void**)&tr->h_seed, 16 * sizeof(uint64_t), hipHostMallocDefault));
   HIP_OK(hipMemcpy(tr->d_tens, tens.data(), tens.size() * sizeof(XfAdamTensor), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(tr->d_chunks, chunks.data(), chunks.size() * sizeof(XfAdamChunk), hipMemcpyHostToDevice));
@@ -249,6 +280,10 @@ void loss_pass(svg_ctx* ctx, XfModel* m, const svg_train_cfg& cfg, const float* 
   auto body = [&](const float* src, const float* tgt, const float* expected, const float* text, const float* mask) {
     Run r{ctx, m, tr, s, B, tr->d_seed, backward ? cfg.dropout_p : 0.f, backward != 0};
     r.text = text;
+    // off by default: measured 11.1-11.4 ms per step with the fork against 10.46-10.49 ms without (same box, graph replay) — the
+    // 75 fork / join pairs cost more inside the graph than the overlapped 1.6 ms of dW kernels give back
+    static const bool fork_env = getenv("SVG_TRAIN_FORK") && atoi(getenv("SVG_TRAIN_FORK")) != 0;
+    r.fork = fork_env && backward && expected && !ctx->prof;
     LinTape e_src, e_tgt, l_out;
     XfDrop d_src, d_tgt;
     float* xs = r.embed(e_src, d_src, src, Ts, m->iota);
@@ -322,6 +357,7 @@ void loss_pass(svg_ctx* ctx, XfModel* m, const svg_train_cfg& cfg, const float* 
     }
     r.embed_bwd(e_src, d_src, dxs, Ts, false);
     r.embed_bwd(e_tgt, d_tgt, dxt, Tt, true);                 // the embedding layer is shared: second contribution accumulates
+    r.join();
   };
   // ---- the plan of this call signature ----------------------------------------------------------------------------------------
   struct ArenaSwap {       // the training workspace stands in for the context arena until this call returns (or throws)
