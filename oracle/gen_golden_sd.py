@@ -3,7 +3,7 @@ as small fixtures so that the GPU parity tests need not spend minutes of CPU per
 THIS repository's oracle (oracle/sd_oracle.py — parity unpinned, see its header: the reference holds no SD fixtures and
 diffusers is not installable here), on seeded weights and CPU-generator noise; nothing of the reference is involved.
 
-    python oracle/gen_golden_sd.py [cfg2] [cfg2c] [cfg1] [cfg3] [cfg3c]          (~45 min of 8 CPU threads in total)
+    python oracle/gen_golden_sd.py [cfg2] [cfg2c] [cfg1] [cfg3] [cfg3c] [cfg4c]          (~45 min of 8 CPU threads in total)
 
   sd_cfg2_frame.pt    configs[2]: 1_16_kitti_L1_64, F=64, one clip, ONE predicted frame, --denoise_start_step 0:
                       50 DDIM steps of the SD-v1.4 UNet at 64x64 latents between the 512x512 VAE passes; keeps the
@@ -17,7 +17,10 @@ diffusers is not installable here), on seeded weights and CPU-generator noise; n
   sd_cfg1_rollout.pt  configs[1]: same model, 8 predicted frames, --denoise_start_step 25 (25 steps per frame)
   sd_cfg3_rollout.pt  configs[3]: 11_27_ucf_final, F=128, 16 predicted frames, start step 48 (2 steps per frame)
   sd_cfg3_full_contractive.pt  configs[3] at its full length: 16 predicted frames x 50 DDIM steps (800 UNet calls at 16x16 latents),
-                      on the non-chaotic weights of sd_cfg2_contractive.pt (`cfg3c`, ~25 min of 6 CPU threads)
+                      on the non-chaotic weights of sd_cfg2_contractive.pt (`cfg3c`, ~75 min of 5 CPU threads)
+  sd_cfg4_text_guided_contractive.pt  configs[4]'s loop at full DDIM length: 11_27_ucf_text_final (text-conditioned Transformer,
+                      d = 2432), guidance_scale 7.5 with distinct uncond / cond embeddings (batch-2 UNet calls), 4 predicted frames x
+                      50 steps on the non-chaotic weights (`cfg4c`, ~40 min)
 
 Conventions shared with tests/test_configs_gpu.py (which rebuilds the same inputs from the same seeds):
   UNet / VAE weights   SO.seeded_weights(shapes, 31) / (…, 32)
@@ -82,6 +85,58 @@ def build_transformer(cfg_name, seed=XF_SEED):
     return m, cfg
 
 
+TEXT_XF_SEED, TEXT_EMB_SEED, TEXT_CLASS = 9, 321, "WallPushups"
+
+
+def build_text_transformer(cfg_name="11_27_ucf_text_final", seed=TEXT_XF_SEED):
+    """the text-conditioned host module (parameters only) of configs[4]; the class embedding is the seeded per-string stand-in
+    (text_encoder="hash": the MiniLM encoder has its own parity tests), so fixture and test need no sentence encoder"""
+    from sd_video_gen_amd import config as svg_config
+    from sd_video_gen_amd.transformer_text import Transformer as TextTransformer
+    svg_config.set_args(["--dataset", "ucf", "--config", cfg_name, "--denoise", "1"])
+    cfg = svg_config.load_config(cfg_name)
+    torch.manual_seed(seed)
+    m = TextTransformer(dim_model=cfg.DIM_MODEL[0], num_heads=cfg.NUM_HEADS[0], num_encoder_layers=cfg.NUM_ENCODER_LAYERS[0],
+                        num_decoder_layers=cfg.NUM_DECODER_LAYERS[0], dropout_p=cfg.DROPOUT_P[0], text_encoder="hash", st_weights="synthetic").eval()
+    return m, cfg
+
+
+def text_emb_pair(seed=TEXT_EMB_SEED):
+    """[uncond; cond] with DISTINCT rows: guidance 7.5 genuinely needs the batch-2 UNet call"""
+    return torch.randn((2, 77, 768), generator=torch.Generator().manual_seed(seed))
+
+
+def run_text(pred_frames, out_name):
+    """configs[4]'s loop at FULL DDIM length: text-conditioned Transformer (d = 2432), guidance_scale 7.5, all 50 steps per frame,
+    non-chaotic UNet weights; both rows of every UNet call are evaluated (uncond and cond differ)."""
+    from sd_video_gen_amd.predict import bouncing_ball_clips
+    t0 = time.time()
+    usd = contractive_unet(SO.seeded_weights(SO.unet_shapes(), UNET_SEED))
+    vsd = SO.seeded_weights(SO.vae_shapes(), VAE_SEED)
+    m, cfg = build_text_transformer()
+    xsd = {k: v.detach() for k, v in m.state_dict().items() if not k.startswith("sent_transformer.")}
+    F = cfg.FRAME_SIZE
+    clip = bouncing_ball_clips(1, F, 5, seed=CLIP_SEED)[0]
+    noise = loop_noise(NOISE_SEED, F, pred_frames, 0)
+    emb = text_emb_pair()
+    txt = m.encode_classes([TEXT_CLASS])
+    calls = [0]
+
+    def unet_both(x, t, c):
+        calls[0] += 1
+        e = SO.unet_forward(usd, x, t, c)
+        print("  unet call %d (t=%d, batch %d) %.0fs" % (calls[0], t, x.shape[0], time.time() - t0), flush=True)
+        return e
+    with torch.no_grad():
+        lat = loop_oracle.sample_clip(xsd, cfg.NUM_HEADS[0], vsd, clip, pred_frames, noise, denoise=True, start_step=0, unet_sd=usd,
+                                      text_emb=emb, txt=txt, guidance_scale=7.5, unet=unet_both)
+    torch.save({"config": "11_27_ucf_text_final", "pred_frames": pred_frames, "start_step": 0, "guidance_scale": 7.5, "all_latents": lat,
+                "class": TEXT_CLASS, "unet_calls": calls[0],
+                "seeds": dict(unet=UNET_SEED, vae=VAE_SEED, xf=TEXT_XF_SEED, clip=CLIP_SEED, noise=NOISE_SEED, emb=TEXT_EMB_SEED)},
+               os.path.join(OUT, out_name))
+    print("%s: %d UNet calls (batch 2), %.0f s, |lat| %.4f" % (out_name, calls[0], time.time() - t0, float(lat.abs().mean())), flush=True)
+
+
 def run(cfg_name, pred_frames, start_step, out_name, keep_hist, contractive=False):
     from sd_video_gen_amd.predict import bouncing_ball_clips
     t0 = time.time()
@@ -128,5 +183,7 @@ if __name__ == "__main__":
         run("11_27_ucf_final", 16, 48, "sd_cfg3_rollout.pt", False)
     if "cfg1" in which:
         run("1_19_ball_complex_L1_64", 8, 25, "sd_cfg1_rollout.pt", False)
+    if "cfg4c" in which:      # configs[4]: text + guidance 7.5 at the full DDIM length (4 frames x 50 steps x batch 2), non-chaotic weights
+        run_text(4, "sd_cfg4_text_guided_contractive.pt")
     if "cfg3c" in which:      # configs[3] at FULL length: 16 frames x 50 DDIM steps (800 UNet calls), non-chaotic weights
         run("11_27_ucf_final", 16, 0, "sd_cfg3_full_contractive.pt", False, contractive=True)

@@ -216,6 +216,27 @@ def test_config3_full_length_contractive(ctx, nets, dtype, tol_first, tol_all, t
     margin("cfg3 FULL length (%s): last frame (16 autoregressive steps)" % dtype, per[-1], tol_last)
 
 
+@pytest.mark.parametrize("dtype,tol_first,tol_all", [("fp16", 2e-2, 4e-2), ("bf16", 1e-1, 2e-1)])
+def test_config4_full_ddim_length_text_guided(ctx, nets, dtype, tol_first, tol_all):
+    """configs[4] at the full DDIM length: 11_27_ucf_text_final (text-conditioned Transformer, d = 2432), guidance_scale 7.5 with
+    distinct uncond / cond embeddings, four autoregressive frames of 50 steps each (200 batch-2 UNet calls in the oracle fixture,
+    oracle/gen_golden_sd.py cfg4c), free-running on the non-chaotic weights."""
+    from sd_video_gen_amd.predict import sample_clips, bouncing_ball_clips
+    g = gold("sd_cfg4_text_guided_contractive.pt")
+    assert g["pred_frames"] == 4 and g["start_step"] == 0 and g["guidance_scale"] == 7.5 and g["unet_calls"] == 200
+    usd, vsd = nets
+    m, cfg = GG.build_text_transformer()
+    sdu = _sdu("11_27_ucf_text_final", (GG.contractive_unet(usd), vsd), dtype)
+    clip = bouncing_ball_clips(1, cfg.FRAME_SIZE, 5, seed=GG.CLIP_SEED)
+    lat = sample_clips(m, sdu, clip.cuda(), 4, denoise=True, start_step=0, seeds=[GG.NOISE_SEED], text_embeddings=GG.text_emb_pair().cuda(),
+                       guidance_scale=7.5, cls_list=[g["class"]], cpu_noise=True).cpu()
+    assert lat.shape == g["all_latents"].shape
+    per = [rel_l2(lat[:, 4 + k], g["all_latents"][:, 4 + k]) for k in range(4)]
+    print("[parity] cfg4 full DDIM length (%s) per-frame rel-L2: " % dtype + " ".join("%.2e" % e for e in per))
+    margin("cfg4 text + guidance 7.5, 50 steps per frame (%s): first generated frame" % dtype, per[0], tol_first)
+    margin("cfg4 text + guidance 7.5, 50 steps per frame (%s): all four generated frames" % dtype, rel_l2(lat[:, 4:], g["all_latents"][:, 4:]), tol_all)
+
+
 def test_config4_guidance_7p5_full_size(ctx, nets):
     """configs[4]: a real prompt + guidance_scale 7.5 (evaluation/predict_fvd2_denoise.py:203,227-229): the batch-2 UNet call
     with DIFFERENT uncond / cond embeddings, the CFG combine and three scheduler steps, full-size UNet."""
