@@ -12,10 +12,10 @@ def run():
     vcfg = dict(block_out=(64, 128, 128, 128), layers=1, groups=32, latent=4)
     usd = SO.seeded_weights(SO.unet_shapes(ucfg), 5)
     vsd = SO.seeded_weights(SO.vae_shapes(vcfg), 6)
-    ctx.configure(_lib.SVG_UNET, block_out=list(ucfg["block_out"]), layers=1, heads=4, ctx_dim=64, groups=32, attn=list(ucfg["attn"]))
+    ctx.configure(_lib.SVG_UNET, block_out=list(ucfg["block_out"]), layers=1, heads=4, ctx_dim=64, groups=32, attn=list(ucfg["attn"]), f16=1)
     ctx.load_state_dict(_lib.SVG_UNET, usd)
     ctx.finalize(_lib.SVG_UNET)
-    ctx.configure(_lib.SVG_VAE, block_out=list(vcfg["block_out"]), layers=1, groups=32, latent=4)
+    ctx.configure(_lib.SVG_VAE, block_out=list(vcfg["block_out"]), layers=1, groups=32, latent=4, f16=1)     # fp16 storage: the default mode of the façade
     ctx.load_state_dict(_lib.SVG_VAE, vsd)
     ctx.finalize(_lib.SVG_VAE)
     g = torch.Generator().manual_seed(0)
@@ -34,5 +34,5 @@ def run():
     frame_ref = SO.decode_img_latents(vsd, den_ref, vcfg)
     e1, e2 = rel(z.cpu(), z_ref), rel(den.cpu(), den_ref)
     d = (frame.int() - frame_ref.int()).abs().float()
-    assert e1 < 3e-2 and e2 < 3e-2 and d.mean() <= 1.0, (e1, e2, float(d.mean()))
+    assert e1 < 1e-2 and e2 < 1e-2 and d.mean() <= 0.5, (e1, e2, float(d.mean()))
     print("smoke: VAE enc rel-L2 %.2e, DDIM(2 steps) rel-L2 %.2e, frame mean |diff| %.3f LSB vs oracle" % (e1, e2, float(d.mean())))
