@@ -251,3 +251,32 @@ def test_loop_oracle_matches_reference_trace_shapes():
     noise = {"cond": torch.randn(5, 4, 8, 8, generator=gen)}
     out = loop_oracle.sample_clip(g["state_dict"], g["num_heads"], vsd, clip, 3, noise, vae_cfg=vcfg)
     assert out.shape == (1, 7, 256) and torch.isfinite(out).all()
+
+
+def test_host_thread_cap_follows_the_cgroup_quota(tmp_path, monkeypatch):
+    """_lib.fit_host_threads(): torch's intra-op pool is capped to a quarter of the CFS quota (cpu.max = "quota period") unless the user
+    chose a thread count; an unlimited cgroup ("max") leaves the affinity count (profiles/r03_throttle_*.txt: why this exists)."""
+    import torch
+    from sd_video_gen_amd import _lib
+    before = torch.get_num_threads()
+    try:
+        f = tmp_path / "cpu.max"
+        f.write_text("1600000 100000\n")
+        monkeypatch.setenv("SVG_CGROUP_CPU_MAX", str(f))
+        monkeypatch.delenv("OMP_NUM_THREADS", raising=False)
+        monkeypatch.delenv("SVG_HOST_THREADS", raising=False)
+        import os
+        n_aff = len(os.sched_getaffinity(0))
+        assert _lib.host_cpu_quota() == min(16, n_aff)
+        torch.set_num_threads(max(before, 8))
+        assert _lib.fit_host_threads() == min(max(before, 8), max(1, min(16, n_aff) // 4))
+        f.write_text("max 100000\n")
+        assert _lib.host_cpu_quota() == n_aff
+        monkeypatch.setenv("SVG_HOST_THREADS", "3")
+        torch.set_num_threads(8)
+        assert _lib.fit_host_threads() == 3
+        monkeypatch.setenv("OMP_NUM_THREADS", "7")          # an explicit user choice wins: nothing is changed
+        torch.set_num_threads(5)
+        assert _lib.fit_host_threads() == 5
+    finally:
+        torch.set_num_threads(before)
