@@ -107,7 +107,9 @@ def fit_host_threads():
     training it/s).  An explicit OMP_NUM_THREADS / $SVG_HOST_THREADS wins."""
     if os.environ.get("OMP_NUM_THREADS"):
         return torch.get_num_threads()
-    want = int(os.environ.get("SVG_HOST_THREADS", "0")) or max(1, host_cpu_quota() // 4)
+    # the quota is shared by the ranks of a node (one process per GPU under torch.distributed.run: LOCAL_WORLD_SIZE)
+    ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1))
+    want = int(os.environ.get("SVG_HOST_THREADS", "0")) or max(1, host_cpu_quota() // (4 * ranks))
     if torch.get_num_threads() > want:
         torch.set_num_threads(want)
     return torch.get_num_threads()

@@ -265,11 +265,17 @@ def test_host_thread_cap_follows_the_cgroup_quota(tmp_path, monkeypatch):
         monkeypatch.setenv("SVG_CGROUP_CPU_MAX", str(f))
         monkeypatch.delenv("OMP_NUM_THREADS", raising=False)
         monkeypatch.delenv("SVG_HOST_THREADS", raising=False)
+        monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+        monkeypatch.delenv("WORLD_SIZE", raising=False)
         import os
         n_aff = len(os.sched_getaffinity(0))
         assert _lib.host_cpu_quota() == min(16, n_aff)
         torch.set_num_threads(max(before, 8))
         assert _lib.fit_host_threads() == min(max(before, 8), max(1, min(16, n_aff) // 4))
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")          # eight ranks share the node's quota
+        torch.set_num_threads(8)
+        assert _lib.fit_host_threads() == 1
+        monkeypatch.delenv("LOCAL_WORLD_SIZE")
         f.write_text("max 100000\n")
         assert _lib.host_cpu_quota() == n_aff
         monkeypatch.setenv("SVG_HOST_THREADS", "3")
