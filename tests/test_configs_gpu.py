@@ -199,7 +199,7 @@ def test_config3_rollout_16_frames_f128(ctx, nets, dtype, tol_first, tol_all, to
     margin("cfg3 16-frame rollout (%s), last frame (16 autoregressive steps)" % dtype, rel_l2(lat[:, -1], g["all_latents"][:, -1]), tol_last)   # bf16 1.1e-1
 
 
-@pytest.mark.parametrize("dtype,tol_first,tol_all,tol_last", [("fp16", 1.5e-2, 4e-2, 6e-2), ("bf16", 7e-2, 2.2e-1, 3e-1)])
+@pytest.mark.parametrize("dtype,tol_first,tol_all,tol_last", [("fp16", 1.5e-2, 4e-2, 6e-2), ("bf16", 4.5e-2, 1.1e-1, 1.6e-1)])   # measured fp16: 5.1e-3, 1.8e-2, 2.8e-2; bf16: 1.6e-2, 3.7e-2, 5.3e-2
 def test_config3_full_length_contractive(ctx, nets, dtype, tol_first, tol_all, tol_last):
     """configs[3] at its FULL length: 11_27_ucf_final, 16 autoregressive frames, each with all 50 DDIM steps of the full-size UNet
     between the 512 x 512 VAE passes (800 UNet calls in the oracle fixture, oracle/gen_golden_sd.py cfg3c), free-running, in the
