@@ -88,6 +88,7 @@ void gemm_pp_init_device();
 void gemm_ws_init_device();
 void conv_halo_init_device();
 void ff_fused_init_device();
+void xattn_fused_init_device();
 void gemm_fp8_init_device();
 
 // ---- MX block-scaled fp8 (OCP e4m3 elements, one E8M0 scale per 32 K elements): quantiser and GEMM (gemm_fp8.hip)
@@ -98,6 +99,16 @@ void gemm_fp8(svg_ctx* ctx, const uint8_t* A, const uint8_t* As, const uint8_t* 
 
 // fused GEGLU feed-forward (C = 320): out = (GEGLU(LN(x) W1^T + b1)) W2^T + b2 + residual; the M x 4C intermediate stays on chip
 bool ff_fused_supported(int C, int M);
+// cross-attention of a C = 320 block in one launch (xattn_fused.hip): to_q + attention over <= 80 context keys + to_out + residual
+bool xattn_fused_supported(int C, int heads, int M, int rows_per_sample, int L);
+int64_t xattn_kv_pack_elems(int N);
+void xattn_pack_q(const float* w, const float* gamma, const float* beta, h16* Wq, float* sq, float* bq, int perm, hipStream_t s);
+bool xattn_chain_enabled();
+void xattn_pack_o(const float* w, h16* Wo, hipStream_t s);
+void xattn_pack_kv(const h16* K, int ldk, int64_t k_bs, const h16* Vt, int ldv, int64_t v_bs, h16* Kp, h16* Vp, int N, int L, hipStream_t s);
+void xattn_fused(svg_ctx* ctx, const h16* X, int ldx, const h16* R, int ldr, const h16* Wp, const float* bp, const float* rs, const float* rm,
+                 const h16* Wq, const float* sq, const float* bq, const h16* Kp, const h16* Vp, const h16* Wo, const float* bo, h16* out, int ldo,
+                 int M, int rows_per_sample, int L, hipStream_t s);
 void pack_ff2_perm(const float* w, h16* out, int N, int K, hipStream_t s);
 void ff_fused(svg_ctx* ctx, const h16* X, int ldx, const h16* W1, const float* b1, const float* s1, const float* rs, const float* rm,
               const h16* W2p, const float* b2, const h16* residual, int ldr, h16* out, int ldo, int M, hipStream_t s);

@@ -175,12 +175,17 @@ struct XfBlockW {   // SpatialTransformer with one BasicTransformerBlock
   PackedLinear qkv1;               // [Wq; Wk; Wv] of the self-attention stacked (C = 320 only): the fused q | k | V^T projection
   float* proj_in_f32 = nullptr;   // [C][C] f32: source of the per-sample GroupNorm-folded weights
   h16* ff2p = nullptr;           // ff.net.2 weights with the k order of the fused GEGLU feed-forward (ff_fused.hip), C = 320 only
+  h16* xq = nullptr; float* xq_s = nullptr; float* xq_b = nullptr;   // attn2.to_q for the fused cross-attention (xattn_fused.hip): [384][320] head-padded, LN2 folded
+  h16* xqp = nullptr;            // the same with the contraction index in accumulator order (CHAIN form: its B operand comes from registers)
+  h16* xo = nullptr;             // attn2.to_out.0 [320][384] with the padded / permuted contraction order of that kernel
   int C = 0;
 };
 // cross-attention K / V^T of a constant context, computed on the first DDIM step and reused by the others
 struct KvCache {
   std::vector<h16*> k, vt;
   std::vector<int64_t> k_cap, vt_cap;
+  std::vector<h16*> kp, vp;            // per-head packed copies for the fused cross-attention kernel
+  std::vector<int64_t> kvp_cap;
   bool valid = false;
 };
 

@@ -188,6 +188,7 @@ void sd_init_device() {
   vae_attn_init_device();
   conv_halo_init_device();
   ff_fused_init_device();
+  xattn_fused_init_device();
   gemm_fp8_init_device();
 }
 

@@ -122,6 +122,19 @@ XfBlockW load_xf(svg_ctx* ctx, WeightStore& ws, const std::string& p, int C, int
   b.qk1 = load_stacked(ctx, ws, {t + ".attn1.to_q", t + ".attn1.to_k"}, {C, C}, C, false, s, fold ? &b.ln1 : nullptr);
   b.v1 = load_linear(ctx, ws, t + ".attn1.to_v", C, C, false, s, fold ? &b.ln1 : nullptr);
   b.o1 = load_linear(ctx, ws, t + ".attn1.to_out.0", C, C, true, s);
+  if (fold && C == 320) {   // packed copies for the one-launch cross-attention (xattn_fused.hip), made before load_linear releases the f32 originals
+    const Weight& wq = ws.get(t + ".attn2.to_q.weight", {C, C});
+    const Weight& wo = ws.get(t + ".attn2.to_out.0.weight", {C, C});
+    b.xq = (h16*)ctx->dalloc((int64_t)384 * C * sizeof(h16));
+    b.xq_s = (float*)ctx->dalloc(384 * sizeof(float));
+    b.xq_b = (float*)ctx->dalloc(384 * sizeof(float));
+    b.xo = (h16*)ctx->dalloc((int64_t)C * 384 * sizeof(h16));
+    b.xqp = (h16*)ctx->dalloc((int64_t)384 * C * sizeof(h16));
+    xattn_pack_q(wq.f32, b.ln2.g, b.ln2.b, b.xq, b.xq_s, b.xq_b, 0, s);
+    xattn_pack_q(wq.f32, b.ln2.g, b.ln2.b, b.xqp, b.xq_s, b.xq_b, 1, s);      // (row sums and W beta do not depend on the order)
+    xattn_pack_o(wo.f32, b.xo, s);
+    HIP_OK(hipStreamSynchronize(s));
+  }
   b.q2 = load_linear(ctx, ws, t + ".attn2.to_q", C, C, false, s, fold ? &b.ln2 : nullptr);
   b.k2 = load_linear(ctx, ws, t + ".attn2.to_k", C, ctx_dim, false, s);
   b.v2 = load_linear(ctx, ws, t + ".attn2.to_v", C, ctx_dim, false, s);
@@ -435,13 +448,18 @@ struct UnetRun {
       ctx->arena.pop();
     }
     h16* h1 = ctx->arena.get<h16>(P * C);
-    linear(ctx, ao, C, b.o1, h1, C, M, ACT_NONE, h, C, 0, s, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, &le);
+    // C = 320: to_q + attention over the context + to_out + residual in ONE launch (xattn_fused.hip), LayerNorm 2 from the rows it holds
+    const bool xa_one = fold && b.xq && xattn_fused_supported(C, m->heads, M, HW, L);
+    // ... and, CHAIN form, the self-attention's output projection + residual in front of it: h1 is never written
+    const bool xa_chain = xa_one && xattn_chain_enabled() && b.o1.K == C && b.o1.N == C;
+    if (!xa_chain) linear(ctx, ao, C, b.o1, h1, C, M, ACT_NONE, h, C, 0, s, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, xa_one ? nullptr : &le);
+    h16* h2 = ctx->arena.get<h16>(P * C);
     // ---- cross-attention
-    const h16* a2 = norm(h1, b.ln2);
+    const h16* a2 = xa_one ? h1 : norm(h1, b.ln2);
     {
       ctx->arena.push();
-      h16* q = ctx->arena.get<h16>(P * C);
-      linear(ctx, a2, C, b.q2, q, C, M, ACT_NONE, nullptr, 0, 0, s, rs, rm);
+      h16* q = xa_one ? nullptr : ctx->arena.get<h16>(P * C);
+      if (!xa_one) linear(ctx, a2, C, b.q2, q, C, M, ACT_NONE, nullptr, 0, 0, s, rs, rm);
       const int idx = xf_idx++;
       const int64_t kn = (int64_t)N * L * C, vn = (int64_t)N * C * Lp;
       h16 *k, *vt;
@@ -454,15 +472,32 @@ struct UnetRun {
         k = ctx->arena.get<h16>(kn);
         vt = ctx->arena.get<h16>(vn);
       }
+      h16 *kp = nullptr, *vp = nullptr;
+      if (xa_one) {
+        const int64_t pn = xattn_kv_pack_elems(N);
+        if (cache && SVG_LAUNCHING(ctx)) {
+          if ((int)cache->kp.size() <= idx) { cache->kp.resize(idx + 1, nullptr); cache->vp.resize(idx + 1, nullptr); cache->kvp_cap.resize(idx + 1, 0); }
+          if (cache->kvp_cap[idx] < pn) {
+            cache->kp[idx] = (h16*)ctx->dalloc(pn * sizeof(h16)); cache->vp[idx] = (h16*)ctx->dalloc(pn * sizeof(h16));
+            cache->kvp_cap[idx] = pn; cache->valid = false;
+          }
+          kp = cache->kp[idx]; vp = cache->vp[idx];
+        } else {
+          kp = ctx->arena.get<h16>(pn);
+          vp = ctx->arena.get<h16>(pn);
+        }
+      }
       if (!(cache && cache->valid && SVG_LAUNCHING(ctx))) {
         linear(ctx, ctxb, m->ctx_dim, b.k2, k, C, N * L, ACT_NONE, nullptr, 0, 0, s);
         vt_proj_into(b.v2, ctxb, L, Lp, m->ctx_dim, vt);
+        if (xa_one && SVG_LAUNCHING(ctx)) xattn_pack_kv(k, C, (int64_t)L * C, vt, Lp, (int64_t)C * Lp, kp, vp, N, L, s);
       }
-      attn_core(q, C, k, C, (int64_t)L * C, vt, Lp, (int64_t)C * Lp, ao, C, HW, L);
+      if (xa_chain) xattn_fused(ctx, ao, C, h, C, b.o1.w, b.o1.b, nullptr, nullptr, b.xqp, b.xq_s, b.xq_b, kp, vp, b.xo, b.o2.b, h2, C, M, HW, L, s);
+      else if (xa_one) xattn_fused(ctx, h1, C, nullptr, 0, nullptr, nullptr, nullptr, nullptr, b.xq, b.xq_s, b.xq_b, kp, vp, b.xo, b.o2.b, h2, C, M, HW, L, s);
+      else attn_core(q, C, k, C, (int64_t)L * C, vt, Lp, (int64_t)C * Lp, ao, C, HW, L);
       ctx->arena.pop();
     }
-    h16* h2 = ctx->arena.get<h16>(P * C);
-    linear(ctx, ao, C, b.o2, h2, C, M, ACT_NONE, h1, C, 0, s, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, &le);
+    if (!xa_one) linear(ctx, ao, C, b.o2, h2, C, M, ACT_NONE, h1, C, 0, s, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, &le);
     // ---- GEGLU feed-forward
     const bool ff_one = fold && b.ff2p && ff_fused_supported(C, M);
     const h16* a3 = ff_one ? h2 : norm(h2, b.ln3);     // the fused feed-forward takes its LayerNorm statistics from the rows it holds

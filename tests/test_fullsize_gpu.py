@@ -79,6 +79,32 @@ def test_unet_step_full_size_batch7(ctx, full_unet):
         margin("full-size UNet, sample %d of a batch of 7 (t=%d)" % (b, int(t[b])), rel_l2(e[b:b + 1], ref), 2.5e-2)
 
 
+def test_unet_fused_cross_attention_vs_three_launches(ctx, full_unet, monkeypatch):
+    """the one-launch cross-attention of the C = 320 blocks (xattn_fused.hip: to_q + attention over the 77 context keys + to_out +
+    residual, LayerNorm 2 from the rows the kernel holds; head dimension padded 40 -> 48, K / V^T / W_out packed in accumulator order)
+    against the three-launch form on the same batch-7 call (28672 rows: the regime where the kernel is selected), with per-sample
+    contexts; both within the network tolerance of the fp32 oracle"""
+    g = torch.Generator().manual_seed(4)
+    N = 7
+    x = torch.randn(N, 4, 64, 64, generator=g)
+    c = torch.randn(N, 77, 768, generator=g)
+    t = torch.tensor([980.0, 860.0, 700.0, 500.0, 320.0, 120.0, 0.0])
+    monkeypatch.setenv("SVG_XATTN_FUSED", "0")
+    e0 = ctx.unet_forward(x.cuda(), t.cuda(), c.cuda()).cpu()
+    monkeypatch.setenv("SVG_XATTN_FUSED", "1")                                   # one launch, block input read from memory (the default)
+    e1 = ctx.unet_forward(x.cuda(), t.cuda(), c.cuda()).cpu()
+    monkeypatch.setenv("SVG_XATTN_FUSED", "2")                                   # CHAIN form: the self-attention's to_out + residual in front (opt-in)
+    e2 = ctx.unet_forward(x.cuda(), t.cuda(), c.cuda()).cpu()
+    assert torch.isfinite(e1).all() and torch.isfinite(e2).all()
+    assert not torch.equal(e0, e1) and not torch.equal(e1, e2)                    # three different kernel sequences ran
+    margin("full-size UNet batch 7: fused cross-attention vs the three-launch form", rel_l2(e1, e0), 1.5e-2)      # two bf16 roundings apart
+    margin("full-size UNet batch 7: chained to_out1 + cross-attention vs the three-launch form", rel_l2(e2, e0), 1.5e-2)
+    ref = SO.unet_forward(full_unet, x[3:4], float(t[3]), c[3:4])
+    margin("full-size UNet batch 7, fused cross-attention, sample 3 vs oracle", rel_l2(e1[3:4], ref), 2.5e-2)
+    margin("full-size UNet batch 7, chained form, sample 3 vs oracle", rel_l2(e2[3:4], ref), 2.5e-2)
+    margin("full-size UNet batch 7, three-launch cross-attention, sample 3 vs oracle", rel_l2(e0[3:4], ref), 2.5e-2)
+
+
 def test_vae_full_size_128(ctx, full_vae):
     g = torch.Generator().manual_seed(2)
     img = torch.randint(0, 256, (2, 128, 128, 3), dtype=torch.uint8, generator=g)
