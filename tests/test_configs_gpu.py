@@ -216,7 +216,7 @@ def test_config3_full_length_contractive(ctx, nets, dtype, tol_first, tol_all, t
     margin("cfg3 FULL length (%s): last frame (16 autoregressive steps)" % dtype, per[-1], tol_last)
 
 
-@pytest.mark.parametrize("dtype,tol_first,tol_all", [("fp16", 2e-2, 4e-2), ("bf16", 1e-1, 2e-1)])
+@pytest.mark.parametrize("dtype,tol_first,tol_all", [("fp16", 2e-2, 2.9e-2), ("bf16", 1.2e-1, 1.6e-1)])   # measured fp16: 7.5e-3, 9.6e-3; bf16: 5.3e-2, 5.6e-2 (guidance 7.5 amplifies the per-call error)
 def test_config4_full_ddim_length_text_guided(ctx, nets, dtype, tol_first, tol_all):
     """configs[4] at the full DDIM length: 11_27_ucf_text_final (text-conditioned Transformer, d = 2432), guidance_scale 7.5 with
     distinct uncond / cond embeddings, four autoregressive frames of 50 steps each (200 batch-2 UNet calls in the oracle fixture,
