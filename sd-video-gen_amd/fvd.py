@@ -108,6 +108,42 @@ def get_fvd_logits(videos, i3d, device=None):
     return torch.cat([i3d.ctx.fvd_logits(v[i:i + 16], i3d.num_classes) for i in range(0, v.shape[0], 16)], dim=0)
 
 
+def preprocess(videos, target_resolution=224, ctx=None):
+    """fvd_2.py:7-14: uint8 (b,t,h,w,c) -> float (b,c,t,224,224) in [-1, 1] (shorter side scaled bilinearly, centre crop), on device"""
+    v = torch.as_tensor(np.asarray(videos) if not isinstance(videos, torch.Tensor) else videos)
+    assert target_resolution == 224, "the I3D of the FVD takes 224 x 224 crops (fvd_2.py:7)"
+    return (ctx or _lib.default_context()).fvd_preprocess(v)
+
+
+def get_logits(i3d, videos, device=None):
+    """fvd_2.py:81-89: preprocessed clips (b,c,t,h,w), b a multiple of 16 -> logits, in batches of 16"""
+    assert videos.shape[0] % 16 == 0
+    i3d._check()
+    return torch.cat([i3d(videos[i:i + 16]) for i in range(0, videos.shape[0], 16)], dim=0)
+
+
+class InceptionI3d(I3D):
+    """evaluation/pytorch_i3d.py:136 by name: ``InceptionI3d(400, in_channels=3)`` then ``load_state_dict`` then call.  The library
+    model is configured when the weights arrive."""
+
+    def __init__(self, num_classes=400, spatial_squeeze=True, final_endpoint="Logits", name="inception_i3d", in_channels=3, dropout_keep_prob=0.5):
+        if in_channels != 3 or final_endpoint != "Logits":
+            raise ValueError("the FVD path uses the RGB InceptionI3d up to its logits")
+        self.num_classes, self.source, self.ctx, self.n_params = num_classes, "unset", None, 0
+
+    def load_state_dict(self, state_dict, strict=True):
+        I3D.__init__(self, state_dict, self.ctx, self.num_classes, source="state_dict")
+        return self
+
+    def to(self, device):
+        return self
+
+    def _check(self):
+        if self.ctx is None:
+            raise RuntimeError("InceptionI3d: load_state_dict() has not been called")
+        I3D._check(self)
+
+
 def frechet_distance(x1, x2, ctx=None):
     return (ctx or _lib.default_context()).frechet_distance(x1, x2)
 

@@ -11,6 +11,7 @@ through conftest.margin (printed, and collected into gpurun_out/parity_margins.j
               and at full length (all 50 steps per frame, non-chaotic weights)                          sd_cfg3_full_contractive.pt
   configs[4]  11_27_ucf_text_final: d = 2432 text-conditioned Transformer; guidance_scale 7.5 => the batch-2 UNet call of
               evaluation/predict_fvd2_denoise.py:227-229 is genuinely needed (in-test oracle, a few UNet calls)
+              and at the full DDIM length (4 frames x 50 steps, batch-2 calls, non-chaotic weights)      sd_cfg4_text_guided_contractive.pt
 Every fixture test runs in both storage modes: fp16 (SDUtils' default: the reference's autocast arithmetic) and bf16.  Tolerances are
 <= 3x what was measured on MI355X in that mode (f32 accumulation, against the fp32 oracle); free-running 50-step comparisons are
 asserted on the non-chaotic weights (test_config2_free_running_contractive, test_config3_full_length_contractive).

@@ -43,6 +43,25 @@ def test_i3d_logits_against_reference_golden(ctx, i3d):
     assert rel_l2(lg2, GOLD["logits"]) < 2e-5
 
 
+def test_reference_module_paths(ctx, i3d):
+    """a user of the reference imports `evaluation.fvd_2` / `evaluation.pytorch_i3d` (predict_text.py:14-15 there): same names here,
+    same call sequence (InceptionI3d(400, in_channels=3) -> load_state_dict -> eval; preprocess -> get_logits), same numbers"""
+    from evaluation import fvd_2
+    from evaluation.pytorch_i3d import InceptionI3d
+    videos = torch.cat([GOLD["video"]] * 8)
+    want = fvd.get_fvd_logits(videos, i3d).cpu()
+    m = InceptionI3d(400, in_channels=3).to("cuda")
+    with pytest.raises(RuntimeError):
+        fvd_2.get_logits(m, fvd_2.preprocess(videos), "cuda")                      # no weights yet
+    m.load_state_dict(IO.seeded_i3d_weights(GOLD["w_seed"]))
+    m.eval()
+    got = fvd_2.get_logits(m, fvd_2.preprocess(videos.numpy()), "cuda").cpu()      # the reference hands preprocess() a numpy array
+    assert torch.equal(got, want)
+    assert torch.equal(fvd_2.get_fvd_logits(videos.numpy(), m, "cuda").cpu(), want)
+    e1, e2, _ = IO.fvd_test_embeddings(GOLD["emb_seed"])
+    assert abs(fvd_2.frechet_distance(e1, e2) - GOLD["fd_12"]) <= 3e-3 * abs(GOLD["fd_12"])
+
+
 def test_frechet_distance_against_reference_golden(ctx):
     e1, e2, e3 = IO.fvd_test_embeddings(GOLD["emb_seed"])
     for a, b, key in ((e1, e2, "fd_12"), (e1, e3, "fd_13"), (e3, e3[:300], "fd_33")):

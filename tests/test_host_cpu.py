@@ -286,3 +286,17 @@ def test_host_thread_cap_follows_the_cgroup_quota(tmp_path, monkeypatch):
         assert _lib.fit_host_threads() == 5
     finally:
         torch.set_num_threads(before)
+
+
+def test_reference_module_paths_exist():
+    """the reference's import paths resolve to the mirror (thin re-exports; nothing computes without the GPU)"""
+    import importlib
+    for mod, names in (("evaluation.fvd_2", ("preprocess", "get_fvd_logits", "get_logits", "frechet_distance", "load_i3d_pretrained", "all_gather")),
+                       ("evaluation.pytorch_i3d", ("InceptionI3d",)),
+                       ("prediction.predict_text", ("predict", "main", "find_classes", "splitClassNames")),
+                       ("prediction.predict", ("predict", "main")),
+                       ("models.transformer", ("Transformer",)), ("models.transformer_text", ("Transformer",)),
+                       ("utils.sd_utils", ("SDUtils",)), ("utils.config", ("parse_config_args",))):
+        m = importlib.import_module(mod)
+        for n in names:
+            assert hasattr(m, n), "%s.%s" % (mod, n)

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 FAMILIES = [("conv3x3", ("conv_halo_kernel", "igemm_kernel<", "conv_")), ("gemm", ("gemm_pp_kernel", "gemm_ws_kernel", "gemm_fp8_kernel", "splitk_reduce", "ff_fused", "ff_pair")),
-            ("attention", ("attn_kernel", "attn_dma", "vae_attn")), ("groupnorm", ("gn_",)), ("layernorm", ("ln_stats", "ln_finish", "layernorm_kernel")),
+            ("attention", ("attn_kernel", "attn_dma", "vae_attn", "xattn_fused")), ("groupnorm", ("gn_",)), ("layernorm", ("ln_stats", "ln_finish", "layernorm_kernel")),
             ("xf", ("xf_",))]
 
 
