@@ -106,6 +106,28 @@ def test_gemm_pingpong_integer_exact(ctx):
     assert torch.equal(out.float(), (A.float() @ W.float().t()).to(HALF.dtype).float())
 
 
+@pytest.mark.parametrize("M,N,res", [(20000, 320, True), (16384 + 77, 640, False), (33000, 960, False)])
+def test_gemm_weight_stationary_kernel_integer_exact(ctx, M, N, res):
+    """K = 320 at M >= 16384 goes to the weight-stationary persistent kernel (gemm_ws.hip: a 160-column group of W resident in LDS, row
+    tiles of A through registers one tile ahead, stores deferred): integer operands -> bit for bit, ragged last row tile, bias + residual;
+    the profile tag shows which kernel family took the call."""
+    K = 320
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    A = bf(torch.randint(-2, 3, (M, K), device="cuda", generator=g).float())
+    W = bf(torch.randint(-2, 3, (N, K), device="cuda", generator=g).float())
+    b = torch.randint(-3, 4, (N,), device="cuda", generator=g).float()
+    R = bf(torch.randint(-4, 5, (M, N), device="cuda", generator=g).float()) if res else None
+    out = torch.empty(M, N, device="cuda", dtype=HALF.dtype)
+    ctx.prof_reset(); ctx.prof_enable(True, detail=True)
+    ctx.check(op(ctx, "gemm")(ctx.h, u16(A), u16(W), b.data_ptr(), u16(R) if res else None, out.data_ptr(), M, N, K, 0, 0, stream()), "gemm")
+    torch.cuda.synchronize()
+    tags = [k for k in ctx.prof_report() if k.startswith("@gemm|")]
+    ctx.prof_enable(False)
+    assert any(t.endswith("_ws") for t in tags), tags
+    ref = A.float() @ W.float().t() + b + (R.float() if res else 0.0)
+    assert torch.equal(out.float(), ref.to(HALF.dtype).float())
+
+
 def test_gemm_integer_exact(ctx):
     """small-integer operands: every product and partial sum is exact in f32 -> bit-exact result;
     asymmetric W so a row/col swap in the C write cannot hide (guide: A=I check with asymmetric B)."""
