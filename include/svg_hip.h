@@ -237,6 +237,14 @@ int svg_op_gemm_cat(svg_ctx* ctx, const uint16_t* A, const uint16_t* A2, const u
 int svg_op_ff_fused(svg_ctx* ctx, const uint16_t* x, const float* ln_gamma, const float* ln_beta, const float* w1,
                     const float* b1, const float* w2, const float* b2, const uint16_t* residual, uint16_t* out, int M,
                     int C, void* stream);
+/* Cross-attention of a BasicTransformerBlock (C = 320: 8 heads of 40, context of L <= 80 tokens) in ONE kernel:
+ * out = x + to_out(softmax(to_q(LayerNorm(x)) K^T / sqrt(40)) V) + bo.  x, out (M,320) 16-bit; k (N,L,320) and vt (N,320,Lp) 16-bit: the
+ * projected context of each of the N = M / rows_per_sample samples; wq, wo (320,320), bo, LayerNorm gamma / beta (320): f32 in the
+ * state_dict layout (folded, head-padded and packed inside: test hook).  Chained form: x == NULL and a (M,320) = the self-attention's
+ * output, r (M,320) its residual, wp (320,320) / bp (320) its output projection: x = r + a wp^T + bp is formed inside the kernel. */
+int svg_op_xattn_fused(svg_ctx* ctx, const uint16_t* x, const uint16_t* a, const uint16_t* r, const float* wp, const float* bp,
+                       const float* ln_gamma, const float* ln_beta, const float* wq, const uint16_t* k, const uint16_t* vt, int Lp,
+                       const float* wo, const float* bo, uint16_t* out, int M, int rows_per_sample, int L, void* stream);
 /* dropout mask of one site of the training step: out[i] = 1/(1-p) (kept) or 0, i < n (tests regenerate the masks with it) */
 int svg_op_dropout_mask(svg_ctx* ctx, uint64_t seed, int site, float p, float* out, int64_t n, void* stream);
 /* MX block-scaled fp8 (BASELINE configs[4]): OCP e4m3 elements with one E8M0 scale per 32 consecutive K elements.
@@ -276,6 +284,9 @@ int svg_op_gemm_cat_f16(svg_ctx* ctx, const uint16_t* A, const uint16_t* A2, con
 int svg_op_ff_fused_f16(svg_ctx* ctx, const uint16_t* x, const float* ln_gamma, const float* ln_beta, const float* w1,
                         const float* b1, const float* w2, const float* b2, const uint16_t* residual, uint16_t* out, int M, int C,
                         void* stream);
+int svg_op_xattn_fused_f16(svg_ctx* ctx, const uint16_t* x, const uint16_t* a, const uint16_t* r, const float* wp, const float* bp,
+                           const float* ln_gamma, const float* ln_beta, const float* wq, const uint16_t* k, const uint16_t* vt, int Lp,
+                           const float* wo, const float* bo, uint16_t* out, int M, int rows_per_sample, int L, void* stream);
 int svg_op_quant_mx_f16(svg_ctx* ctx, const uint16_t* x, uint8_t* q, uint8_t* scales, int64_t rows, int K, void* stream);
 int svg_op_gemm_fp8_f16(svg_ctx* ctx, const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* residual, void* C,
                         int M, int N, int K, int act, int out_f32, void* stream);

@@ -193,6 +193,56 @@ int SVG_OP(svg_op_ff_fused)(svg_ctx* ctx, const uint16_t* x, const float* ln_gam
   API_END(ctx)
 }
 
+// one-launch cross-attention of a C = 320 block (xattn_fused.hip).  x (M,320): the block input (pre-LayerNorm rows, also the residual) — or,
+// chained form (a != null): x is not given, the kernel starts from a (M,320) = the self-attention's output, r its residual and wp (320,320) /
+// bp its output projection.  k (N,L,320) and vt (N,320,Lp) are the projected context of every sample (rows_per_sample rows each); weights
+// f32 in the state_dict layout; folding, padding and packing happen here (test hook).
+int SVG_OP(svg_op_xattn_fused)(svg_ctx* ctx, const uint16_t* x, const uint16_t* a, const uint16_t* r, const float* wp, const float* bp,
+                               const float* ln_gamma, const float* ln_beta, const float* wq, const uint16_t* k, const uint16_t* vt, int Lp,
+                               const float* wo, const float* bo, uint16_t* out, int M, int rows_per_sample, int L, void* stream) {
+  API_BEGIN
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int C = 320;
+  SVG_CHECK(xattn_fused_supported(C, 8, std::max(M, 128 * 192), rows_per_sample, L) && M % rows_per_sample == 0,
+            "xattn_fused op: needs 8 heads of 40, L <= 80, samples of a multiple of 128 rows (M %d, rows per sample %d, L %d)", M, rows_per_sample, L);
+  SVG_CHECK((x != nullptr) != (a != nullptr), "xattn_fused op: give either x (plain form) or a, r, wp, bp (chained form)");
+  const int N = M / rows_per_sample;
+  run_planned(ctx, [&]() {
+    float* wqd = ctx->arena.get<float>((int64_t)C * C);
+    float* wod = ctx->arena.get<float>((int64_t)C * C);
+    float* wpd = ctx->arena.get<float>((int64_t)C * C);
+    float* gd = ctx->arena.get<float>(C);
+    float* bd = ctx->arena.get<float>(C);
+    float* bod = ctx->arena.get<float>(C);
+    float* bpd = ctx->arena.get<float>(C);
+    h16* Wq = ctx->arena.get<h16>((int64_t)384 * C);
+    float* sq = ctx->arena.get<float>(384);
+    float* bq = ctx->arena.get<float>(384);
+    h16* Wo = ctx->arena.get<h16>((int64_t)C * 384);
+    h16* Wp = ctx->arena.get<h16>((int64_t)C * C);
+    h16* kp = ctx->arena.get<h16>(xattn_kv_pack_elems(N));
+    h16* vp = ctx->arena.get<h16>(xattn_kv_pack_elems(N));
+    if (SVG_LAUNCHING(ctx)) {
+      HIP_OK(hipMemcpyAsync(wqd, wq, (size_t)C * C * 4, hipMemcpyDefault, s));
+      HIP_OK(hipMemcpyAsync(wod, wo, (size_t)C * C * 4, hipMemcpyDefault, s));
+      HIP_OK(hipMemcpyAsync(gd, ln_gamma, (size_t)C * 4, hipMemcpyDefault, s));
+      HIP_OK(hipMemcpyAsync(bd, ln_beta, (size_t)C * 4, hipMemcpyDefault, s));
+      HIP_OK(hipMemcpyAsync(bod, bo, (size_t)C * 4, hipMemcpyDefault, s));
+      xattn_pack_q(wqd, gd, bd, Wq, sq, bq, a ? 1 : 0, s);
+      xattn_pack_o(wod, Wo, s);
+      xattn_pack_kv((const h16*)k, C, (int64_t)L * C, (const h16*)vt, Lp, (int64_t)C * Lp, kp, vp, N, L, s);
+      if (a) {
+        HIP_OK(hipMemcpyAsync(wpd, wp, (size_t)C * C * 4, hipMemcpyDefault, s));
+        HIP_OK(hipMemcpyAsync(bpd, bp, (size_t)C * 4, hipMemcpyDefault, s));
+        pack_linear(wpd, Wp, C, C, C, s);
+      }
+    }
+    if (a) xattn_fused(ctx, (const h16*)a, C, (const h16*)r, C, Wp, bpd, nullptr, nullptr, Wq, sq, bq, kp, vp, Wo, bod, (h16*)out, C, M, rows_per_sample, L, s);
+    else xattn_fused(ctx, (const h16*)x, C, nullptr, 0, nullptr, nullptr, nullptr, nullptr, Wq, sq, bq, kp, vp, Wo, bod, (h16*)out, C, M, rows_per_sample, L, s);
+  });
+  API_END(ctx)
+}
+
 // MX fp8 quantiser: x (rows,K) bf16 -> q (rows,K) e4m3 bytes + scales (rows,K/32) E8M0 bytes
 int SVG_OP(svg_op_quant_mx)(svg_ctx* ctx, const uint16_t* x, uint8_t* q, uint8_t* scales, int64_t rows, int K, void* stream) {
   API_BEGIN

@@ -494,3 +494,47 @@ def test_gemm_epilogue_layernorm_statistics(ctx, M, N, K, batch, res):
     else:
         assert used.value >= 0                           # small problems may take split-K (no emission): the statistics pass fills rs / rm
     assert rel_l2(rs, rstd) < 2e-5 and rel_l2(rm, rstd * mean) < 2e-5, (used.value, rel_l2(rs, rstd), rel_l2(rm, rstd * mean))
+
+
+@pytest.mark.parametrize("chain", [False, True])
+def test_xattn_fused_against_torch(ctx, chain):
+    """the one-launch cross-attention of the C = 320 blocks (xattn_fused.hip) against the same block in plain torch fp32: LayerNorm ->
+    to_q -> 8 heads of 40 over 77 context tokens -> to_out + bias + residual, per-sample contexts, 6 samples of 256 rows; the chained
+    form additionally starts from the self-attention's output (x = r + a Wp^T + bp formed inside the kernel).  Operands are rounded to
+    the storage type first; the kernel rounds q, P and O to it once more (as the three-launch form does)."""
+    C, H, D, L, Lp = 320, 8, 40, 77, 80
+    N, rows = 6, 256
+    M = N * rows
+    g = torch.Generator(device="cuda").manual_seed(5 + int(chain))
+    rnd = lambda *sh: torch.randn(*sh, device="cuda", generator=g)
+    wq, wo, wp = rnd(C, C) / math.sqrt(C), rnd(C, C) / math.sqrt(C), rnd(C, C) / math.sqrt(C)
+    bo, bp = 0.1 * rnd(C), 0.1 * rnd(C)
+    gamma, beta = 1.0 + 0.1 * rnd(C), 0.1 * rnd(C)
+    k = bf(rnd(N, L, C))
+    v = bf(rnd(N, L, C))
+    vt = torch.zeros(N, C, Lp, device="cuda", dtype=HALF.dtype)
+    vt[:, :, :L] = v.transpose(1, 2)
+    out = torch.empty(M, C, device="cuda", dtype=HALF.dtype)
+    if chain:
+        a, r = bf(rnd(M, C)), bf(rnd(M, C))
+        x32 = bf(r.float() + a.float() @ bf(wp).float().t() + bp).float()             # the block input as the kernel rounds it
+        rc = op(ctx, "xattn_fused")(ctx.h, None, u16(a), u16(r), wp.data_ptr(), bp.data_ptr(), gamma.data_ptr(), beta.data_ptr(), wq.data_ptr(),
+                                    u16(k), u16(vt), Lp, wo.data_ptr(), bo.data_ptr(), out.data_ptr(), M, rows, L, stream())
+    else:
+        x = bf(rnd(M, C))
+        x32 = x.float()
+        rc = op(ctx, "xattn_fused")(ctx.h, u16(x), None, None, None, None, gamma.data_ptr(), beta.data_ptr(), wq.data_ptr(),
+                                    u16(k), u16(vt), Lp, wo.data_ptr(), bo.data_ptr(), out.data_ptr(), M, rows, L, stream())
+    ctx.check(rc, "xattn_fused")
+    q = F.layer_norm(x32, (C,), gamma, beta, 1e-5) @ wq.t()
+    q = q.view(N, rows, H, D).transpose(1, 2)                                         # (N,H,rows,D)
+    kk = k.float().view(N, L, H, D).transpose(1, 2)
+    vv = v.float().view(N, L, H, D).transpose(1, 2)
+    p = torch.softmax(q @ kk.transpose(-1, -2) / math.sqrt(D), dim=-1)
+    o = (p @ vv).transpose(1, 2).reshape(M, C)
+    ref = x32 + o @ wo.t() + bo
+    assert torch.isfinite(out.float()).all()
+    assert rel_l2(out.float(), ref) < HALF.tol
+    # the attention branch itself (the residual dominates the norm above)
+    assert rel_l2(out.float() - x32, ref - x32) < 4 * HALF.tol
+
