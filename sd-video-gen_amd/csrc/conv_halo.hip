@@ -30,8 +30,10 @@ constexpr int NPD = 6;                 // patch DMA instructions per wave: 8 wav
 // PP = ping-pong schedule: the 8 waves run as two groups of four (one wave of each group per SIMD) staggered by one
 // barrier, so that while one group multiplies (20 MFMAs between two barriers, s_setprio 1) the other issues its fragment
 // reads and DMAs — the matrix pipe always has a wave feeding it instead of all eight loading, then all eight multiplying.
-template <int BN, bool PP>
+// MODE 0: lock-step loop, 1: ping-pong (PP), 2: merged ping-pong (below, BN = 128 with an even number of channel chunks)
+template <int BN, int MODE>
 __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
+  constexpr bool PP = MODE != 0;
   constexpr int NT = BN / 32;            // 16-wide channel tiles per wave
   constexpr int MT = 4;                  // image rows per wave
   constexpr int BIT = BN / 64;           // weight row groups per thread (64 rows per DMA instruction of all 8 waves)
@@ -237,7 +239,7 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
   // The load segment has to be shorter than the MFMA segment it hides under, so its address arithmetic is hoisted: the
   // swizzle key of a patch read is (l15 + d) & 7 with d = (18 i + tap offset) & 7 a compile-time constant, so 8 x 2
   // precomputed lane addresses + an immediate serve all 72 reads of a chunk; the weight reads need 2.
-  if (PP && cc_begin < cc_end) {
+  if (MODE == 1 && cc_begin < cc_end) {
     constexpr int N0 = (NW + 1) / 2;
     const int grp = wave_u >> 2;
 #pragma unroll
@@ -318,6 +320,88 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
     if (grp == 0) bar();
   }
 
+  // ---- merged ping-pong loop (MODE 2) ---------------------------------------------------------------------------------------------
+  // A phase of the loop above is 16 (BN = 128) or 20 (BN = 160) MFMAs per wave — 256 / 320 matrix cycles — between two barriers,
+  // against a load segment of 8-9 fragment reads + DMA issue that does not get shorter: the VAE's 128-channel convs at 512 x 512 ran
+  // at 0.29-0.35 of the peak.  Here a step (tap) is ONE phase: both k halves, 32 / 40 MFMAs between two barriers, half the barriers.
+  // The fragments of a step are read in the step's own load segment (one register set, not two): its latency runs beside the OTHER
+  // group's MFMA segment, which is what the stagger is for.
+  //   group 0:  [L(s)] P [M(s)] P [L(s+1)] ...      group 1 one barrier behind: its L(s) runs beside group 0's M(s).
+  //   L(s): read the 2 (MT + NT) fragments of step s (slab s: own pieces retired by the counted vmcnt of L(s - 1), the others'
+  //         published by the barriers since); DMA slab s + 2 -> stage (s + 2) % 3 (slab s - 1: its reads were drained — lgkmcnt(0) —
+  //         before the barrier that closed L(s - 1) in BOTH groups); patch piece (taps 0-5) of the next chunk; vmcnt(own issues): slab
+  //         s + 1 and the previous patch piece have landed; lgkmcnt(0).
+  if (MODE == 2 && cc_begin < cc_end) {
+    const int grp = wave_u >> 2;
+#pragma unroll
+    for (int i = 0; i < NPD; ++i) dma_patch_piece(cc_begin, 0, i);
+    dma_weights(cc_begin, 0, 0);
+    dma_weights(cc_begin, 1, 1);
+    wait_vm(NW);                                          // patch and slab 0 have landed; slab 1 may be in flight
+    bar();
+    if (grp == 1) bar();
+
+    int xaddr[8][2];
+#pragma unroll
+    for (int d = 0; d < 8; ++d)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        xaddr[d][kk] = (wm * 4 * PW + l15) * 128 + (((kk * 4 + lq) ^ ((l15 + d) & 7)) << 4);
+    int waddr[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) waddr[kk] = OFF_B + (wn * (BN / 2) + l15) * 128 + (((kk * 4 + lq) ^ (l15 & 7)) << 4);
+    auto rd_x = [&](int tap, int kk, h16x8 (&xf)[MT]) {
+      const int toff = (tap / 3) * PW + (tap % 3);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int rel = i * PW + toff;
+        xf[i] = *(const h16x8*)(smem + xaddr[rel & 7][kk] + rel * 128);
+      }
+    };
+    auto rd_w = [&](int stage, int kk, h16x8 (&wf)[NT]) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wf[j] = *(const h16x8*)(smem + waddr[kk] + stage * B_BYTES + j * 2048);
+    };
+
+    for (int cc = cc_begin; cc < cc_end; ++cc) {
+      const int pbuf = (cc - cc_begin) & 1;
+      const int hn = (cc + 1 < cc_end) ? 1 : 0;
+      if (cc != cc_begin) {                                // this chunk's patch sits in the other buffer
+        const int flip = pbuf ? PBUF : -PBUF;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) { xaddr[d][0] += flip; xaddr[d][1] += flip; }
+      }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const bool more_w = tap < 7 || hn;                    // slab s + 2 exists
+        const int wcc = tap < 7 ? cc : cc + 1, wtap = (tap + 2) % 9;
+        const bool pp = tap < NPD && hn;
+        h16x8 x0[MT], x1[MT], w0[NT], w1[NT];
+        rd_x(tap, 0, x0); rd_w(tap % NWS, 0, w0);
+        rd_x(tap, 1, x1); rd_w(tap % NWS, 1, w1);
+        if (more_w) dma_weights(wcc, wtap, (tap + 2) % NWS);
+        if (pp) dma_patch_piece(cc + 1, pbuf ^ 1, tap);
+        wait_vm((more_w ? NW : 0) + (pp ? 1 : 0));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bar();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = MFMA_16x16x32(w0[j], x0[i], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = MFMA_16x16x32(w1[j], x1[i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        bar();
+      }
+    }
+    if (grp == 0) bar();
+  }
+
   // ---- lock-step main loop over steps s = (cc, tap): weight slab s lives in stage s % 3; the patch alternates per chunk
   // iteration s:  wait until slab s (and anything older) has landed, leaving only slab s+1 (and a just-issued patch)
   //               in flight -> barrier (everyone's pieces landed; stage (s+2)%3 and, at tap 0, the other patch buffer
@@ -371,10 +455,10 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
   }
 }
 
-template <int BN, bool PP>
+template <int BN, int MODE>
 void launch_halo(const GemmArgs& g, dim3 grid, hipStream_t s) {
   constexpr int smem = 2 * PPIX * 128 + 3 * BN * 128 + 8192;
-  hipLaunchKernelGGL((conv_halo_kernel<BN, PP>), grid, dim3(512), smem, s, g);
+  hipLaunchKernelGGL((conv_halo_kernel<BN, MODE>), grid, dim3(512), smem, s, g);
 }
 
 }  // namespace
@@ -406,17 +490,25 @@ int conv_halo_bn(const GemmArgs& g) {
 }
 
 void conv_halo_init_device() {
-  HIP_OK(hipFuncSetAttribute((const void*)conv_halo_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PPIX * 128 + 3 * 128 * 128 + 8192));
-  HIP_OK(hipFuncSetAttribute((const void*)conv_halo_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PPIX * 128 + 3 * 128 * 128 + 8192));
-  HIP_OK(hipFuncSetAttribute((const void*)conv_halo_kernel<160, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PPIX * 128 + 3 * 160 * 128 + 8192));
-  HIP_OK(hipFuncSetAttribute((const void*)conv_halo_kernel<160, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PPIX * 128 + 3 * 160 * 128 + 8192));
+  HIP_OK(hipFuncSetAttribute((const void*)conv_halo_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PPIX * 128 + 3 * 128 * 128 + 8192));
+  HIP_OK(hipFuncSetAttribute((const void*)conv_halo_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PPIX * 128 + 3 * 128 * 128 + 8192));
+  HIP_OK(hipFuncSetAttribute((const void*)conv_halo_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PPIX * 128 + 3 * 128 * 128 + 8192));
+  HIP_OK(hipFuncSetAttribute((const void*)conv_halo_kernel<160, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PPIX * 128 + 3 * 160 * 128 + 8192));
+  HIP_OK(hipFuncSetAttribute((const void*)conv_halo_kernel<160, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PPIX * 128 + 3 * 160 * 128 + 8192));
+  HIP_OK(hipFuncSetAttribute((const void*)conv_halo_kernel<160, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PPIX * 128 + 3 * 160 * 128 + 8192));
 }
 
 void launch_conv_halo(const GemmArgs& g, dim3 grid, hipStream_t s) {
   static const int pp = getenv("SVG_HALO_PP") ? atoi(getenv("SVG_HALO_PP")) : 1;
   const bool w160 = conv_halo_bn(g) == 160;
-  if (pp) { if (w160) launch_halo<160, true>(g, grid, s); else launch_halo<128, true>(g, grid, s); }
-  else    { if (w160) launch_halo<160, false>(g, grid, s); else launch_halo<128, false>(g, grid, s); }
+  // merged ping-pong (one 32 / 40-MFMA phase per tap); SVG_HALO_MERGE (read per call): 0 off, 1 BN = 128 only, 2 / unset both widths
+  const char* em = getenv("SVG_HALO_MERGE");
+  const int mm = em ? atoi(em) : 2;
+  if (pp && mm >= 2 && w160) { launch_halo<160, 2>(g, grid, s); return; }
+  if (pp && mm >= 1 && !w160) { launch_halo<128, 2>(g, grid, s); return; }
+  if (false) {}
+  else if (pp) { if (w160) launch_halo<160, 1>(g, grid, s); else launch_halo<128, 1>(g, grid, s); }
+  else    { if (w160) launch_halo<160, 0>(g, grid, s); else launch_halo<128, 0>(g, grid, s); }
 }
 
 }  // namespace SDNS

@@ -134,7 +134,45 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs g) {
   // ---- main loop: same phase structure, RAW / WAR argument and vmcnt accounting as conv_halo.hip's ping-pong loop:
   // step s (slab s, stage s % 3) = phase 0 [reads of its second k half; first NA DMAs of slab s+2; wait until only those
   // are in flight -> slab s+1 landed] + phase 1 [reads of the first k half of slab s+1; the other DMAs of slab s+2].
-  {
+  if (g.pp_merge) {
+    // merged form (as conv_halo.hip's MODE 2): a slab is ONE phase of 2 * MT * NT MFMAs between two barriers; its fragments are read in
+    // its own load segment (one register set), whose latency runs beside the other group's MFMA segment.
+    //   L(s): read slab s; DMA slab s + 2 -> stage (s + 2) % 3 (slab s - 1: drained by both groups before the barriers since);
+    //         vmcnt(own issues) -> slab s + 1 landed; lgkmcnt(0).
+    const int grp = wave_u >> 2;
+    dma_part(0, 0, 0, NW);
+    dma_part(1, 1, 0, NW);
+    wait_vm(NW);
+    bar();
+    if (grp == 1) bar();
+    int st = 0;
+    for (int s = 0; s < KT; ++s) {
+      const bool more = s + 2 < KT;
+      const int st2 = st == 0 ? 2 : st - 1;
+      h16x8 x0[MT], w0[NT], x1[MT], w1[NT];
+      rd(st, 0, x0, w0);
+      rd(st, 1, x1, w1);
+      if (more) dma_part(s + 2, st2, 0, NW);
+      wait_vm(more ? NW : 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      bar();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = MFMA_16x16x32(w0[j], x0[i], acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = MFMA_16x16x32(w1[j], x1[i], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      bar();
+      st = st == 2 ? 0 : st + 1;
+    }
+    if (grp == 0) bar();
+  } else {
     const int grp = wave_u >> 2;
     dma_part(0, 0, 0, NW);
     dma_part(1, 1, 0, NW);
@@ -212,6 +250,8 @@ void launch_gemm_pp(const GemmArgs& g0, hipStream_t s) {
   static const int gm_env = getenv("SVG_PP_GROUPM") ? atoi(getenv("SVG_PP_GROUPM")) : 4;
   GemmArgs g = g0;
   g.group_m = gm_env;
+  const char* em = getenv("SVG_PP_MERGE");                  // read per call: 0 = the two-phase loop
+  g.pp_merge = em ? atoi(em) : 1;
   if (gemm_pp_bn(g) == 160) launch_pp<160>(g, s);
   else launch_pp<128>(g, s);
 }
