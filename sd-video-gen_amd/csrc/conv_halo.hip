@@ -56,7 +56,11 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
 
   // tile order: the channel tiles of one pixel block are adjacent (they share the patch through L2)
   const int tiles_n = (g.N + BN - 1) / BN;
-  const int bx_n = g.W >> 4, by_n = g.H >> 4;
+  // nearest-2x upsample fused in front (A_CONV_UP2: the VAE / UNet upsamplers): the conv runs over the OH x OW upsampled image, patch pixel
+  // (yy, xx) of it is source pixel (yy >> 1, xx >> 1) — only the DMA source offsets change, the LDS patch holds the upsampled pixels
+  const bool up2 = g.amode == A_CONV_UP2;
+  const int OH = up2 ? g.Ho : g.H, OW = up2 ? g.Wo : g.W;
+  const int bx_n = OW >> 4, by_n = OH >> 4;
   int tile;
   {
     const int nblk = gridDim.x, bid = blockIdx.x;
@@ -82,7 +86,7 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
   const int cc_begin = ks * cc_per;
   const int cc_end = min(CC, cc_begin + cc_per);
 
-  const unsigned a_bytes = (unsigned)((int64_t)(g.M / (g.H * g.W)) * g.H * g.W * g.Cin * 2);
+  const unsigned a_bytes = (unsigned)((int64_t)(g.M / (OH * OW)) * g.H * g.W * g.Cin * 2);
   const unsigned b_bytes = (unsigned)(((int64_t)(g.n_valid - 1) * g.ldb + g.K) * 2);
   // buffer descriptors: {base[31:0], base[47:32] (stride 0), num_records, flags}
   const uint64_t pa = (uint64_t)g.A, pw = (uint64_t)g.Wt;
@@ -99,8 +103,9 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
     const int c = pos ^ (pp & 7);
     const int py = pp / PW, px = pp - py * PW;
     const int yy = y0 - 1 + py, xx = x0 - 1 + px;
-    const bool ok = pp < PPIX && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W;
-    return ok ? (unsigned)(((b * g.H + yy) * g.W + xx) * g.Cin + c * 8) * 2u : INVALID;
+    const bool ok = pp < PPIX && (unsigned)yy < (unsigned)OH && (unsigned)xx < (unsigned)OW;
+    const int sy = up2 ? yy >> 1 : yy, sx = up2 ? xx >> 1 : xx;
+    return ok ? (unsigned)(((b * g.H + sy) * g.W + sx) * g.Cin + c * 8) * 2u : INVALID;
   };
   // the lock-step loop keeps the six offsets in registers; the ping-pong loop (one piece per step, registers are its
   // scarce resource) recomputes the piece's offset when it issues it
@@ -440,7 +445,7 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
 
   // ---- epilogue -----------------------------------------------------------------------------------------------
   if (ABL == 1 && acc[0][0][0] != 12345.f) return;
-  const int mr = (b * g.H + y0 + wm * 4) * g.W + x0 + l15;      // image row i of the wave adds i * W
+  const int mr = (b * OH + y0 + wm * 4) * OW + x0 + l15;        // image row i of the wave adds i * OW
   const int nc = n0 + wn * (BN / 2) + lq * 4;
   if (g.splitk > 1) {
 #pragma unroll
@@ -448,10 +453,10 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int n = nc + j * 16;
-        if (n < g.N) *(f32x4*)(g.slabs + ((int64_t)ks * g.M + mr + i * g.W) * g.N + n) = acc[i][j];
+        if (n < g.N) *(f32x4*)(g.slabs + ((int64_t)ks * g.M + mr + i * OW) * g.N + n) = acc[i][j];
       }
   } else {
-    epi_tile<MT, NT>(g, 0, mr, g.W, nc, acc, smem, 4, wm, wn, tile_m, n0);
+    epi_tile<MT, NT>(g, 0, mr, OW, nc, acc, smem, 4, wm, wn, tile_m, n0);
   }
 }
 
@@ -469,8 +474,11 @@ int conv_halo_bn(const GemmArgs& g);
 // every CU a workgroup (below that the 128-row implicit GEMM with its split-K is faster: same-box A/B at 16x16 images)
 bool conv_halo_supported(const GemmArgs& g) {
   static const int off = getenv("SVG_NO_HALO") ? atoi(getenv("SVG_NO_HALO")) : 0;
-  if (off || g.amode != A_CONV_S1 || g.Cin % 64 != 0 || g.H % 16 != 0 || g.W % 16 != 0 || g.batch != 1 || g.out_f32 ||
-      g.act == ACT_GEGLU || g.N < 128 || g.Ho != g.H || g.Wo != g.W)
+  static const int up_on = getenv("SVG_HALO_UP2") ? atoi(getenv("SVG_HALO_UP2")) : 1;
+  const bool s1 = g.amode == A_CONV_S1 && g.Ho == g.H && g.Wo == g.W;
+  const bool up = up_on && g.amode == A_CONV_UP2 && g.Ho == 2 * g.H && g.Wo == 2 * g.W && !g.A2;
+  if (off || !(s1 || up) || g.Cin % 64 != 0 || g.Ho % 16 != 0 || g.Wo % 16 != 0 || g.batch != 1 || g.out_f32 ||
+      g.act == ACT_GEGLU || g.N < 128)
     return false;
   static const int min_wg = getenv("SVG_HALO_MIN") ? atoi(getenv("SVG_HALO_MIN")) : 192;
   return (int64_t)(g.M / 256) * cdiv(g.N, conv_halo_bn(g)) >= min_wg;

@@ -453,6 +453,27 @@ def test_conv3x3_halo_integer_exact(ctx):
         assert torch.equal(out.float(), ref.to(HALF.dtype).float()), (B, H, W, Cin, Cout)   # sums are exact; only the bf16 store rounds
 
 
+def test_conv3x3_halo_upsample_integer_exact(ctx):
+    """the nearest-2x upsample fused in front of the conv (VAE / UNet upsamplers) on the halo kernel: the 18 x 18 patch of the
+    UPSAMPLED image is gathered from source pixels (y >> 1, x >> 1); integer data -> bit for bit, incl. the borders of the upsampled
+    image and odd block seams; the profile tag shows the halo kernel took the call."""
+    g = torch.Generator(device="cuda").manual_seed(8)
+    for (B, H, W, Cin, Cout) in [(6, 16, 16, 64, 1024), (8, 24, 16, 128, 640), (6, 32, 32, 192, 320)]:      # output 2H x 2W: >= 192 workgroups
+        x = bf(torch.randint(-2, 3, (B, H, W, Cin), device="cuda", generator=g).float())
+        w = torch.randint(-2, 3, (Cout, Cin, 3, 3), device="cuda", generator=g).float()
+        b = torch.randint(-3, 4, (Cout,), device="cuda", generator=g).float()
+        ref = conv_ref(x, w, b, 3)
+        assert ref.shape == (B, 2 * H, 2 * W, Cout)
+        out = torch.empty(ref.shape, device="cuda", dtype=HALF.dtype)
+        ctx.prof_reset(); ctx.prof_enable(True, detail=True)
+        ctx.check(op(ctx, "conv3x3")(ctx.h, u16(x), w.data_ptr(), b.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout, 3, stream()), "conv")
+        torch.cuda.synchronize()
+        tags = [k for k in ctx.prof_report() if k.startswith("@conv3x3|")]
+        ctx.prof_enable(False)
+        assert any(t.endswith("_halo") for t in tags), tags
+        assert torch.equal(out.float(), ref.to(HALF.dtype).float()), (B, H, W, Cin, Cout)
+
+
 def test_resize_nearest_u8(ctx):
     g = torch.Generator(device="cuda").manual_seed(9)
     img = torch.randint(0, 256, (2, 64, 64, 3), device="cuda", dtype=torch.uint8, generator=g)
