@@ -8,6 +8,9 @@ bench.py --gpus N ...`, RANK/LOCAL_RANK/WORLD_SIZE in the env) or, when WORLD_SI
 torch.distributed.run itself BEFORE it touches the GPU and exits with the children's code (no process that has
 initialised HIP is ever re-exec'ed).
 
+`--workload cfg1|cfg3|cfg4` runs BASELINE.json's other configs (S = 25 x 8 frames at F=64; F=128 x 16 frames; text + guidance 7.5, MX-fp8)
+with the same contract; the default is configs[2]:
+
 Workload (BASELINE.json configs[2], the one the metric is quoted on): config 1_16_kitti_L1_64 (F=64 frames,
 latent Transformer d=2048 4enc/8dec, 437.6 M params) with --denoise --denoise_start_step 0: per generated
 frame one Transformer forward, VAE decode @64, VAE encode @512x512, 50 DDIM steps of the SD-v1.4 UNet at
@@ -25,10 +28,33 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_BF16 = 2.5e15        # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_BF16 = 2.5e15        # dense bf16 / fp16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_FP8 = 5.0e15         # dense MX-fp8 MFMA (same table)
 PEAK_HBM = 8.0e12
 UNET_FLOP = 803.27e9      # per sample per call
-FRAME_FLOP = 43.85e12     # per generated frame, denoise @512, 50 steps, F=64, guidance 0
+VAE_FLOP = {"enc": {64: 16.9e9, 128: 67.8e9, 512: 1116.7e9}, "dec": {64: 38.8e9, 128: 155.1e9, 512: 2514.5e9}}
+
+# BASELINE.json's workloads.  The driver's default line is configs[2] (the one the metric is quoted on); the others are
+# `--workload cfgN` lines kept under profiles/ (VERDICT r03 #5).  `dtype` None = the --dtype default (fp16, the reference's autocast).
+WORKLOADS = {
+    "cfg1": dict(idx=1, config="1_19_ball_complex_L1_64", pred_frames=8, start_step=25, guidance=0.0, text=False, dtype="bf16",
+                 what="bouncing-ball 64x64, 8 predicted frames, --denoise --denoise_start_step 25 (25 DDIM steps per frame)"),
+    "cfg2": dict(idx=2, config="1_16_kitti_L1_64", pred_frames=1, start_step=0, guidance=0.0, text=False, dtype=None,
+                 what="64x64 latents -> 512x512 VAE passes, 50-step DDIM"),
+    "cfg3": dict(idx=3, config="11_27_ucf_final", pred_frames=16, start_step=0, guidance=0.0, text=False, dtype=None,
+                 what="F=128, 16 predicted frames, 50-step DDIM per frame, clips sharded over the GPUs"),
+    "cfg4": dict(idx=4, config="11_27_ucf_text_final", pred_frames=16, start_step=0, guidance=7.5, text=True, dtype="fp8",
+                 what="text-conditioned Transformer (d = 2432) + CLIP prompt per clip, guidance_scale 7.5 (batch-2 UNet calls), F=128, "
+                      "16 predicted frames, 50-step DDIM per frame"),
+}
+
+
+def frame_flop(F, n_unet_calls, unet_batch_per_clip):
+    """algorithmic FLOP per generated frame: the UNet calls, VAE enc + dec at 512x512 and at FxF, ~5 GFLOP of Transformer"""
+    return n_unet_calls * unet_batch_per_clip * UNET_FLOP + VAE_FLOP["enc"][512] + VAE_FLOP["dec"][512] + VAE_FLOP["enc"][F] + VAE_FLOP["dec"][F] + 5e9
+
+
+DTYPES = ["bf16", "fp16", "fp8"]
 
 
 def parse():
@@ -38,11 +64,14 @@ def parse():
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--clips", type=int, default=56, help="clips sampled in lock step per GPU")
     p.add_argument("--streams", type=int, default=2, help="concurrent clip groups per GPU (own context + stream each)")
-    p.add_argument("--pred_frames", type=int, default=1)
-    p.add_argument("--start_step", type=int, default=0)
-    p.add_argument("--config", type=str, default="1_16_kitti_L1_64")
+    p.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2",
+                   help="which BASELINE.json config the step runs (default cfg2 = configs[2], the one the metric is quoted on); "
+                        "sets --config / --pred_frames / --start_step / guidance / text conditioning / the config's named dtype")
+    p.add_argument("--pred_frames", type=int, default=None)
+    p.add_argument("--start_step", type=int, default=None)
+    p.add_argument("--config", type=str, default=None)
     p.add_argument("--no-denoise", action="store_true")
-    p.add_argument("--dtype", choices=["bf16", "fp16", "fp8"], default=os.environ.get("SVG_BENCH_DTYPE", "fp16"),
+    p.add_argument("--dtype", choices=DTYPES, default=None,
                    help="storage type of the SD networks (f32 accumulation): fp16 (default: the reference's autocast arithmetic, "
                         "sd_utils.py:246; UNet call 1.2e-3 from the fp32 oracle), bf16 (BASELINE configs[1] names it; 1e-2, ~3.6 %% faster), fp8 = BASELINE configs[4]: qualifying dense projections of the UNet in MX "
                         "block-scaled fp8 (the rest stays bf16)")
@@ -51,7 +80,20 @@ def parse():
                         "one step = forward in train mode + criterion + backward + Adam on the config's own batch")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
-    return p.parse_args()
+    args = p.parse_args()
+    wl = WORKLOADS[args.workload]
+    if args.dtype is None:
+        # argparse does not check a DEFAULT against `choices`: validate the environment's value by hand (a typo such as
+        # 'float16' used to fall through to bf16 and the line was labelled bf16)
+        env = os.environ.get("SVG_BENCH_DTYPE")
+        if env is not None and env not in DTYPES:
+            p.error("SVG_BENCH_DTYPE=%r is not one of %s" % (env, ", ".join(DTYPES)))
+        args.dtype = env or wl["dtype"] or "fp16"
+    for k in ("config", "pred_frames", "start_step"):
+        if getattr(args, k) is None:
+            setattr(args, k, wl[k])
+    args.guidance, args.text = wl["guidance"], wl["text"]
+    return args
 
 
 def host_cores():
@@ -76,11 +118,11 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(cfg_name, start_step, denoise=True):
+def cpu_baseline(cfg_name, start_step, denoise=True, guidance=0.0, text=False):
     """The CPU restatement (oracle/, kind "port": the reference's own Python cannot travel to the GPU box) timed on this
-    host's cores on a bounded sample of the same per-frame work: the latent Transformer forward, ONE batch-1 UNet step
-    (the DDIM loop repeats it 50 - start_step times: linear extrapolation, stated), and the VAE passes at 512x512 and at
-    F x F timed directly."""
+    host's cores on a bounded sample of the same per-frame work: the latent Transformer forward (the text-conditioned one for
+    configs[4]), ONE batch-1 UNet step (the DDIM loop repeats it (50 - start_step) x (2 under guidance) times: linear
+    extrapolation, stated), and the VAE passes at 512x512 and at F x F timed directly."""
     import torch
     from oracle import sd_oracle as SO, transformer_oracle as TO
     from sd_video_gen_amd import sd_layout
@@ -97,16 +139,23 @@ def cpu_baseline(cfg_name, start_step, denoise=True):
     with torch.no_grad():
         # latent Transformer at the configured size (weights drawn by torch.nn init, as the reference's)
         from sd_video_gen_amd import config as svg_config
-        from sd_video_gen_amd.transformer import Transformer
         svg_config.set_args(["--dataset", "synthetic-ball", "--config", cfg_name])
         cfg = svg_config.load_config(cfg_name)
         torch.manual_seed(0)
-        m = Transformer(dim_model=cfg.DIM_MODEL[0], num_heads=cfg.NUM_HEADS[0], num_encoder_layers=cfg.NUM_ENCODER_LAYERS[0],
-                        num_decoder_layers=cfg.NUM_DECODER_LAYERS[0], dropout_p=cfg.DROPOUT_P[0])
-        sd = m.state_dict()
+        kw = dict(dim_model=cfg.DIM_MODEL[0], num_heads=cfg.NUM_HEADS[0], num_encoder_layers=cfg.NUM_ENCODER_LAYERS[0],
+                  num_decoder_layers=cfg.NUM_DECODER_LAYERS[0], dropout_p=cfg.DROPOUT_P[0])
+        txt = None
+        if text:
+            from sd_video_gen_amd.transformer_text import Transformer as TextTransformer
+            m = TextTransformer(text_encoder="hash", **kw)
+            txt = torch.nn.functional.normalize(torch.randn(1, 384), dim=1)
+        else:
+            from sd_video_gen_amd.transformer import Transformer
+            m = Transformer(**kw)
+        sd = {k: v for k, v in m.state_dict().items() if not k.startswith("sent_transformer.")}
         D = m.d_lat
         X = torch.randn(1, 6, D)
-        timed("transformer", lambda: TO.predict(sd, X, cfg.NUM_HEADS[0]), reps=5 if denoise else 40)
+        timed("transformer", lambda: TO.predict(sd, X, cfg.NUM_HEADS[0], txt=txt), reps=5 if denoise else 40)
         del m, sd
         if not denoise:
             return {"value": 1.0 / t["transformer"], "unit": "frames/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
@@ -127,12 +176,13 @@ def cpu_baseline(cfg_name, start_step, denoise=True):
         timed("vae_enc_F", lambda: SO.encode_img(vsd, imgF))
         zF = torch.randn(1, 4, F // 8, F // 8) * 0.2
         timed("vae_dec_F", lambda: SO.decode_img_latents(vsd, zF))
-    n_unet = 50 - start_step
+    n_unet = (50 - start_step) * (2 if guidance != 0.0 else 1)
     per_frame = t["transformer"] + n_unet * t["unet_step_b1"] + t["vae_enc_512"] + t["vae_dec_512"] + t["vae_enc_F"] + t["vae_dec_F"]
     return {"value": 1.0 / per_frame, "unit": "frames/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
-            "sample": "oracle (plain torch fp32) on %d host threads: 1 Transformer fwd %.3fs, 1 batch-1 UNet step %.2fs (mean of 2; x%d DDIM steps extrapolated: "
-                      "every step is the same call), VAE enc + dec at 512x512 %.2fs + %.2fs and at %dx%d %.2fs + %.2fs timed directly"
-                      % (cores, t["transformer"], t["unet_step_b1"], n_unet, t["vae_enc_512"], t["vae_dec_512"], F, F, t["vae_enc_F"], t["vae_dec_F"])}
+            "sample": "oracle (plain torch fp32) on %d host threads: 1 %sTransformer fwd %.3fs, 1 batch-1 UNet step %.2fs (mean of 2; x%d UNet sample-calls per frame "
+                      "extrapolated: every step is the same call%s), VAE enc + dec at 512x512 %.2fs + %.2fs and at %dx%d %.2fs + %.2fs timed directly"
+                      % (cores, "text-conditioned " if text else "", t["transformer"], t["unet_step_b1"], n_unet,
+                         ", two samples per step under guidance" if guidance != 0.0 else "", t["vae_enc_512"], t["vae_dec_512"], F, F, t["vae_enc_F"], t["vae_dec_F"])}
 
 
 def self_launch(args):
@@ -244,15 +294,20 @@ def roofline_pass(args, sd_utils, step, denoise, C, model=None):
             e["traffic_source"] = "profiles/%s (%s)" % (pmc[0], pmc[1].get("note", ""))
         by_family[k] = e
     dom_name = max((k for k in by_family if by_family[k]["bound"] == "mfma"), key=lambda k: by_family[k]["ms"])
+    per_clip = 2 if args.guidance != 0.0 else 1          # UNet samples per clip and call (the CFG pair is algorithmic at guidance 7.5)
+    fflop = frame_flop(sd_utils.config.FRAME_SIZE, 50 - args.start_step, per_clip)
     out["roofline"] = dict(by_family[dom_name], family=dom_name, by_family=by_family,
                            instrumented_pass="one stream group (%d clips) run alone with hipEvent brackets around every launch" % n_grp,
-                           whole_frame_frac_of_mfma_peak=FRAME_FLOP * n_grp * args.pred_frames / (tot_ms * 1e-3) / PEAK_BF16)
+                           algorithmic_flop_per_frame=fflop,
+                           whole_frame_frac_of_mfma_peak=fflop * n_grp * args.pred_frames / (tot_ms * 1e-3) / PEAK_BF16)
     if outer and outer["calls"]:
         t_step = outer["ms"] / outer["calls"] * 1e-3
-        out["roofline"]["unet_step"] = {"calls": outer["calls"], "ms_per_call": t_step * 1e3, "samples": n_grp,
-                                        "achieved": UNET_FLOP * n_grp / t_step / 1e12, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                                        "frac": UNET_FLOP * n_grp / t_step / PEAK_BF16,
-                                        "definition": "803.27e9 FLOP x samples / time of one UNet call + scheduler step (SURVEY 8d)"}
+        nb = n_grp * per_clip
+        out["roofline"]["unet_step"] = {"calls": outer["calls"], "ms_per_call": t_step * 1e3, "samples": nb,
+                                        "achieved": UNET_FLOP * nb / t_step / 1e12, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                                        "frac": UNET_FLOP * nb / t_step / PEAK_BF16,
+                                        "definition": "803.27e9 FLOP x samples / time of one UNet call + scheduler step (SURVEY 8d); "
+                                                      "peak = the 16-bit MFMA peak also under --dtype fp8 (5.0e15 there would be: frac / 2)"}
     out["families"] = fam
     return out
 
@@ -388,6 +443,7 @@ def main():
     if args.train:
         return train_bench(args, rank, local_rank, world, dist)
     denoise = not args.no_denoise
+    wl = WORKLOADS[args.workload]
     argv = ["--dataset", "synthetic-ball", "--config", args.config, "--pred_frames", str(args.pred_frames),
             "--denoise_start_step", str(args.start_step)] + (["--denoise", "True"] if denoise else [])
     svg_config.set_args(argv)
@@ -395,40 +451,62 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.manual_seed(0)
     fp8 = args.dtype == "fp8"
-    sd_dtype = "fp16" if args.dtype == "fp16" else "bf16"
+    sd_dtype = "fp16" if args.dtype in ("fp16", "fp8") else "bf16"      # fp8: e4m3 operands where they pay, fp16 storage elsewhere
+    if os.environ.get("SVG_FP8_BASE"):
+        sd_dtype = os.environ["SVG_FP8_BASE"]
+    guidance = args.guidance if denoise else 0.0
+
+    def build_model(ctx=None):
+        torch.manual_seed(0)
+        kw = dict(num_tokens=0, dim_model=cfg.DIM_MODEL[0], num_heads=cfg.NUM_HEADS[0], num_encoder_layers=cfg.NUM_ENCODER_LAYERS[0],
+                  num_decoder_layers=cfg.NUM_DECODER_LAYERS[0], dropout_p=cfg.DROPOUT_P[0])
+        if args.text:
+            from sd_video_gen_amd.transformer_text import Transformer as TextTransformer
+            m = TextTransformer(st_weights="synthetic", **kw).eval()
+        else:
+            m = Transformer(**kw).eval()
+        return m.use_context(ctx) if ctx is not None else m
+
     sd_utils = SDUtils(weights="synthetic", seed=0, verbose=(rank == 0), fp8=fp8, dtype=sd_dtype)
-    torch.manual_seed(0)
-    model = Transformer(num_tokens=0, dim_model=cfg.DIM_MODEL[0], num_heads=cfg.NUM_HEADS[0],
-                        num_encoder_layers=cfg.NUM_ENCODER_LAYERS[0], num_decoder_layers=cfg.NUM_DECODER_LAYERS[0],
-                        dropout_p=cfg.DROPOUT_P[0]).eval()
+    model = build_model()
     F = cfg.FRAME_SIZE
     C = args.clips
     n_global = C * world
     a, b = sharding.shard_range(n_global, rank, world)
     clips = bouncing_ball_clips(b - a, F, 5, seed=a, device=dev)          # resident in HBM before timing
     seeds = sharding.clip_seeds(1234, a, b)
-    emb = sd_utils.encode_text([""]) if denoise else None
+    emb, cls_emb = None, None
+    if denoise and args.text:
+        # configs[4]: one UCF-101 class per clip; the class name conditions the Transformer (MiniLM sentence embedding, once per clip)
+        # and its prompt the UNet (CLIP, [uncond(C); cond(C)] rows; evaluation/predict_fvd2_denoise.py:203,227-229) — both constant
+        # over a clip's frames, so computed before the timed region like the '' embedding of configs[2] (hoisted, exact)
+        names = ["ApplyEyeMakeup", "Archery", "BabyCrawling", "Basketball", "BenchPress", "Biking", "Bowling", "WallPushups"]
+        cls = [names[(a + i) % len(names)] for i in range(b - a)]
+        emb = sd_utils.encode_text(["a person doing " + c for c in cls])
+        cls_emb = model.encode_classes(cls).to(dev)
+    elif denoise:
+        emb = sd_utils.encode_text([""])
 
     workers = [(model, sd_utils, torch.cuda.Stream())]
     for _ in range(1, args.streams):
         c2 = _lib.Context(local_rank)
         torch.manual_seed(0)
         sdu2 = SDUtils(weights="synthetic", seed=0, verbose=False, ctx=c2, fp8=fp8, dtype=sd_dtype)
-        torch.manual_seed(0)
-        m2 = Transformer(num_tokens=0, dim_model=cfg.DIM_MODEL[0], num_heads=cfg.NUM_HEADS[0],
-                         num_encoder_layers=cfg.NUM_ENCODER_LAYERS[0], num_decoder_layers=cfg.NUM_DECODER_LAYERS[0],
-                         dropout_p=cfg.DROPOUT_P[0]).eval().use_context(c2)
-        workers.append((m2, sdu2, torch.cuda.Stream()))
+        workers.append((build_model(c2), sdu2, torch.cuda.Stream()))
+    kw_s = dict(denoise=denoise, start_step=args.start_step, text_embeddings=emb, guidance_scale=guidance)
 
     def step(gather=True):
         if args.streams > 1 and gather:
-            lat = sample_clips_streams(workers, clips, args.pred_frames, seeds, denoise=denoise, start_step=args.start_step,
-                                       text_embeddings=emb)
+            lat = sample_clips_streams(workers, clips, args.pred_frames, seeds, cls_list=cls_emb, **kw_s)
         else:
             # single-stream form; the rank-0 instrumented pass (gather=False) times one stream group's share of the clips
-            n1 = clips.shape[0] if gather else max(1, clips.shape[0] // args.streams)
-            lat = sample_clips(model, sd_utils, clips[:n1], args.pred_frames, denoise=denoise, start_step=args.start_step,
-                               seeds=seeds[:n1], text_embeddings=emb)
+            n = clips.shape[0]
+            n1 = n if gather else max(1, n // args.streams)
+            kw1 = dict(kw_s)
+            if emb is not None and emb.shape[0] == 2 * n and n > 1:
+                kw1["text_embeddings"] = torch.cat([emb[:n1], emb[n:n + n1]])
+            lat = sample_clips(model, sd_utils, clips[:n1], args.pred_frames, seeds=seeds[:n1],
+                               cls_list=(cls_emb[:n1] if cls_emb is not None else None), **kw1)
         return sharding.gather_clips(lat, n_global) if gather else lat
 
     def sync():
@@ -452,25 +530,30 @@ def main():
     frames = n_global * args.pred_frames * args.steps
     fps = frames / dt
 
-    metric = "generated frames/sec at 50 DDIM denoise steps, 512x512" if denoise else \
+    n_steps = 50 - args.start_step
+    metric = ("generated frames/sec at %d DDIM denoise steps, 512x512" % n_steps) if denoise else \
         "generated frames/sec, 64x64 no-denoise (latent Transformer only)"
+    # what actually ran, read back from the library (the requested string is not evidence)
+    ran_dtype = sd_utils.ctx.model_dtype(_lib.SVG_UNET) if denoise else "f32"
+    if denoise and fp8:
+        ran_dtype = "fp8 (MX e4m3: 3x3 convs + qualifying projections) + " + ran_dtype
     line = {"metric": metric, "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("fp8 (MX e4m3 projections) + bf16" if fp8 else sd_dtype) if denoise else "f32", "data": "synthetic",
+            "dtype": ran_dtype, "data": "synthetic",
             "ranks_seen": (dist.get_world_size() if world > 1 else 1),
-            "config": {"workload": "configs[2]: %s F=%d, --denoise --denoise_start_step %d (%d DDIM steps of the SD-v1.4 UNet at 64x64 latents, "
-                                   "VAE enc/dec at 512x512), guidance_scale 0" % (args.config, F, args.start_step, 50 - args.start_step)
-                                   + ("; the UNet's qualifying dense projections in MX block-scaled fp8 — the ARITHMETIC of configs[4], on configs[2]'s "
-                                      "workload (not configs[4]'s text-conditioned guidance-7.5 batch-2 UNet: tests/test_configs_gpu.py covers that one)" if fp8 else "")
+            "config": {"workload": ("configs[%d]: %s F=%d, %s; --denoise --denoise_start_step %d, guidance_scale %g; SD-v1.4 UNet at 64x64 latents, VAE enc/dec at 512x512"
+                                    % (wl["idx"], args.config, F, wl["what"], args.start_step, guidance)
+                                    + ("; MX block-scaled fp8 arithmetic (the dtype configs[4] names) on this workload" if fp8 and args.workload != "cfg4" else ""))
                        if denoise else "%s F=%d no --denoise (latent Transformer only)" % (args.config, F),
                        "clips_per_gpu": C, "streams_per_gpu": args.streams, "pred_frames": args.pred_frames, "global_clips": n_global, "parallelism": "clip-sharded dp%d" % world,
                        "weights": "seeded random init (SD v1.4 architecture, %s)" % args.config}}
 
     if rank == 0 and not args.no_roofline:
         line.update(roofline_pass(args, sd_utils, step, denoise, C, model))
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(args.config, args.start_step, denoise)
+    if rank == 0 and not args.no_cpu_baseline:
+        # rank 0 only; at N > 1 the other ranks wait in the barrier below (the N > 1 lines carry the baseline too)
+        line["cpu_baseline"] = cpu_baseline(args.config, args.start_step, denoise, guidance, args.text)
     if rank == 0:
         print(json.dumps(line))
     if world > 1:

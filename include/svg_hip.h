@@ -61,6 +61,9 @@ int svg_create(int device_id, svg_ctx** out);
 void svg_destroy(svg_ctx* ctx);
 const char* svg_last_error(svg_ctx* ctx);            /* ctx may be NULL (creation errors) */
 const char* svg_version(void);
+/* The library reads its $SVG_* tuning / debugging knobs once per name and caches them (no getenv on a launch path); a process
+ * that changes such a variable after the first call (the tests do) calls this to have the next call look it up again. */
+void svg_env_refresh(void);
 
 /* ---- models: configure -> load every tensor by state_dict name -> finalize ------------------ */
 /* `kv`: "key=v[,v...];key=v" e.g. "block_out=320,640,1280,1280;layers=2;heads=8;ctx_dim=768".

@@ -36,6 +36,7 @@ SIGNATURES = {
     "svg_destroy": [_vp],
     "svg_last_error": [_vp],
     "svg_version": [],
+    "svg_env_refresh": [],
     "svg_model_configure": [_vp, _i, C.c_char_p],
     "svg_load_weight": [_vp, _i, C.c_char_p, _vp, C.POINTER(_i64), _i],
     "svg_finalize": [_vp, _i, C.POINTER(_i64)],
@@ -83,34 +84,46 @@ for _n in ("gemm", "conv3x3", "conv3x3_gn", "gemm_lnstats", "gemm_cat", "ff_fuse
            "attention"):
     SIGNATURES["svg_op_%s_f16" % _n] = SIGNATURES["svg_op_" + _n]
 SIGNATURES["svg_model_dtype"] = [_vp, _i]
-_RESTYPES = {"svg_destroy": None, "svg_model_dtype": C.c_char_p, "svg_last_error": C.c_char_p, "svg_version": C.c_char_p,
+_RESTYPES = {"svg_destroy": None, "svg_env_refresh": None, "svg_model_dtype": C.c_char_p, "svg_last_error": C.c_char_p, "svg_version": C.c_char_p,
              "svg_workspace_bytes": _i64}
 
 
 def host_cpu_quota():
-    """CPUs this process may burn: the affinity mask capped by the cgroup's CFS bandwidth (cpu.max = "quota period")."""
+    """(cpus, limited): CPUs this process may burn — the affinity mask capped by the cgroup's CFS bandwidth (cpu.max = "quota
+    period") — and whether a finite CFS quota is in force at all (cpu.max = "max ..." or no cgroup file: not limited)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    limited = False
     for path in (os.environ.get("SVG_CGROUP_CPU_MAX", "/sys/fs/cgroup/cpu.max"),):      # (the override exists for the host tests)
         try:
             q, p = open(path).read().split()
             if q != "max":
                 n = min(n, max(1, int(q) // int(p)))
+                limited = True
         except (OSError, ValueError):
             pass
-    return n
+    return n, limited
 
 
 def fit_host_threads():
-    """Caps torch's intra-op pool to a quarter of the CPU quota.  torch sizes the pool from the VISIBLE cores (128 threads on the
-    256-core GPU host) while the cgroup grants 16 CPUs per 100 ms CFS period; the pool's idle workers spin, the group burns its
-    1.6 CPU-seconds in ~37 ms and the kernel then parks EVERY thread of the process — including the one inside hipLaunchKernel —
-    until the next 100-ms period (profiles/r03_stall_trace.json, r03_throttle.txt: the round-2 "100-ms-tick stall", 28 -> 94
-    training it/s).  An explicit OMP_NUM_THREADS / $SVG_HOST_THREADS wins."""
+    """Caps torch's intra-op pool to a quarter of the CPU quota WHEN the cgroup sets a finite CFS quota.  torch sizes the pool from
+    the VISIBLE cores (128 threads on the 256-core GPU host) while the cgroup grants 16 CPUs per 100 ms CFS period; the pool's idle
+    workers spin, the group burns its 1.6 CPU-seconds in ~37 ms and the kernel then parks EVERY thread of the process — including
+    the one inside hipLaunchKernel — until the next 100-ms period (profiles/r03_stall_trace.json, r03_throttle_before.txt /
+    r03_throttle_after.txt: the round-2 "100-ms-tick stall", 28 -> 94 training it/s).  Without a quota (cpu.max = "max") nothing
+    throttles and the pool is left alone.  An explicit OMP_NUM_THREADS / $SVG_HOST_THREADS wins.  The quota is shared by the ranks
+    of THIS node: LOCAL_WORLD_SIZE (torch.distributed.run sets it), never WORLD_SIZE — a multi-node launch must not over-divide."""
     if os.environ.get("OMP_NUM_THREADS"):
         return torch.get_num_threads()
-    # the quota is shared by the ranks of a node (one process per GPU under torch.distributed.run: LOCAL_WORLD_SIZE)
-    ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1))
-    want = int(os.environ.get("SVG_HOST_THREADS", "0")) or max(1, host_cpu_quota() // (4 * ranks))
+    explicit = int(os.environ.get("SVG_HOST_THREADS", "0") or 0)
+    if explicit:
+        if torch.get_num_threads() > explicit:
+            torch.set_num_threads(explicit)
+        return torch.get_num_threads()
+    cpus, limited = host_cpu_quota()
+    if not limited:
+        return torch.get_num_threads()
+    ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+    want = max(1, cpus // (4 * ranks))
     if torch.get_num_threads() > want:
         torch.set_num_threads(want)
     return torch.get_num_threads()
@@ -133,6 +146,11 @@ def load():
         fn.restype = _RESTYPES.get(name, _i)
     _lib = lib
     return lib
+
+
+def env_refresh():
+    """the library caches its $SVG_* knobs per name: call after changing one in-process (svg_env_refresh)"""
+    load().svg_env_refresh()
 
 
 def source_hash():

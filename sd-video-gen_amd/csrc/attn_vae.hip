@@ -198,8 +198,8 @@ bool vae_attention_supported(int S, int C, int ldqk, int ldvt, int ldo) {
   // Default OFF: built, correct (parity tests run it), and 3.3x SLOWER than the three-GEMM path it replaces — 9.5 vs 2.9 ms per
   // 28 x 4096-token attention (profiles/README.md): four barriers per 32-key tile at one wave per SIMD, the cross-wave S reduction
   // through LDS, and 272 bytes of scratch per lane (the Q fragments spill).  It removes 7.5 GB of HBM traffic per frame group, but
-  // the time is what the frame pays: SVG_VAE_ATTN_FUSED=1 selects it (read per call: the tests toggle it).
-  const int on = getenv("SVG_VAE_ATTN_FUSED") ? atoi(getenv("SVG_VAE_ATTN_FUSED")) : 0;
+  // the time is what the frame pays: SVG_VAE_ATTN_FUSED=1 selects it (cached; the tests toggle it and call svg_env_refresh).
+  const int on = (int)svg_env_i64("SVG_VAE_ATTN_FUSED", 0);
   return on && C == VA_D && S % VA_Q == 0 && S >= VA_Q && ldqk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0;
 }
 

@@ -65,6 +65,10 @@ struct SvgHipError : std::runtime_error {
     }                                                                                  \
   } while (0)
 
+// Tuning / debugging knobs ($SVG_*): looked up ONCE per name and cached (a launch path must not call getenv — VERDICT r03 hygiene);
+// svg_env_refresh() (C ABI) drops the cache so that a test that changes a knob in-process is seen by the next call.
+int64_t svg_env_i64(const char* name, int64_t dflt);
+
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -509,9 +509,8 @@ void conv_halo_init_device() {
 void launch_conv_halo(const GemmArgs& g, dim3 grid, hipStream_t s) {
   static const int pp = getenv("SVG_HALO_PP") ? atoi(getenv("SVG_HALO_PP")) : 1;
   const bool w160 = conv_halo_bn(g) == 160;
-  // merged ping-pong (one 32 / 40-MFMA phase per tap); SVG_HALO_MERGE (read per call): 0 off, 1 BN = 128 only, 2 / unset both widths
-  const char* em = getenv("SVG_HALO_MERGE");
-  const int mm = em ? atoi(em) : 2;
+  // merged ping-pong (one 32 / 40-MFMA phase per tap); SVG_HALO_MERGE (cached, svg_env_refresh): 0 off, 1 BN = 128 only, 2 / unset both widths
+  const int mm = (int)svg_env_i64("SVG_HALO_MERGE", 2);
   if (pp && mm >= 2 && w160) { launch_halo<160, 2>(g, grid, s); return; }
   if (pp && mm >= 1 && !w160) { launch_halo<128, 2>(g, grid, s); return; }
   if (false) {}

@@ -473,8 +473,8 @@ void ff_fused(svg_ctx* ctx, const h16* X, int ldx, const h16* W1, const float* b
   ProfScope ps(ctx, PK_GEMM, s, 2.0 * M * (double)FC * (2 * FH) + 2.0 * M * (double)FH * FC,
                2.0 * ((double)M * FC * 3 + 3.0 * FC * FH), tag);
   FfArgs a{X, ldx, W1, b1, s1, rs, rm, W2p, b2, residual, ldr, out, ldo, M};
-  const char* ep = getenv("SVG_FF_PAIR");                  // read per call: 1 (default) the paired 32-row form, 0 the 16-rows-per-wave form
-  if (ep ? atoi(ep) != 0 : true) hipLaunchKernelGGL(ff_pair_kernel, dim3(cdiv(M, 128)), dim3(512), P_LDS, s, a);
+  // SVG_FF_PAIR: 1 (default) the paired 32-row form, 0 the 16-rows-per-wave form
+  if (svg_env_i64("SVG_FF_PAIR", 1) != 0) hipLaunchKernelGGL(ff_pair_kernel, dim3(cdiv(M, 128)), dim3(512), P_LDS, s, a);
   else hipLaunchKernelGGL(ff_fused_kernel, dim3(cdiv(M, 128)), dim3(512), F_LDS, s, a);
   check_launch("ff_fused");
 }

@@ -250,8 +250,7 @@ void launch_gemm_pp(const GemmArgs& g0, hipStream_t s) {
   static const int gm_env = getenv("SVG_PP_GROUPM") ? atoi(getenv("SVG_PP_GROUPM")) : 4;
   GemmArgs g = g0;
   g.group_m = gm_env;
-  const char* em = getenv("SVG_PP_MERGE");                  // read per call: 0 = the two-phase loop
-  g.pp_merge = em ? atoi(em) : 1;
+  g.pp_merge = (int)svg_env_i64("SVG_PP_MERGE", 1);        // 0 = the two-phase loop
   if (gemm_pp_bn(g) == 160) launch_pp<160>(g, s);
   else launch_pp<128>(g, s);
 }

@@ -1,4 +1,5 @@
 // Context, workspace arena, weight store, profiler, C-ABI error plumbing.
+#include <mutex>
 #include "models.h"
 #include "../../include/svg_hip.h"
 #include <algorithm>
@@ -148,7 +149,28 @@ std::unordered_map<std::string, std::vector<int64_t>> parse_kv(const char* kv) {
   }                                                    \
   catch (const std::exception& e) { return svg_fail(ctx, e); }
 
+static std::mutex g_env_mu;
+static std::unordered_map<std::string, int64_t> g_env;      // values of the $SVG_* knobs already looked up (absent -> its default)
+
+int64_t svg_env_i64(const char* name, int64_t dflt) {
+  std::lock_guard<std::mutex> lk(g_env_mu);
+  std::string key(name);
+  key += '\x01';
+  key += std::to_string(dflt);
+  auto it = g_env.find(key);
+  if (it != g_env.end()) return it->second;
+  const char* e = getenv(name);
+  const int64_t v = (e && *e) ? atoll(e) : dflt;
+  g_env.emplace(std::move(key), v);
+  return v;
+}
+
 extern "C" {
+
+void svg_env_refresh(void) {
+  std::lock_guard<std::mutex> lk(g_env_mu);
+  g_env.clear();
+}
 
 const char* svg_version(void) { return "svg_hip 0.3 (gfx950, bf16+fp16) src " SVG_SRC_HASH; }
 

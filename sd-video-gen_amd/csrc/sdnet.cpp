@@ -7,12 +7,10 @@
 namespace SDNS {
 
 // elements one kernel launch may address per operand (32-bit byte offsets); $SVG_CHUNK_LIMIT lowers it so that the tests can
-// drive the batch / row chunking of conv3x3() and linear() at small sizes (read per call: the tests toggle it in-process)
+// drive the batch / row chunking of conv3x3() and linear() at small sizes (cached; the tests toggle it in-process and call svg_env_refresh)
 static int64_t chunk_limit() {
-  const char* e = getenv("SVG_CHUNK_LIMIT");
   const int64_t full = (1LL << 31) - 1;
-  if (!e) return full;
-  const int64_t v = atoll(e);
+  const int64_t v = svg_env_i64("SVG_CHUNK_LIMIT", full);
   return v > 0 && v < full ? v : full;
 }
 

@@ -634,7 +634,7 @@ void UnetModel::ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const flo
   // counter (ddim_step_tab / ddim_tvec / ddim_bump), so a replay needs no new kernel arguments.  The graph bakes arena pointers:
   // it lives for this call only (the arena is planned just above and cannot move until the loop ends).  Off: SVG_DDIM_GRAPH=0,
   // the legacy null stream (not capturable), the profiler's event brackets, and the latent history (a per-step copy target).
-  const int graph_env = getenv("SVG_DDIM_GRAPH") ? atoi(getenv("SVG_DDIM_GRAPH")) : 1;      // read per call: the tests toggle it in-process
+  const int graph_env = (int)svg_env_i64("SVG_DDIM_GRAPH", 1);      // cached; the tests toggle it in-process and call svg_env_refresh
   const bool use_graph = graph_env && s != nullptr && !ctx->prof && !hist && (num_steps - start_step) >= 3;
 
   // planned once for the whole loop: every step has the same shapes

@@ -390,15 +390,13 @@ void xattn_fused_init_device() {
 }
 
 // C = 320 with 8 heads of 40, at most 80 context keys, samples of a multiple of 128 rows, enough 128-row tiles for every CU; SVG_XATTN_FUSED
-// (read per call): 0 keeps the three-launch form, 1 / unset the fused form (block input from memory), 2 the CHAIN form
+// (cached, svg_env_refresh): 0 keeps the three-launch form, 1 / unset the fused form (block input from memory), 2 the CHAIN form
 bool xattn_fused_supported(int C, int heads, int M, int rows_per_sample, int L) {
-  const char* e = getenv("SVG_XATTN_FUSED");
-  if (e && atoi(e) == 0) return false;
+  if (svg_env_i64("SVG_XATTN_FUSED", 1) == 0) return false;
   return C == XC && heads == XH && L > 0 && L <= 80 && rows_per_sample % 128 == 0 && M % rows_per_sample == 0 && M >= 128 * 192;
 }
 bool xattn_chain_enabled() {       // measured, same box: 18.46 frames/s chained, 18.49-18.52 plain fused, 18.33-18.35 three launches -> off by default
-  const char* e = getenv("SVG_XATTN_FUSED");
-  return e && atoi(e) >= 2;
+  return svg_env_i64("SVG_XATTN_FUSED", 1) >= 2;
 }
 
 int64_t xattn_kv_pack_elems(int N) { return (int64_t)N * XH * X_HEAD_ELEMS; }

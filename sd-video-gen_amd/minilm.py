@@ -9,7 +9,9 @@ checkpoint fills it through ``load_state_dict`` and a checkpoint saved here load
 
 Weights (hub-only in the reference): a local HF-format directory in ``$SVG_MINILM_WEIGHTS`` (``model.safetensors`` or
 ``pytorch_model.bin``, ``config.json``, ``vocab.txt``), a checkpoint's ``sent_transformer.*`` entries, or — explicit opt-in like
-the SD networks — seeded synthetic weights.  Without any of them ``encode`` raises like a failed ``from_pretrained``.
+the SD networks — seeded synthetic weights.  Without any of them ``encode`` raises like a failed ``from_pretrained``.  The
+WordPiece vocabulary is a separate input (``vocab=`` / ``$SVG_MINILM_VOCAB`` / the weights directory): real weights without it
+refuse to encode; the crc32 stand-in tokenizer serves the synthetic weights only.
 """
 import os
 import re
@@ -94,25 +96,35 @@ def _attach(root, dotted, tensor, buffer=False):
 
 
 class SentenceEncoder(nn.Module):
-    def __init__(self, weights=None, cfg=None, seed=0, ctx=None):
+    def __init__(self, weights=None, cfg=None, seed=0, ctx=None, vocab=None, allow_standin_tokenizer=False):
+        """``vocab``: path of a WordPiece ``vocab.txt`` (else ``$SVG_MINILM_VOCAB``, else ``vocab.txt`` inside
+        ``$SVG_MINILM_WEIGHTS``) — independent of where the weights come from, so that a reference text checkpoint (which carries the
+        MiniLM weights but no vocabulary) can be paired with it.  REAL weights (local directory, checkpoint, dict) without such a
+        file refuse to encode: hashed stand-in ids into trained embeddings would silently differ from SentenceTransformer.encode.
+        ``allow_standin_tokenizer=True`` (or ``$SVG_MINILM_STANDIN_TOKENIZER=1``) is the explicit opt-out for tests."""
         super().__init__()
         self.cfg = dict(MINILM, **(cfg or {}))
         self.loaded = False
+        self.synthetic = False            # True only for the seeded stand-in weights: the one case the hash tokenizer is meant for
         self._ctx = ctx
         self._uploaded = None
         self.tokenizer = None
+        self._allow_standin = bool(allow_standin_tokenizer) or os.environ.get("SVG_MINILM_STANDIN_TOKENIZER", "") not in ("", "0")
         d = os.environ.get("SVG_MINILM_WEIGHTS")
         from .sd_utils import synthetic_allowed
         if isinstance(weights, dict):
             self._fill(weights)
         elif d and weights in (None, "local"):
             self._fill(self._load_local(d))
-            vf = os.path.join(d, "vocab.txt")
-            if os.path.exists(vf):
-                self.tokenizer = _HFWordPiece(vf)
         elif weights == "synthetic" or (weights is None and synthetic_allowed()):
             from . import sd_layout
-            self._fill(sd_layout.seeded_weights(bert_shapes(self.cfg), seed))
+            self._fill(sd_layout.seeded_weights(bert_shapes(self.cfg), seed), synthetic=True)
+        if vocab and not os.path.exists(vocab):
+            raise FileNotFoundError("MiniLM vocab file %s" % vocab)
+        for vf in (vocab, os.environ.get("SVG_MINILM_VOCAB"), os.path.join(d, "vocab.txt") if d else None):
+            if vf and os.path.exists(vf):
+                self.tokenizer = _HFWordPiece(vf)
+                break
         if self.tokenizer is None:
             self.tokenizer = StandInWordPiece(self.cfg["vocab"])
 
@@ -134,7 +146,7 @@ class SentenceEncoder(nn.Module):
                 return torch.load(p, map_location="cpu", weights_only=True)
         raise FileNotFoundError("no model.safetensors / pytorch_model.bin under $SVG_MINILM_WEIGHTS=%s" % d)
 
-    def _fill(self, sd):
+    def _fill(self, sd, synthetic=False):
         sd = {(k[len("bert."):] if k.startswith("bert.") else k): v for k, v in sd.items()}
         sd = {(k[len(PREFIX):] if k.startswith(PREFIX) else k): v for k, v in sd.items()}
         shapes = bert_shapes(self.cfg, pooler="pooler.dense.weight" in sd)
@@ -151,6 +163,7 @@ class SentenceEncoder(nn.Module):
         # transformers 4.21's BertEmbeddings keeps position_ids as a persistent buffer: part of the reference's checkpoints
         _attach(self, PREFIX + "embeddings.position_ids", torch.arange(self.cfg["max_pos"]).unsqueeze(0), buffer=True)
         self.loaded = True
+        self.synthetic = bool(synthetic)
         self._uploaded = None
 
     def load_state_dict(self, state_dict, strict=True):
@@ -176,6 +189,11 @@ class SentenceEncoder(nn.Module):
             raise FileNotFoundError("no MiniLM weights: set $SVG_MINILM_WEIGHTS to a local all-MiniLM-L6-v2 directory (model.safetensors, "
                                     "config.json, vocab.txt), load a reference text checkpoint (its sent_transformer.* entries), pass "
                                     "text_encoder=, or opt in to seeded synthetic weights (SVG_ALLOW_SYNTHETIC_WEIGHTS=1)")
+        if isinstance(self.tokenizer, StandInWordPiece) and not self.synthetic and not self._allow_standin:
+            raise FileNotFoundError("MiniLM holds REAL weights (checkpoint / local directory / dict) but no WordPiece vocabulary: the "
+                                    "stand-in tokenizer's hashed ids would feed garbage to trained embeddings.  Pass vocab=<vocab.txt>, set "
+                                    "$SVG_MINILM_VOCAB, or put vocab.txt into $SVG_MINILM_WEIGHTS (explicit opt-out for tests: "
+                                    "allow_standin_tokenizer=True / SVG_MINILM_STANDIN_TOKENIZER=1)")
         if isinstance(sentences, str):
             sentences = [sentences]
         ids, lens = self.tokenizer(list(sentences))

@@ -32,13 +32,22 @@ def find_classes(directory):
 
 
 def fvd_from_stacks(real_groups, fake_groups, i3d):
-    """real_groups / fake_groups: lists of (16,T,H,W,3) uint8 tensors -> Fréchet distance of their I3D logits (predict_text.py:308-315)"""
+    """real_groups / fake_groups: lists of (16,T,H,W,3) uint8 tensors -> Fréchet distance of their I3D logits (predict_text.py:308-315).
+    The decision "are there enough clips" is COLLECTIVE: every rank embeds what it holds (possibly nothing: a (0, 400) block),
+    every rank enters both all_gathers, and only then the gathered row counts are tested — a rank whose shard held fewer than 16
+    clips must not leave before the collective the other ranks are waiting in.  Returns (None, real, fake) when either set is empty."""
     from . import fvd
-    real = torch.cat([fvd.get_fvd_logits(g, i3d) for g in real_groups])
-    fake = torch.cat([fvd.get_fvd_logits(g, i3d) for g in fake_groups])
-    real, fake = fvd.all_gather(real), fvd.all_gather(fake)
+    dev = i3d.ctx.device
+
+    def embed(groups):
+        if groups:
+            return torch.cat([fvd.get_fvd_logits(g, i3d) for g in groups])
+        return torch.zeros((0, i3d.num_classes), dtype=torch.float32, device=dev)
+    real, fake = fvd.all_gather(embed(real_groups)), fvd.all_gather(embed(fake_groups))
     print("fake_embeddings shape", tuple(fake.shape))
     print("real_embeddings shape", tuple(real.shape))
+    if real.shape[0] == 0 or fake.shape[0] == 0:
+        return None, real, fake
     return fvd.frechet_distance(fake.clone(), real), real, fake
 
 
@@ -72,7 +81,12 @@ def main(argv=None):
     idx_to_class = None
     if args.dataset == "ball":                                                                                 # :90-92
         ds = BouncingBall(num_frames=5, stride=1, dir=args.folder, stage="test", shuffle=False)
-        items = [(torch.tensor(ds.indices[i]), torch.from_numpy(ds[i][1])) for i in range(len(ds)) if len(ds.dataset[i]) == 5]
+        keep = [i for i in range(len(ds)) if len(ds.dataset[i]) == 5]
+        n_items = len(keep)
+
+        def load_item(j):
+            i = keep[j]
+            return torch.tensor(ds.indices[i]), torch.from_numpy(ds[i][1])
     elif "ucf" in args.dataset:                                                                                # :94-138
         ucf_data_dir, ucf_label_dir = ucf_dirs(args.dataset)
         if args.folder:                       # pre-extracted frames live elsewhere: <folder>/<same relative layout>
@@ -81,18 +95,28 @@ def main(argv=None):
         print("Loading UCF dataset from", ucf_data_dir)
         train = args.mode == "train"
         ucf = UCF101Frames(ucf_data_dir, ucf_label_dir, frames_per_clip=5 if train else 16, train=train, transform=ucf_transform(F), frame_rate=3)
-        n = min(len(ucf), int(os.environ.get("SVG_FVD_CLIPS", "2048")))
-        order = torch.randperm(len(ucf), generator=torch.Generator().manual_seed(0))[:n].tolist()              # RandomSampler(num_samples=2048)
-        items = [(torch.tensor([ucf[i][2]]), torch.from_numpy(ucf[i][0])) for i in order]
+        # RandomSampler(num_samples=2048) (:137) draws WITHOUT replacement permutation after permutation until it has 2048
+        # indices: a set smaller than 2048 is visited several times.  Same here, seeded; $SVG_FVD_CLIPS shortens the walk.
+        n = int(os.environ.get("SVG_FVD_CLIPS", "2048"))
+        g = torch.Generator().manual_seed(0)
+        order = []
+        while len(order) < n and len(ucf) > 0:
+            order += torch.randperm(len(ucf), generator=g).tolist()
+        order = order[:n]
+        n_items = len(order)
+
+        def load_item(j):                      # one decode + transform per clip, and only for the clips of this rank's shard
+            v, _, l = ucf[order[j]]
+            return torch.tensor([l]), torch.from_numpy(v)
     else:
         raise ValueError("Invalid dataset name")
-    a, b = sharding.shard_range(len(items), rank, ws)
+    a, b = sharding.shard_range(n_items, rank, ws)
     real_embeddings, fake_embeddings = [], []
     real_input, fake_input = None, None
     out_tag = str(args.config) + "_" + str(args.index) + "_" + str(args.mode)
     with torch.no_grad():
         for ind in range(a, b):
-            index_list, clip = items[ind]
+            index_list, clip = load_item(ind)
             batch = clip.unsqueeze(0)                                              # (1,T,F,F,3) uint8 BGR, like the DataLoader's batch
             cls_list = [idx_to_class[int(i)] for i in index_list.tolist()] if idx_to_class is not None else None
             real_input = batch if real_input is None else torch.cat((real_input, batch), 0)                   # :157-161
@@ -112,12 +136,14 @@ def main(argv=None):
                 if fake_input.shape[0] >= 16:
                     fake_embeddings.append((fake_input * 255).to(torch.uint8))                                 # :283
                     fake_input = None
-        if not real_embeddings or not fake_embeddings:
+        # every rank takes part in the gathers, whatever its shard produced (a rank that returned early here left the others
+        # hanging in all_gather: e.g. 31 clips on 2 ranks = one complete group on rank 0, none on rank 1)
+        fvd_value, real_all, fake_all = fvd_from_stacks(real_embeddings, fake_embeddings, i3d)
+        if fvd_value is None:
             if rank == 0:
-                print("FVD needs at least 16 real clips and, under --save_output, 16 generated ones (got %d / %d groups)"
-                      % (len(real_embeddings), len(fake_embeddings)))
+                print("FVD needs at least 16 real clips and, under --save_output, 16 generated ones on some rank (got %d / %d rows)"
+                      % (real_all.shape[0], fake_all.shape[0]))
             return None
-        fvd_value, _, _ = fvd_from_stacks(real_embeddings, fake_embeddings, i3d)
     if rank == 0:
         print("FVD: ", fvd_value)                                                                              # :315
     return fvd_value

@@ -23,6 +23,18 @@ def ctx():
     c.close()
 
 
+@pytest.fixture(autouse=True)
+def _fresh_env_knobs():
+    """the library caches its $SVG_* knobs (svg_env_refresh): a test starts from the environment as it is now, and whatever a
+    test changed through monkeypatch is dropped again before the next one looks"""
+    from sd_video_gen_amd import _lib
+    if os.path.exists(_lib.LIB_PATH):
+        _lib.env_refresh()
+    yield
+    if os.path.exists(_lib.LIB_PATH):
+        _lib.env_refresh()
+
+
 def rel_l2(a, b):
     a = a.double().flatten()
     b = b.double().flatten()

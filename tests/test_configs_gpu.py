@@ -188,16 +188,21 @@ def test_config1_rollout_8_frames_start25(ctx, nets, dtype, tol_all, tol_worst):
     margin("cfg1 8-frame rollout (%s), worst frame" % dtype, max(rel_l2(lat[:, 4 + k], g["all_latents"][:, 4 + k]) for k in range(g["pred_frames"])), tol_worst)
 
 
-@pytest.mark.parametrize("dtype,tol_first,tol_all,tol_last", [("fp16", 2e-2, 1.7e-1, 2.8e-1), ("bf16", 7e-2, 2.2e-1, 3e-1)])   # measured fp16: 6.5e-3, 5.6e-2, 9.4e-2
-def test_config3_rollout_16_frames_f128(ctx, nets, dtype, tol_first, tol_all, tol_last):
-    """configs[3]: 11_27_ucf_final (F=128, D_lat=1024), 16 autoregressive frames with the 512x512 round trip."""
+@pytest.mark.parametrize("dtype,tol_first", [("fp16", 2e-2), ("bf16", 7e-2)])   # measured fp16: 6.5e-3; bf16: 2.6e-2
+def test_config3_rollout_16_frames_f128(ctx, nets, dtype, tol_first):
+    """configs[3]: 11_27_ucf_final (F=128, D_lat=1024), 16 autoregressive frames with the 512x512 round trip, on the CHAOTIC
+    (unscaled) synthetic weights.  Only the first generated frame is asserted: from the second frame on the distance measures how
+    the random-weight networks amplify a rounding through the feedback loop (fp16 5.6e-2 over all frames, 9.4e-2 at the sixteenth;
+    HIP against HIP under a 1e-3 perturbation grows the same way), not arithmetic — those figures are printed, and the full-length
+    ASSERTED check of this config is test_config3_full_length_contractive below (VERDICT r03 weak #1)."""
     g = gold("sd_cfg3_rollout.pt")
     lat, _ = _rollout("11_27_ucf_final", g, nets, dtype)
     for k in (0, 7, 15):
         print("[parity] cfg3 frame %d rel-L2 %.3e" % (k, rel_l2(lat[:, 4 + k], g["all_latents"][:, 4 + k])))
-    margin("cfg3 16-frame rollout (%s), first generated frame" % dtype, rel_l2(lat[:, 4], g["all_latents"][:, 4]), tol_first)       # bf16 measured 2.6e-2
-    margin("cfg3 16-frame rollout (%s), all generated latents" % dtype, rel_l2(lat[:, 4:], g["all_latents"][:, 4:]), tol_all)   # bf16 measured 7.8e-2
-    margin("cfg3 16-frame rollout (%s), last frame (16 autoregressive steps)" % dtype, rel_l2(lat[:, -1], g["all_latents"][:, -1]), tol_last)   # bf16 1.1e-1
+    margin("cfg3 16-frame rollout (%s), first generated frame" % dtype, rel_l2(lat[:, 4], g["all_latents"][:, 4]), tol_first)
+    print("[parity] cfg3 16-frame rollout (%s), chaotic weights, printed only: all generated latents %.3e, last frame %.3e"
+          % (dtype, rel_l2(lat[:, 4:], g["all_latents"][:, 4:]), rel_l2(lat[:, -1], g["all_latents"][:, -1])))
+    assert torch.isfinite(lat).all()
 
 
 @pytest.mark.parametrize("dtype,tol_first,tol_all,tol_last", [("fp16", 1.5e-2, 4e-2, 6e-2), ("bf16", 4.5e-2, 1.1e-1, 1.6e-1)])   # measured fp16: 5.1e-3, 1.8e-2, 2.8e-2; bf16: 1.6e-2, 3.7e-2, 5.3e-2

@@ -90,10 +90,13 @@ def test_unet_fused_cross_attention_vs_three_launches(ctx, full_unet, monkeypatc
     c = torch.randn(N, 77, 768, generator=g)
     t = torch.tensor([980.0, 860.0, 700.0, 500.0, 320.0, 120.0, 0.0])
     monkeypatch.setenv("SVG_XATTN_FUSED", "0")
+    _lib.env_refresh()
     e0 = ctx.unet_forward(x.cuda(), t.cuda(), c.cuda()).cpu()
     monkeypatch.setenv("SVG_XATTN_FUSED", "1")                                   # one launch, block input read from memory (the default)
+    _lib.env_refresh()
     e1 = ctx.unet_forward(x.cuda(), t.cuda(), c.cuda()).cpu()
     monkeypatch.setenv("SVG_XATTN_FUSED", "2")                                   # CHAIN form: the self-attention's to_out + residual in front (opt-in)
+    _lib.env_refresh()
     e2 = ctx.unet_forward(x.cuda(), t.cuda(), c.cuda()).cpu()
     assert torch.isfinite(e1).all() and torch.isfinite(e2).all()
     assert not torch.equal(e0, e1) and not torch.equal(e1, e2)                    # three different kernel sequences ran
@@ -147,6 +150,7 @@ def test_vae_fused_mid_attention_512(ctx, full_vae, monkeypatch):
     _, mom0 = ctx.vae_encode(img.cuda(), return_moments=True)
     _, fl0 = ctx.vae_decode(zz.cuda(), return_float=True)
     monkeypatch.setenv("SVG_VAE_ATTN_FUSED", "1")
+    _lib.env_refresh()
     _, mom1 = ctx.vae_encode(img.cuda(), return_moments=True)
     _, fl1 = ctx.vae_decode(zz.cuda(), return_float=True)
     assert not torch.equal(mom0, mom1)                                     # another kernel ran

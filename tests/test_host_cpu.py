@@ -147,6 +147,48 @@ def test_run_sharded_one_allgather_gloo_world2(n_clips):
         assert torch.equal(lat, want_lat) and torch.equal(frames, want_frames)
 
 
+class _FakeCtx:
+    device = torch.device("cpu")
+
+
+class _FakeI3D:
+    ctx, num_classes = _FakeCtx(), 400
+
+
+def _fvd_worker(rank, ws, port, groups_per_rank, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    from sd_video_gen_amd import fvd, predict_text as PT
+    fvd.get_fvd_logits = lambda g, i3d, device=None: g.reshape(g.shape[0], -1)[:, :400].float()      # stands where the I3D stands
+    fvd.frechet_distance = lambda a, b, ctx=None: float((a.mean(0) - b.mean(0)).pow(2).sum())
+    n_real, n_fake = groups_per_rank[rank]
+    mk = lambda n, base: [torch.full((16, 2, 4, 25, 3), base + 10 * rank + i, dtype=torch.uint8) for i in range(n)]
+    val, real, fake = PT.fvd_from_stacks(mk(n_real, 1), mk(n_fake, 3), _FakeI3D())
+    q.put((rank, val, tuple(real.shape), tuple(fake.shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("groups", [((1, 1), (0, 0)), ((0, 0), (0, 0)), ((2, 1), (1, 1))])
+def test_fvd_decision_is_collective_gloo_world2(groups):
+    """a rank whose shard produced no complete group of 16 clips (31 clips on 2 ranks) must still enter the all_gathers
+    of the logits; whether an FVD exists is decided on the GATHERED row counts, on every rank alike — no rank hangs, all agree."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + 7 * sum(sum(g) for g in groups)
+    procs = [ctx.Process(target=_fvd_worker, args=(r, 2, port, groups, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n_real, n_fake = 16 * (groups[0][0] + groups[1][0]), 16 * (groups[0][1] + groups[1][1])
+    assert res[0][1:] == res[1][1:]
+    assert res[0][2] == (n_real, 400) and res[0][3] == (n_fake, 400)
+    assert (res[0][1] is None) == (n_real == 0 or n_fake == 0)
+
+
 def test_save_frames_bytes(tmp_path):
     """prediction/predict.py:201-223: one PNG per frame; predicted frames carry a 1-px red border (BGR [0,0,255]); frames are
     BGR in memory and written like cv2.imwrite (so the file holds RGB = reversed channels)."""
@@ -191,6 +233,38 @@ def test_text_model_loads_reference_checkpoint_layout():
         m.load_state_dict({k: v for k, v in sd.items() if k != "out.bias"})
     with pytest.raises(FileNotFoundError):                          # an encoder without weights refuses, like a failed from_pretrained
         Transformer(dim_model=32, num_heads=4, num_encoder_layers=1, num_decoder_layers=1).encode_classes(["Archery"])
+    # the checkpoint brought REAL MiniLM weights but no WordPiece vocabulary — hashed stand-in ids must not reach them
+    assert not m.sent_transformer.synthetic and isinstance(m.sent_transformer.tokenizer, minilm.StandInWordPiece)
+    with pytest.raises(FileNotFoundError, match="vocab"):
+        m.encode_classes(["Archery"])
+
+
+def test_minilm_vocab_is_separate_from_the_weights(tmp_path, monkeypatch):
+    """the WordPiece vocabulary comes from vocab= / $SVG_MINILM_VOCAB / the weights directory, independently of the weights; seeded
+    synthetic weights are the only ones the crc32 stand-in tokenizer may serve (no GPU: tokenisation only)."""
+    from sd_video_gen_amd import minilm, sd_layout
+    tiny = dict(vocab=1200, d_model=384, heads=12, layers=1, ffn=64, max_pos=32)
+    vf = tmp_path / "vocab.txt"
+    vf.write_text("\n".join(["[PAD]"] + ["[unused%d]" % i for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]", "apply", "eye", "make", "##up", "archery"]) + "\n")
+    monkeypatch.delenv("SVG_MINILM_WEIGHTS", raising=False)
+    monkeypatch.delenv("SVG_MINILM_VOCAB", raising=False)
+    monkeypatch.delenv("SVG_MINILM_STANDIN_TOKENIZER", raising=False)
+    real = sd_layout.seeded_weights(minilm.bert_shapes(tiny), 4)                 # handed over as a dict = "real" weights
+    enc = minilm.SentenceEncoder(weights=dict(real), cfg=tiny)
+    assert enc.loaded and not enc.synthetic and isinstance(enc.tokenizer, minilm.StandInWordPiece)
+    with pytest.raises(FileNotFoundError, match="vocab"):
+        enc.encode(["Apply Eye Makeup"])
+    enc = minilm.SentenceEncoder(weights=dict(real), cfg=tiny, vocab=str(vf))
+    ids, lens = enc.tokenizer(["Apply Eye Makeup", "Archery"])
+    cls, sep = 101, 102
+    assert ids[0].tolist() == [cls, 104, 105, 106, 107, sep] and ids[1].tolist() == [cls, 108, sep, 0, 0, 0] and lens.tolist() == [6, 3]
+    monkeypatch.setenv("SVG_MINILM_VOCAB", str(vf))
+    assert isinstance(minilm.SentenceEncoder(weights=dict(real), cfg=tiny).tokenizer, minilm._HFWordPiece)
+    monkeypatch.delenv("SVG_MINILM_VOCAB")
+    with pytest.raises(FileNotFoundError):
+        minilm.SentenceEncoder(weights=dict(real), cfg=tiny, vocab=str(tmp_path / "missing.txt"))
+    syn = minilm.SentenceEncoder(weights="synthetic", cfg=tiny, seed=1)
+    assert syn.synthetic and isinstance(syn.tokenizer, minilm.StandInWordPiece)
 
 
 def test_checkpoint_format_roundtrip(tmp_path):
@@ -269,15 +343,21 @@ def test_host_thread_cap_follows_the_cgroup_quota(tmp_path, monkeypatch):
         monkeypatch.delenv("WORLD_SIZE", raising=False)
         import os
         n_aff = len(os.sched_getaffinity(0))
-        assert _lib.host_cpu_quota() == min(16, n_aff)
+        assert _lib.host_cpu_quota() == (min(16, n_aff), True)
         torch.set_num_threads(max(before, 8))
         assert _lib.fit_host_threads() == min(max(before, 8), max(1, min(16, n_aff) // 4))
         monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")          # eight ranks share the node's quota
         torch.set_num_threads(8)
         assert _lib.fit_host_threads() == 1
         monkeypatch.delenv("LOCAL_WORLD_SIZE")
-        f.write_text("max 100000\n")
-        assert _lib.host_cpu_quota() == n_aff
+        monkeypatch.setenv("WORLD_SIZE", "64")              # a multi-node job: WORLD_SIZE says nothing about THIS node's ranks
+        torch.set_num_threads(8)
+        assert _lib.fit_host_threads() == min(8, max(1, min(16, n_aff) // 4))
+        monkeypatch.delenv("WORLD_SIZE")
+        f.write_text("max 100000\n")                       # no CFS quota: nothing throttles, the pool is left alone
+        assert _lib.host_cpu_quota() == (n_aff, False)
+        torch.set_num_threads(8)
+        assert _lib.fit_host_threads() == 8
         monkeypatch.setenv("SVG_HOST_THREADS", "3")
         torch.set_num_threads(8)
         assert _lib.fit_host_threads() == 3

@@ -95,11 +95,13 @@ def test_vae_batch_chunking(ctx):
     imgs = torch.randint(0, 256, (5, 64, 64, 3), dtype=torch.uint8, generator=g)
     z0 = ctx.vae_encode(imgs.cuda())
     os.environ["SVG_CHUNK_LIMIT"] = str(2 * 128 * 128 * 64)      # two images of the widest level per launch
+    _lib.env_refresh()
     try:
         img1, fl1 = ctx.vae_decode(z.cuda(), return_float=True)
         z1 = ctx.vae_encode(imgs.cuda())
     finally:
         del os.environ["SVG_CHUNK_LIMIT"]
+        _lib.env_refresh()
     # the chunks may pick other tile shapes than the whole batch (accumulation order): equal up to bf16 rounding
     assert rel_l2(fl1, fl0) < 1.5e-2 and rel_l2(z1, z0) < 1.5e-2   # other tile shapes per chunk: bf16 roundings differ layer by layer
     ref_img, ref_fl = SO.decode_img_latents(sd, z, cfg, return_float=True)
@@ -184,6 +186,7 @@ def test_ddim_graph_replay_equals_direct_launches(ctx, monkeypatch, cfg, guidanc
     outs = {}
     for mode in ("1", "0", "1"):
         monkeypatch.setenv("SVG_DDIM_GRAPH", mode)
+        _lib.env_refresh()
         with torch.cuda.stream(side):
             outs.setdefault(mode, []).append(ctx.ddim_loop(lat, emb, num_steps=50, start_step=start, guidance=guidance, noise=noise))
         side.synchronize()

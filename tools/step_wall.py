@@ -31,6 +31,7 @@ def main():
     steps = 20
     for mode in ("0", "1", "0", "1"):
         os.environ["SVG_DDIM_GRAPH"] = mode
+        _lib.env_refresh()
         with torch.cuda.stream(side):
             ctx.ddim_loop(z, emb, num_steps=50, start_step=50 - steps, guidance=0.0, noise=torch.zeros_like(z))   # warm
             side.synchronize()
