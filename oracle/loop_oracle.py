@@ -49,9 +49,13 @@ def sample_clip(xf_sd, num_heads, vae_sd, clip_u8, pred_frames, noise, denoise=F
             den = hist[-1:]
             if trace is not None:
                 trace.append({"pred": pred.clone(), "lat0": lat.clone(), "hist": hist.clone()})
+                if not latent_denoise:
+                    trace[-1]["img"] = img.clone()
             img2 = SO.decode_img_latents(vae_sd, den, vae_cfg)
             small = SO.resize_nearest_u8(img2, F, F)
             pred = SO.encode_img(vae_sd, small, noise["eF"][k][None], vae_cfg).flatten()
+            if trace is not None:
+                trace[-1].update(small=small.clone(), out=pred.clone())
         preds = torch.cat((preds, pred.reshape(1, 1, D)), dim=1)
         all_latents = torch.cat([inputs[:, :-1], preds], dim=1)
         X = all_latents[:, -5:]

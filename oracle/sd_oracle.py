@@ -34,6 +34,56 @@ SCALE = 0.18215
 
 
 # =================================================================================================
+# precision: fp32 (default: what a CPU host executes) or the CUDA-autocast policy
+# =================================================================================================
+# utils/sd_utils.py:246 wraps the UNet loop in torch.autocast('cuda'): on the reference's GPU the UNet does NOT run in fp32.
+# `with autocast_fp16():` makes this restatement apply torch 1.11's CUDA autocast policy op by op (the VAE call sites at
+# sd_utils.py:140,162 sit outside the autocast block and stay fp32):
+#   * conv2d / linear / matmul (bmm, einsum): every floating input is cast to fp16, the result IS an fp16 tensor (the products are
+#     accumulated in fp32 by the tensor cores and rounded once: computed here in fp32 from the fp16-rounded operands, then rounded);
+#   * group_norm / layer_norm / softmax: inputs cast to fp32, result fp32 (autocast's fp32 list);
+#   * everything else (silu, gelu, +, *, cat, chunk, nearest interpolate) runs in the dtype of its inputs with the usual type
+#     promotion: fp16 in -> fp16 out (one rounding per op), fp16 (+) fp32 -> fp32.
+# torch.autocast('cpu') is NOT that policy (its fp32 list lacks the norms and softmax), hence the explicit form.
+_AC = [None]
+
+
+class autocast_fp16:
+    def __init__(self, dtype=torch.float16):
+        self.dtype = dtype
+
+    def __enter__(self):
+        self.prev = _AC[0]
+        _AC[0] = self.dtype
+        return self
+
+    def __exit__(self, *a):
+        _AC[0] = self.prev
+        return False
+
+
+def _lo(fn, *ts, **kw):
+    """an op of autocast's lower-precision list"""
+    if _AC[0] is None:
+        return fn(*ts, **kw)
+    lo = [t.to(_AC[0]).float() if isinstance(t, torch.Tensor) and t.is_floating_point() else t for t in ts]
+    return fn(*lo, **kw).to(_AC[0])
+
+
+def _f32(t):
+    """input of an op of autocast's fp32 list"""
+    return t.float() if _AC[0] is not None else t
+
+
+def _linear(x, w, b=None):
+    return _lo(F.linear, x, w, b)
+
+
+def _matmul(a, b):
+    return _lo(torch.matmul, a, b)
+
+
+# =================================================================================================
 # parameter tables (name -> shape) in diffusers' state_dict naming
 # =================================================================================================
 def _res_shapes(p, cin, cout, temb=None):
@@ -183,18 +233,18 @@ def seeded_weights(shapes, seed, gain=0.6, device="cpu"):
 # blocks
 # =================================================================================================
 def _gn(sd, p, x, groups, eps):
-    return F.group_norm(x, groups, sd[p + ".weight"], sd[p + ".bias"], eps)
+    return F.group_norm(_f32(x), groups, sd[p + ".weight"], sd[p + ".bias"], eps)
 
 
 def _conv(sd, p, x, stride=1, padding=1):
-    return F.conv2d(x, sd[p + ".weight"], sd[p + ".bias"], stride=stride, padding=padding)
+    return _lo(F.conv2d, x, sd[p + ".weight"], sd[p + ".bias"], stride=stride, padding=padding)
 
 
 def resnet(sd, p, x, groups, eps, temb=None):
     """ResnetBlock2D (output_scale_factor 1)."""
     h = _conv(sd, p + ".conv1", F.silu(_gn(sd, p + ".norm1", x, groups, eps)))
     if temb is not None:
-        h = h + F.linear(F.silu(temb), sd[p + ".time_emb_proj.weight"], sd[p + ".time_emb_proj.bias"])[:, :, None, None]
+        h = h + _linear(F.silu(temb), sd[p + ".time_emb_proj.weight"], sd[p + ".time_emb_proj.bias"])[:, :, None, None]
     h = _conv(sd, p + ".conv2", F.silu(_gn(sd, p + ".norm2", h, groups, eps)))
     if (p + ".conv_shortcut.weight") in sd:
         x = _conv(sd, p + ".conv_shortcut", x, padding=0)
@@ -205,14 +255,14 @@ def _cross_attention(sd, p, x, context, heads):
     """CrossAttention: to_q/k/v without bias, softmax(q k^T * d^-1/2) v, to_out.0 with bias."""
     B, S, C = x.shape
     d = C // heads
-    q = F.linear(x, sd[p + ".to_q.weight"])
-    k = F.linear(context, sd[p + ".to_k.weight"])
-    v = F.linear(context, sd[p + ".to_v.weight"])
+    q = _linear(x, sd[p + ".to_q.weight"])
+    k = _linear(context, sd[p + ".to_k.weight"])
+    v = _linear(context, sd[p + ".to_v.weight"])
     sp = lambda t: t.reshape(B, -1, heads, d).permute(0, 2, 1, 3)
     q, k, v = sp(q), sp(k), sp(v)
-    a = torch.softmax(q @ k.transpose(-1, -2) * (d ** -0.5), dim=-1)
-    o = (a @ v).permute(0, 2, 1, 3).reshape(B, S, C)
-    return F.linear(o, sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"])
+    a = torch.softmax(_f32(_matmul(q, k.transpose(-1, -2)) * (d ** -0.5)), dim=-1)
+    o = _matmul(a, v).permute(0, 2, 1, 3).reshape(B, S, C)
+    return _linear(o, sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"])
 
 
 def spatial_transformer(sd, p, x, context, heads, groups):
@@ -222,13 +272,13 @@ def spatial_transformer(sd, p, x, context, heads, groups):
     h = _conv(sd, p + ".proj_in", h, padding=0)
     h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
     t = p + ".transformer_blocks.0"
-    ln = lambda n, y: F.layer_norm(y, (C,), sd[t + "." + n + ".weight"], sd[t + "." + n + ".bias"], 1e-5)
+    ln = lambda n, y: F.layer_norm(_f32(y), (C,), sd[t + "." + n + ".weight"], sd[t + "." + n + ".bias"], 1e-5)
     n1 = ln("norm1", h)
     h = h + _cross_attention(sd, t + ".attn1", n1, n1, heads)
     h = h + _cross_attention(sd, t + ".attn2", ln("norm2", h), context, heads)
-    ff = F.linear(ln("norm3", h), sd[t + ".ff.net.0.proj.weight"], sd[t + ".ff.net.0.proj.bias"])
+    ff = _linear(ln("norm3", h), sd[t + ".ff.net.0.proj.weight"], sd[t + ".ff.net.0.proj.bias"])
     hs, gate = ff.chunk(2, dim=-1)                                   # GEGLU
-    h = h + F.linear(hs * F.gelu(gate), sd[t + ".ff.net.2.weight"], sd[t + ".ff.net.2.bias"])
+    h = h + _linear(hs * F.gelu(gate), sd[t + ".ff.net.2.weight"], sd[t + ".ff.net.2.bias"])
     h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
     return _conv(sd, p + ".proj_out", h, padding=0) + res
 
@@ -251,8 +301,8 @@ def unet_forward(sd, x, t, context, cfg=SD_UNET):
     if t.numel() == 1:
         t = t.repeat(x.shape[0])
     temb = timestep_embedding(t, bo[0])
-    temb = F.linear(temb, sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"])
-    temb = F.linear(F.silu(temb), sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"])
+    temb = _linear(temb, sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"])
+    temb = _linear(F.silu(temb), sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"])
     h = _conv(sd, "conv_in", x)
     skips = [h]
     for i in range(len(bo)):
@@ -278,7 +328,7 @@ def unet_forward(sd, x, t, context, cfg=SD_UNET):
             h = F.interpolate(h, scale_factor=2.0, mode="nearest")
             h = _conv(sd, "up_blocks.%d.upsamplers.0.conv" % i, h)
     h = F.silu(_gn(sd, "conv_norm_out", h, groups, 1e-5))
-    return _conv(sd, "conv_out", h)
+    return _conv(sd, "conv_out", h)            # fp16 under autocast_fp16 (the caller's scheduler arithmetic promotes it to fp32)
 
 
 # =================================================================================================
@@ -387,7 +437,9 @@ class DDIM:
 
 def gen_i2i_latents(sd, text_embeddings, latents, num_inference_steps=50, guidance_scale=7.5, start_step=10,
                     noise=None, cfg=SD_UNET, return_all_latents=False, unet=None):
-    """utils/sd_utils.py:222-267 as executed on a CPU host (autocast('cuda') is a no-op there: fp32).
+    """utils/sd_utils.py:222-267 as executed on a CPU host (autocast('cuda') is a no-op there: fp32) — or, inside
+    `with autocast_fp16():`, as executed on the reference's GPU: the UNet call under the CUDA autocast policy (its fp16 result and
+    the fp16 guidance combine of :256-257 are promoted to fp32 by the scheduler's arithmetic on the fp32 latents).
     `noise` = the randn_like draw of :242.  `unet(x, t, ctx)` may replace the oracle UNet (tests)."""
     unet = unet or (lambda x, t, c: unet_forward(sd, x, t, c, cfg))
     sch = DDIM(num_inference_steps)

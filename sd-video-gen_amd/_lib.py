@@ -68,6 +68,7 @@ SIGNATURES = {
     "svg_op_ff_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "svg_op_xattn_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "svg_op_dropout_mask": [_vp, C.c_uint64, _i, _f, _vp, _i64, _vp],
+    "svg_op_conv3x3_mx": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "svg_op_quant_mx": [_vp, _vp, _vp, _vp, _i64, _i, _vp],
     "svg_op_gemm_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "svg_op_groupnorm": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
@@ -80,7 +81,7 @@ SIGNATURES = {
     "svg_workspace_bytes": [_vp],
 }
 # fp16-storage twins of the 16-bit operator hooks (svg_op_<name>_f16: same arguments)
-for _n in ("gemm", "conv3x3", "conv3x3_gn", "gemm_lnstats", "gemm_cat", "ff_fused", "xattn_fused", "quant_mx", "gemm_fp8", "groupnorm", "layernorm",
+for _n in ("gemm", "conv3x3", "conv3x3_gn", "conv3x3_mx", "gemm_lnstats", "gemm_cat", "ff_fused", "xattn_fused", "quant_mx", "gemm_fp8", "groupnorm", "layernorm",
            "attention"):
     SIGNATURES["svg_op_%s_f16" % _n] = SIGNATURES["svg_op_" + _n]
 SIGNATURES["svg_model_dtype"] = [_vp, _i]

@@ -456,7 +456,7 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
         if (n < g.N) *(f32x4*)(g.slabs + ((int64_t)ks * g.M + mr + i * OW) * g.N + n) = acc[i][j];
       }
   } else {
-    epi_tile<MT, NT>(g, 0, mr, OW, nc, acc, smem, 4, wm, wn, tile_m, n0);
+    epi_tile<MT, NT, false, true>(g, 0, mr, OW, nc, acc, smem, 4, wm, wn, tile_m, n0);      // 16-bit output, no GEGLU: the wide form
   }
 }
 

@@ -37,7 +37,8 @@ __device__ __forceinline__ void epi_store_geglu(const GemmArgs& g, int z, int m,
   *(h16x4*)((h16*)g.C + o) = to_h16x4(geglu_value(g, m, nh, h, gt));
 }
 
-template <int BN, int AMODE>
+// WIDE: the wide tile epilogue (igemm_epi.h) — dense GEMMs with a 16-bit output and no GEGLU (the launcher decides)
+template <int BN, int AMODE, bool WIDE = false>
 __global__ void __launch_bounds__(256, 2) igemm_kernel(const GemmArgs g) {
   constexpr int NT = BN / 32;       // 16-wide n tiles per wave
   constexpr int MT = 4;             // 16-high m tiles per wave
@@ -278,7 +279,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const GemmArgs g) {
     return;
   }
   // (an LDS-staged, 16-byte coalesced store variant measured no faster: L2 merges the 8-byte pieces)
-  epi_tile<MT, NT, AMODE == A_DENSE>(g, z, m0 + wm * 64 + l15, 16, n0 + wn * (BN / 2) + lq * 4, acc, smem, 2, wm, wn, tm, n0);
+  epi_tile<MT, NT, AMODE == A_DENSE, WIDE>(g, z, m0 + wm * 64 + l15, 16, n0 + wn * (BN / 2) + lq * 4, acc, smem, 2, wm, wn, tm, n0);
 }
 
 // sums the split-K slabs and applies the epilogue
@@ -347,6 +348,9 @@ __global__ void pack_geglu_kernel(const float* __restrict__ w, const float* __re
 template <int BN, int AMODE>
 void launch_inst(const GemmArgs& g, dim3 grid, hipStream_t s) {
   constexpr int smem = 2 * (BM * 128 + BN * 128);
+  if constexpr (AMODE == A_DENSE && BN >= 64) {
+    if (g.act != ACT_GEGLU && !g.out_f32) { hipLaunchKernelGGL((igemm_kernel<BN, AMODE, true>), grid, dim3(256), smem, s, g); return; }
+  }
   hipLaunchKernelGGL((igemm_kernel<BN, AMODE>), grid, dim3(256), smem, s, g);
 }
 
@@ -368,6 +372,8 @@ void launch_bn(const GemmArgs& g, dim3 grid, hipStream_t s) {
 template <int BN, int AMODE>
 void attr_inst() {
   HIP_OK(hipFuncSetAttribute((const void*)igemm_kernel<BN, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM * 128 + BN * 128)));
+  if constexpr (AMODE == A_DENSE && BN >= 64)
+    HIP_OK(hipFuncSetAttribute((const void*)igemm_kernel<BN, AMODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM * 128 + BN * 128)));
 }
 template <int BN>
 void attr_bn() {

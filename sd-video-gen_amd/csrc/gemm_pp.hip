@@ -17,7 +17,8 @@ namespace SDNS {
 
 namespace {
 
-template <int BN>
+// WIDE: the wide tile epilogue (igemm_epi.h; 16-bit output without GEGLU — the launcher decides)
+template <int BN, bool WIDE>
 __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs g) {
   constexpr int NT = BN / 32;            // 16-wide n tiles per wave
   constexpr int MT = 4;                  // 16-high m tiles per wave
@@ -203,21 +204,24 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs g) {
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------------------
-  epi_tile<MT, NT, true>(g, 0, m0 + wm * 64 + l15, 16, n0 + wn * (BN / 2) + lq * 4, acc, smem, 4, wm, wn, tm, n0);
+  epi_tile<MT, NT, true, WIDE>(g, 0, m0 + wm * 64 + l15, 16, n0 + wn * (BN / 2) + lq * 4, acc, smem, 4, wm, wn, tm, n0);
 }
 
 template <int BN>
 void launch_pp(const GemmArgs& g, hipStream_t s) {
   constexpr int smem = 3 * (256 * 128 + BN * 128) + 1024;
   const int tiles = cdiv(g.M, 256) * cdiv(g.N, BN);
-  hipLaunchKernelGGL((gemm_pp_kernel<BN>), dim3(tiles), dim3(512), smem, s, g);
+  if (g.act == ACT_GEGLU || g.out_f32) hipLaunchKernelGGL((gemm_pp_kernel<BN, false>), dim3(tiles), dim3(512), smem, s, g);
+  else hipLaunchKernelGGL((gemm_pp_kernel<BN, true>), dim3(tiles), dim3(512), smem, s, g);
 }
 
 }  // namespace
 
 void gemm_pp_init_device() {
-  HIP_OK(hipFuncSetAttribute((const void*)gemm_pp_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 * 128 + 128 * 128) + 1024));
-  HIP_OK(hipFuncSetAttribute((const void*)gemm_pp_kernel<160>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 * 128 + 160 * 128) + 1024));
+  HIP_OK(hipFuncSetAttribute((const void*)gemm_pp_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 * 128 + 128 * 128) + 1024));
+  HIP_OK(hipFuncSetAttribute((const void*)gemm_pp_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 * 128 + 128 * 128) + 1024));
+  HIP_OK(hipFuncSetAttribute((const void*)gemm_pp_kernel<160, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 * 128 + 160 * 128) + 1024));
+  HIP_OK(hipFuncSetAttribute((const void*)gemm_pp_kernel<160, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 * 128 + 160 * 128) + 1024));
 }
 
 int gemm_pp_bn(const GemmArgs& g) {

@@ -81,8 +81,8 @@ __device__ __forceinline__ f32x4 ln_fold(const GemmArgs& g, int z, int m, int n,
 
 // the same for a wave's whole accumulator tile (rows mr + 16 i, columns nc + 16 j .. +3), statistics and column sums
 // loaded once up front: inside the store loop they would be re-fetched after every store (possible aliasing with C)
-template <int MT_, int NT_>
-__device__ __forceinline__ void ln_fold_tile(const GemmArgs& g, int z, int mr, int mstep, int nc, float alpha, f32x4 (&acc)[MT_][NT_]) {
+template <int MT_, int NT_, typename ColFn>
+__device__ __forceinline__ void ln_fold_tile(const GemmArgs& g, int z, int mr, int mstep, ColFn cj, float alpha, f32x4 (&acc)[MT_][NT_]) {
   if (g.ln_swapped) {
     float sm[MT_];
     f32x4 rs[NT_], rm[NT_];
@@ -90,7 +90,7 @@ __device__ __forceinline__ void ln_fold_tile(const GemmArgs& g, int z, int mr, i
     for (int i = 0; i < MT_; ++i) sm[i] = (mr + mstep * i < g.M) ? g.ln_s[mr + mstep * i] : 0.f;
 #pragma unroll
     for (int j = 0; j < NT_; ++j) {
-      const int n = nc + 16 * j;
+      const int n = cj(j);
       const int64_t t = z * g.ln_zstride + n;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -113,7 +113,7 @@ __device__ __forceinline__ void ln_fold_tile(const GemmArgs& g, int z, int mr, i
       rm[i] = ok ? g.ln_rm[mr + mstep * i] : 0.f;
     }
 #pragma unroll
-    for (int j = 0; j < NT_; ++j) sv[j] = (nc + 16 * j < g.N) ? *(const f32x4*)(g.ln_s + nc + 16 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT_; ++j) sv[j] = (cj(j) < g.N) ? *(const f32x4*)(g.ln_s + cj(j)) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < MT_; ++i)
 #pragma unroll
@@ -193,7 +193,7 @@ __device__ __forceinline__ void bar() {
 // the K loop) and the first BN_ threads add them in a fixed order.  WM_ = waves along M, wm / wn = this wave's position,
 // BNH_ = columns per wave, tile_m = row-tile index, n0 = first column of the tile.
 // LN_ (dense GEMMs only): additionally emit the LayerNorm row partials of the stored values (GemmArgs::ln_part).
-template <int MT_, int NT_, bool LN_ = false>
+template <int MT_, int NT_, bool LN_ = false, bool WIDE_ = false>
 __device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int mstep, int nc, f32x4 (&acc)[MT_][NT_],
                                          char* lds = nullptr, int WM_ = 0, int wm = 0, int wn = 0, int tile_m = 0, int n0 = 0) {
   const bool geglu = g.act == ACT_GEGLU;
@@ -201,13 +201,46 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int m
   const bool emit_ln = LN_ && g.ln_part != nullptr && lds != nullptr;
   const float* const bias_z = g.bias ? g.bias + (int64_t)z * g.bias_zs : nullptr;
   float alpha = g.alpha;
-  if (g.ln_rs) { ln_fold_tile<MT_, NT_>(g, z, mr, mstep, nc, alpha, acc); alpha = 1.f; }
+  // ---- wide form (16-bit outputs, no GEGLU): a lane of a 16 x 16 MFMA tile holds 4 consecutive output columns (8 bytes of a row);
+  // v_permlane16_swap_b32 between the tiles j and j + 1 of a pair (odd 16-lane rows of tile j <-> even rows of tile j + 1, one swap per
+  // register) leaves every lane with 8 CONSECUTIVE columns — lane rows 0, 2 take columns 0-7 / 8-15 of tile j, rows 1, 3 columns 0-7 /
+  // 8-15 of tile j + 1 — so that a row is stored (and its residual loaded) 16 bytes per lane: half the store / load instructions of the
+  // epilogue, which is issue-bound (cdna_hip_programming.md T21; the K = 320 / 640 launches spend half to two thirds of their time
+  // here).  cj(j) = first of the 4 columns acc[i][j] holds in this lane, before or after the exchange.
+  // WIDE_ is a compile-time choice of the kernel instantiation (the launcher picks it when the output is 16-bit and the activation is
+  // not GEGLU): with the two forms selected at run time inside one kernel the allocator spills 250+ registers at NT_ = 5
+  constexpr bool wide = WIDE_ && NT_ >= 2;
+  // column of acc[i][j][0] in this lane: paired tiles cb + 16 (j & ~1) + (j & 1) * cstep, an unpaired last tile nc + 16 j (two registers,
+  // not a table: these kernels sit at the 256-register limit)
+  int cb = nc, cstep = 16;
+  if constexpr (wide) {
+    const int lq_ = (threadIdx.x & 63) >> 4;
+    cb = (lq_ & 1) ? nc - 4 * lq_ + 16 + 4 * (lq_ - 1) : nc;
+    cstep = 4;
+#pragma unroll
+    for (int j = 0; j + 1 < NT_; j += 2) {
+#pragma unroll
+      for (int i = 0; i < MT_; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // inline asm, not __builtin_amdgcn_permlane16_swap: hipcc (ROCm 7.2) folds the unrolled builtin calls on vector elements into
+          // ONE swap whose result it copies to every element (tools/probe/probe_permlane16.hip shows the instruction itself is fine).
+          // "s_nop 1": the two wait states between a VALU write of an operand and the permlane read (hipcc pads nothing inside asm).
+          float x = acc[i][j][e], y = acc[i][j + 1][e];
+          asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+          acc[i][j][e] = x;
+          acc[i][j + 1][e] = y;
+        }
+    }
+  }
+  auto cj = [&](int j) -> int { return j < (NT_ & ~1) ? cb + 16 * (j & ~1) + (j & 1) * cstep : nc + 16 * j; };
+  if (g.ln_rs) { ln_fold_tile<MT_, NT_>(g, z, mr, mstep, cj, alpha, acc); alpha = 1.f; }
   // ---- loads
   f32x4 bj[NT_];
   float bi[MT_];
 #pragma unroll
   for (int j = 0; j < NT_; ++j) {
-    const int n = nc + 16 * j;
+    const int n = cj(j);
     bj[j] = (bias_z && !g.bias_row && n < g.N) ? *(const f32x4*)(bias_z + n) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
 #pragma unroll
@@ -219,6 +252,7 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int m
   const int ldbn = g.bias_bn_ld ? g.bias_bn_ld : g.N;
   // two row groups: halves the registers the prefetched operands need (one more exposed round trip, not twenty)
   constexpr int RG = (MT_ + 1) / 2;
+  constexpr int NTP = NT_ & ~1;          // tiles that belong to a pair in the wide form
 #pragma unroll
   for (int i0 = 0; i0 < MT_; i0 += RG) {
     f32x4 ex[RG][NT_];        // per-sample bias + residual of this row group (one array: a conv has one or the other)
@@ -233,11 +267,83 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int m
         const float* row = g.bias_bn + (int64_t)(m / g.rows_per_batch) * ldbn;
 #pragma unroll
         for (int j = 0; j < NT_; ++j) {
-          const int n = nc + 16 * j;
+          const int n = cj(j);
           if (i0 + ii < MT_ && m < g.M && n < g.N) ex[ii][j] = *(const f32x4*)(row + n);
         }
       }
     }
+    if constexpr (wide) {
+      // ================= wide form: pairs of tiles as 8 consecutive columns per lane, 16-byte residual loads and stores
+      if (has_res) {
+#pragma unroll
+        for (int ii = 0; ii < RG; ++ii) {
+          const int m = mr + mstep * (i0 + ii);
+          const h16* rrow = g.residual + (int64_t)z * g.sC + (int64_t)m * g.ldr;
+          if (!(i0 + ii < MT_ && m < g.M)) continue;
+#pragma unroll
+          for (int j = 0; j < NTP; j += 2) {
+            const int n = cj(j);
+            if (n + 4 < g.N) {
+              const h16x8 r = *(const h16x8*)(rrow + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { ex[ii][j][e] += (float)r[e]; ex[ii][j + 1][e] += (float)r[4 + e]; }
+            } else if (n < g.N) {
+              const h16x4 r = *(const h16x4*)(rrow + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) ex[ii][j][e] += (float)r[e];
+            }
+          }
+          if constexpr (NT_ & 1) {
+            const int n = cj(NT_ - 1);
+            if (n < g.N) {
+              const h16x4 r = *(const h16x4*)(rrow + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) ex[ii][NT_ - 1][e] += (float)r[e];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int ii = 0; ii < RG; ++ii) {
+        const int i = i0 + ii;
+        if (i >= MT_) continue;
+        const int m = mr + mstep * i;
+        if (m >= g.M) continue;
+        auto value = [&](int j) -> h16x4 {
+          f32x4 v = acc[i][j] * alpha + bj[j] + bi[i];
+          v += ex[ii][j];
+          if (g.act == ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+          } else if (g.act == ACT_GELU) {
+            v = gelu_erf4(v);
+          }
+          const h16x4 w = to_h16x4(v);
+          // the accumulator is dead from here: keep what the consumer will read (the rounded values) in it for the column / row sums below
+          if (emit_gn || emit_ln) { acc[i][j][0] = (float)w[0]; acc[i][j][1] = (float)w[1]; acc[i][j][2] = (float)w[2]; acc[i][j][3] = (float)w[3]; }
+          return w;
+        };
+        h16* crow = (h16*)g.C + (int64_t)z * g.sC + (int64_t)m * g.ldc;
+#pragma unroll
+        for (int j = 0; j < NTP; j += 2) {
+          const int n = cj(j);
+          if (n + 4 < g.N) {
+            const h16x4 w0 = value(j), w1 = value(j + 1);
+            h16x8 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { w[e] = w0[e]; w[4 + e] = w1[e]; }
+            *(h16x8*)(crow + n) = w;
+          } else if (n < g.N) {
+            *(h16x4*)(crow + n) = value(j);
+          }
+        }
+        if constexpr (NT_ & 1) {
+          const int n = cj(NT_ - 1);
+          if (n < g.N) *(h16x4*)(crow + n) = value(NT_ - 1);
+        }
+      }
+    } else {
+    // ================= narrow form (GEGLU, f32 outputs, single-tile waves): 4 columns per lane and tile
     if (has_res) {
 #pragma unroll
       for (int ii = 0; ii < RG; ++ii) {
@@ -289,12 +395,11 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int m
           else {
             const h16x4 w = to_h16x4(v);
             *(h16x4*)((h16*)g.C + o) = w;
-            // the accumulator is dead from here: keep what the consumer will read (the rounded values) in it for the
-            // GroupNorm column sums below — no extra registers live across the stores
             if (emit_gn || emit_ln) { acc[i][j][0] = (float)w[0]; acc[i][j][1] = (float)w[1]; acc[i][j][2] = (float)w[2]; acc[i][j][3] = (float)w[3]; }
           }
         }
       }
+    }
     }
   }
   if (emit_gn) {
@@ -310,7 +415,7 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int m
       f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < MT_; ++i) {
-        const bool ok = (mr + mstep * i < g.M) && (nc + 16 * j < g.N);
+        const bool ok = (mr + mstep * i < g.M) && (cj(j) < g.N);
         const f32x4 v = ok ? acc[i][j] : f32x4{0.f, 0.f, 0.f, 0.f};
         a += v; b += v * v;
       }
@@ -318,7 +423,7 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int m
       for (int e = 0; e < 4; ++e) {
         const float x = row16_sum(a[e]), y = row16_sum(b[e]);
         if ((lane & 15) == 0) {
-          const int col = wn * BNH + j * 16 + (lane >> 4) * 4 + e;
+          const int col = cj(j) - n0 + e;                   // column of the tile this lane's register e of tile j holds
           sc[(wm * ncols + col) * 2] = x;
           sc[(wm * ncols + col) * 2 + 1] = y;
         }
@@ -348,7 +453,7 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int m
       if (m < g.M) {
 #pragma unroll
         for (int j = 0; j < NT_; ++j)
-          if (nc + 16 * j < g.N) {
+          if (cj(j) < g.N) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float v = acc[i][j][e]; a += v; b += v * v; }
           }

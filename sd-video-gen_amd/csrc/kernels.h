@@ -98,6 +98,14 @@ void quant_mx_f32(const float* x, int ldx, uint8_t* q, uint8_t* sc, int64_t rows
 bool gemm_fp8_supported(int M, int N, int K);
 void gemm_fp8(svg_ctx* ctx, const uint8_t* A, const uint8_t* As, const uint8_t* W, const uint8_t* Ws, const GemmArgs& g, hipStream_t s);
 
+// ---- MX fp8 3x3 convolution (conv_halo_fp8.hip): activations e4m3 [P][Cp] + E8M0 [P][Cp/32] (Cp = C rounded up to 128, padding
+// zero), weights e4m3 [Npad][9][Cp] + E8M0 [9][Cp/128][Npad][4]
+bool conv_halo_fp8_supported(int B, int H, int W, int Cin, int N);
+void conv_halo_fp8_init_device();
+void quant_act_mx(svg_ctx* ctx, const h16* x, int C, uint8_t* q, uint8_t* sc, int64_t P, hipStream_t s);
+void pack_conv3x3_mx(const float* w_oihw, uint8_t* q, uint8_t* sc, int O, int I, int Npad, int Cp, hipStream_t s);
+void conv_halo_fp8(svg_ctx* ctx, const uint8_t* A8, const uint8_t* As, const uint8_t* W8, const uint8_t* Ws, int Npad, const GemmArgs& g, hipStream_t s);
+
 // fused GEGLU feed-forward (C = 320): out = (GEGLU(LN(x) W1^T + b1)) W2^T + b2 + residual; the M x 4C intermediate stays on chip
 bool ff_fused_supported(int C, int M);
 // cross-attention of a C = 320 block in one launch (xattn_fused.hip): to_q + attention over <= 80 context keys + to_out + residual

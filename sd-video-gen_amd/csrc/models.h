@@ -142,7 +142,12 @@ struct PackedLinear {
 };
 
 // ---- SD VAE -------------------------------------------------------------------------------------------
-struct ConvW { h16* w = nullptr; float* b = nullptr; int Cin = 0, Cout = 0, Opad = 0; };
+struct ConvW {
+  h16* w = nullptr; float* b = nullptr; int Cin = 0, Cout = 0, Opad = 0;
+  // MX fp8 copy (conv_halo_fp8.hip; models configured with fp8=1, stride-1 convs with Cin % 64 == 0): e4m3 [Opad][9][Cp] and
+  // E8M0 [9][Cp/128][Opad][4], quantised from the f32 weights at load
+  uint8_t* w8 = nullptr; uint8_t* w8s = nullptr; int Cp = 0;
+};
 struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
 struct ResW { NormW n1, n2; ConvW c1, c2; PackedLinear sc; bool has_sc = false; int temb_off = -1; };
 struct VaeAttnW { NormW gn; PackedLinear qk, v, proj; int C = 0; };
@@ -232,7 +237,8 @@ struct LnEmit {
 static inline int64_t gn_part_floats(int64_t B, int64_t HW, int64_t N) { return B * (HW / 128 + 1) * N * 2; }
 
 // shared graph pieces (sdnet.cpp)
-ConvW load_conv3x3(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int Cin, int Cout, hipStream_t s);
+// fp8: additionally keep the MX fp8 copy of the weights (ConvW::w8) when the conv qualifies (Cin % 64 == 0)
+ConvW load_conv3x3(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int Cin, int Cout, hipStream_t s, bool fp8 = false);
 // fold != nullptr: the LayerNorm (gamma, beta) in front of this projection is folded into the packed weights (GemmArgs::ln_*)
 PackedLinear load_linear(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int N, int K, bool bias, hipStream_t s,
                          const NormW* fold = nullptr);
@@ -243,6 +249,11 @@ float* keep_f32(svg_ctx* ctx, WeightStore& ws, const std::string& name, int64_t 
 // out (B,Ho,Wo,Cout) = conv3x3(x) + bias [+ per-sample bias] [+ residual]
 void conv3x3(svg_ctx* ctx, const h16* x, const ConvW& cw, void* out, int B, int H, int W, int amode, const float* bias_bn,
              int bias_bn_ld, const h16* residual, int out_f32, hipStream_t s, GnEmit* emit = nullptr);
+// the same stride-1 conv on MX fp8 operands (conv_halo_fp8.hip): x8 / xs = the quantised input of quant_act_mx (or of the quantising
+// GroupNorm apply pass); the caller asks conv3x3_fp8_ok() first
+bool conv3x3_fp8_ok(const ConvW& cw, int B, int H, int W);
+void conv3x3_fp8(svg_ctx* ctx, const uint8_t* x8, const uint8_t* xs, const ConvW& cw, h16* out, int B, int H, int W, const float* bias_bn,
+                 int bias_bn_ld, const h16* residual, hipStream_t s, GnEmit* emit = nullptr);
 // C[M,N] = act(A[M,K] W^T + b) [+ residual]
 // emit / rows_per_sample: GroupNorm column sums of the output (M = samples x rows_per_sample).  A2 / k_split: the A operand is the
 // channel concat [A | A2] of two tensors (columns >= k_split come from A2, row stride lda2) without materialising it.

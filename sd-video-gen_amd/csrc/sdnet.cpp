@@ -20,7 +20,7 @@ float* keep_f32(svg_ctx* ctx, WeightStore& ws, const std::string& name, int64_t 
   return w.f32;   // stays in the store (small 1-D parameters)
 }
 
-ConvW load_conv3x3(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int Cin, int Cout, hipStream_t s) {
+ConvW load_conv3x3(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int Cin, int Cout, hipStream_t s, bool fp8) {
   const Weight& w = ws.get(prefix + ".weight", {Cout, Cin, 3, 3});
   ConvW cw;
   cw.Cout = Cout;
@@ -32,6 +32,12 @@ ConvW load_conv3x3(svg_ctx* ctx, WeightStore& ws, const std::string& prefix, int
   cw.b = (float*)ctx->dalloc(cw.Opad * sizeof(float));
   HIP_OK(hipMemsetAsync(cw.b, 0, cw.Opad * sizeof(float), s));
   HIP_OK(hipMemcpyAsync(cw.b, keep_f32(ctx, ws, prefix + ".bias", Cout), Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (fp8 && Cin % 64 == 0 && cw.Opad >= 128) {   // MX fp8 copy, quantised from the f32 weights (one rounding, not two)
+    cw.Cp = (int)align_up(Cin, 128);
+    cw.w8 = (uint8_t*)ctx->dalloc((int64_t)cw.Opad * 9 * cw.Cp);
+    cw.w8s = (uint8_t*)ctx->dalloc((int64_t)9 * (cw.Cp / 128) * cw.Opad * 4);
+    pack_conv3x3_mx(w.f32, cw.w8, cw.w8s, Cout, Cin, cw.Opad, cw.Cp, s);
+  }
   HIP_OK(hipStreamSynchronize(s));
   ws.release(prefix + ".weight");
   return cw;
@@ -88,6 +94,30 @@ static void plan_gn_emit(GemmArgs& g, GnEmit* emit, int rows_per_sample) {
   g.gn_part = emit->buf;
   emit->st.part = emit->buf;
   emit->st.tiles_per_sample = rows_per_sample / rows;
+}
+
+bool conv3x3_fp8_ok(const ConvW& cw, int B, int H, int W) {
+  return cw.w8 != nullptr && conv_halo_fp8_supported(B, H, W, cw.Cin, cw.Opad);
+}
+
+void conv3x3_fp8(svg_ctx* ctx, const uint8_t* x8, const uint8_t* xs, const ConvW& cw, h16* out, int B, int H, int W, const float* bias_bn,
+                 int bias_bn_ld, const h16* residual, hipStream_t s, GnEmit* emit) {
+  SVG_CHECK(conv3x3_fp8_ok(cw, B, H, W), "conv3x3_fp8: %d x %dx%d x %d -> %d does not qualify", B, H, W, cw.Cin, cw.Opad);
+  GemmArgs g;
+  g.H = H; g.W = W; g.Cin = cw.Cin; g.amode = A_CONV_S1; g.Ho = H; g.Wo = W;
+  g.K = 9 * cw.Cin; g.M = B * H * W; g.N = cw.Opad; g.n_valid = cw.Opad;
+  g.bias = cw.b;
+  g.bias_bn = bias_bn; g.bias_bn_ld = bias_bn_ld; g.rows_per_batch = H * W;
+  g.residual = residual; g.ldr = cw.Opad;
+  g.C = out; g.ldc = cw.Opad;
+  // GroupNorm column sums of the output: one partial per 16 x 16 pixel block, like the fp16 halo conv
+  static const int use_epi = getenv("SVG_GN_EPI") ? atoi(getenv("SVG_GN_EPI")) : 1;
+  if (use_epi && emit && emit->buf && H * W >= 1024 && (H * W) % 256 == 0) {
+    g.gn_part = emit->buf;
+    emit->st.part = emit->buf;
+    emit->st.tiles_per_sample = H * W / 256;
+  }
+  conv_halo_fp8(ctx, x8, xs, cw.w8, cw.w8s, cw.Opad, g, s);
 }
 
 void conv3x3(svg_ctx* ctx, const h16* x, const ConvW& cw, void* out, int B, int H, int W, int amode, const float* bias_bn,
@@ -188,6 +218,7 @@ void sd_init_device() {
   ff_fused_init_device();
   xattn_fused_init_device();
   gemm_fp8_init_device();
+  conv_halo_fp8_init_device();
 }
 
 }  // namespace SDNS

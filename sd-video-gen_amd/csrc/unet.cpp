@@ -30,12 +30,12 @@ struct TembCollector {
   }
 };
 
-ResW load_res_t(svg_ctx* ctx, WeightStore& ws, const std::string& p, int cin, int cout, TembCollector& tc, hipStream_t s) {
+ResW load_res_t(svg_ctx* ctx, WeightStore& ws, const std::string& p, int cin, int cout, TembCollector& tc, hipStream_t s, bool fp8) {
   ResW r;
   r.n1 = load_norm(ctx, ws, p + ".norm1", cin);
-  r.c1 = load_conv3x3(ctx, ws, p + ".conv1", cin, cout, s);
+  r.c1 = load_conv3x3(ctx, ws, p + ".conv1", cin, cout, s, fp8);
   r.n2 = load_norm(ctx, ws, p + ".norm2", cout);
-  r.c2 = load_conv3x3(ctx, ws, p + ".conv2", cout, cout, s);
+  r.c2 = load_conv3x3(ctx, ws, p + ".conv2", cout, cout, s, fp8);
   r.has_sc = cin != cout;
   if (r.has_sc) r.sc = load_linear(ctx, ws, p + ".conv_shortcut", cout, cin, true, s);
   r.temb_off = tc.add(p + ".time_emb_proj", cout);
@@ -182,6 +182,10 @@ void UnetModel::finalize(svg_ctx* ctx, int64_t* n_params) {
   const int c0 = block_out[0];
   temb_dim = 4 * c0;
   TembCollector tc;
+  // fp8=1: the resnets' 3x3 convs get an MX fp8 copy (conv_halo_fp8.hip) — half of the UNet's FLOPs, K = 2 880 ... 23 040.
+  // $SVG_FP8_CONV=0 / $SVG_FP8_PROJ=0 switch the two fp8 placements off separately (A/B)
+  const bool fp8_conv = fp8 && svg_env_i64("SVG_FP8_CONV", 1) != 0;
+  const bool fp8_proj = fp8 && svg_env_i64("SVG_FP8_PROJ", 0) != 0;
   time1 = load_linear(ctx, ws, "time_embedding.linear_1", temb_dim, c0, true, s);
   time2 = load_linear(ctx, ws, "time_embedding.linear_2", temb_dim, temb_dim, true, s);
   conv_in = load_conv3x3(ctx, ws, "conv_in", in_ch, c0, s);
@@ -193,7 +197,7 @@ void UnetModel::finalize(svg_ctx* ctx, int64_t* n_params) {
     std::vector<ResW> rs; std::vector<XfBlockW> as;
     const std::string bp = "down_blocks." + std::to_string(i);
     for (int j = 0; j < layers; ++j) {
-      rs.push_back(load_res_t(ctx, ws, bp + ".resnets." + std::to_string(j), cin, block_out[i], tc, s));
+      rs.push_back(load_res_t(ctx, ws, bp + ".resnets." + std::to_string(j), cin, block_out[i], tc, s, fp8_conv));
       cin = block_out[i];
       if (attn[i]) as.push_back(load_xf(ctx, ws, bp + ".attentions." + std::to_string(j), cin, ctx_dim, s));
       skip_ch.push_back(cin);
@@ -205,9 +209,9 @@ void UnetModel::finalize(svg_ctx* ctx, int64_t* n_params) {
     }
   }
   // ---- mid
-  mid0 = load_res_t(ctx, ws, "mid_block.resnets.0", cin, cin, tc, s);
+  mid0 = load_res_t(ctx, ws, "mid_block.resnets.0", cin, cin, tc, s, fp8_conv);
   mid_attn = load_xf(ctx, ws, "mid_block.attentions.0", cin, ctx_dim, s);
-  mid1 = load_res_t(ctx, ws, "mid_block.resnets.1", cin, cin, tc, s);
+  mid1 = load_res_t(ctx, ws, "mid_block.resnets.1", cin, cin, tc, s, fp8_conv);
   // ---- up (reversed block_out; layers+1 resnets per block, each consuming one skip)
   for (int i = 0; i < nb; ++i) {
     const int bi = nb - 1 - i;
@@ -216,15 +220,15 @@ void UnetModel::finalize(svg_ctx* ctx, int64_t* n_params) {
     const std::string bp = "up_blocks." + std::to_string(i);
     for (int j = 0; j < layers + 1; ++j) {
       const int sc = skip_ch.back(); skip_ch.pop_back();
-      rs.push_back(load_res_t(ctx, ws, bp + ".resnets." + std::to_string(j), cin + sc, cout, tc, s));
+      rs.push_back(load_res_t(ctx, ws, bp + ".resnets." + std::to_string(j), cin + sc, cout, tc, s, fp8_conv));
       cin = cout;
       if (attn[bi]) as.push_back(load_xf(ctx, ws, bp + ".attentions." + std::to_string(j), cin, ctx_dim, s));
     }
     up_res.push_back(rs); up_attn.push_back(as);
     if (i < nb - 1) up_s.push_back(load_conv3x3(ctx, ws, bp + ".upsamplers.0.conv", cin, cin, s));
   }
-  if (fp8) {
-    // BASELINE configs[4]: the dense projections that qualify get an MX fp8 copy (attention out-projections, ff.net.2, proj_out,
+  if (fp8_proj) {
+    // (round 2-3 placement, off by default since round 4: does not pay, profiles/r03_bench_line_fp8.json) the dense projections that qualify get an MX fp8 copy (attention out-projections, ff.net.2, proj_out,
     // 1x1 shortcuts, cross-attention k / v at the 32 x 32 level and below: K = 640 ... 5120); the 64 x 64 level (K = 320) and
     // every LayerNorm-folded / GEGLU projection stay bf16, as do the convolutions
     auto add_xf = [&](XfBlockW& b) {
@@ -310,7 +314,21 @@ struct UnetRun {
     else groupnorm(ctx, xin, Cin, nullptr, 0, r.n1.g, r.n1.b, t0, N, HW, m->groups, 1e-5f, 1, s, skip ? nullptr : &x.st, nullptr);
     h16* t1 = ctx->arena.get<h16>(P * r.c1.Opad);
     GnEmit e1 = emit_for(HW, r.c1.Opad);
-    conv3x3(ctx, t0, r.c1, t1, N, H, W, A_CONV_S1, temb + r.temb_off, temb_ld, nullptr, 0, s, &e1);
+    // MX fp8 convs (fp8=1): the GroupNorm + SiLU output is quantised to e4m3 + one E8M0 scale per 32 channels and the conv runs on
+    // v_mfma_scale_f32_16x16x128_f8f6f4 at twice the 16-bit matrix rate
+    auto conv_mx = [&](const h16* in, const ConvW& cw, h16* o, const float* bbn, int bbn_ld, const h16* res, GnEmit* e) -> bool {
+      if (!conv3x3_fp8_ok(cw, N, H, W)) return false;
+      ctx->arena.push();
+      const int64_t Cp = align_up(cw.Cin, 128);
+      uint8_t* q = ctx->arena.get<uint8_t>(P * Cp);
+      uint8_t* qs = ctx->arena.get<uint8_t>(P * (Cp / 32));
+      quant_act_mx(ctx, in, cw.Cin, q, qs, P, s);
+      conv3x3_fp8(ctx, q, qs, cw, o, N, H, W, bbn, bbn_ld, res, s, e);
+      ctx->arena.pop();
+      return true;
+    };
+    if (!conv_mx(t0, r.c1, t1, temb + r.temb_off, temb_ld, nullptr, &e1))
+      conv3x3(ctx, t0, r.c1, t1, N, H, W, A_CONV_S1, temb + r.temb_off, temb_ld, nullptr, 0, s, &e1);
     h16* t2 = ctx->arena.get<h16>(P * r.n2.C);
     groupnorm(ctx, t1, r.n2.C, nullptr, 0, r.n2.g, r.n2.b, t2, N, HW, m->groups, 1e-5f, 1, s, &e1.st, nullptr);
     const h16* res = xin;
@@ -320,7 +338,8 @@ struct UnetRun {
       else linear(ctx, xin, Cin, r.sc, sc, r.sc.N, (int)P, ACT_NONE, nullptr, 0, 0, s);
       res = sc;
     }
-    conv3x3(ctx, t2, r.c2, outp, N, H, W, A_CONV_S1, nullptr, 0, res, 0, s, &eo);
+    if (!conv_mx(t2, r.c2, outp, nullptr, 0, res, &eo))
+      conv3x3(ctx, t2, r.c2, outp, N, H, W, A_CONV_S1, nullptr, 0, res, 0, s, &eo);
     ctx->arena.pop();
     out.p = outp;
     out.st = eo.st;

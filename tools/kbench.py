@@ -56,6 +56,22 @@ def main():
             ms, fl, _ = timeit(ctx, "conv3x3", lambda: ctx.check(ctx.lib.svg_op_conv3x3(
                 ctx.h, x.data_ptr(), w.data_ptr(), None, out.data_ptr(), b, H, H, Cin, Cout, mode, stream()), "conv"))
             print("b=%d %4d %5d %5d %d  %8.3f ms  %7.1f TF" % (b, H, Cin, Cout, mode, ms, fl / ms / 1e9))
+    if "convmx" in a.what:
+        print("== MX fp8 conv3x3 vs fp16 (B=%d): H Cin Cout res  fp8 ms TF | fp16 ms TF" % B)
+        f16 = torch.float16
+        for (H, Cin, Cout) in [(64, 320, 320), (64, 640, 320), (64, 960, 320), (32, 640, 640), (32, 1280, 640), (16, 1280, 1280), (16, 2560, 1280)]:
+            x = torch.randn(B, H, H, Cin, device="cuda").to(f16)
+            w = torch.randn(Cout, Cin, 3, 3, device="cuda") / math.sqrt(9 * Cin)
+            res = torch.randn(B, H, H, Cout, device="cuda").to(f16)
+            out = torch.empty(B, H, H, Cout, device="cuda", dtype=f16)
+            for r in (None, res):
+                ms8, fl, _ = timeit(ctx, "conv3x3", lambda: ctx.check(ctx.lib.svg_op_conv3x3_mx_f16(
+                    ctx.h, x.data_ptr(), w.data_ptr(), None, r.data_ptr() if r is not None else None, out.data_ptr(), None, None, B, H, H, Cin, Cout, stream()), "convmx"))
+                ms16 = float("nan")
+                if r is None:
+                    ms16, _, _ = timeit(ctx, "conv3x3", lambda: ctx.check(ctx.lib.svg_op_conv3x3_f16(
+                        ctx.h, x.data_ptr(), w.data_ptr(), None, out.data_ptr(), B, H, H, Cin, Cout, 0, stream()), "conv"))
+                print("b=%d %4d %5d %5d res%d  %8.3f ms %7.1f TF | %8.3f ms %7.1f TF" % (B, H, Cin, Cout, r is not None, ms8, fl / ms8 / 1e9, ms16, fl / ms16 / 1e9))
     if "gemm" in a.what:
         print("== gemm (B=%d): M N K act  ms  TFLOP/s" % B)
         shapes = []

@@ -19,13 +19,16 @@ def main():
     ap.add_argument("--clips", type=int, default=28)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--no-vae", action="store_true")
+    ap.add_argument("--fp8", action="store_true", help="MX fp8 3x3 convs (SDUtils(fp8=True))")
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--grep", default="", help="only print call sites containing this substring")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "shape_profile.json"))
     a = ap.parse_args()
     import torch
     from sd_video_gen_amd import config as svg_config
     from sd_video_gen_amd.sd_utils import SDUtils
     svg_config.set_args(["--dataset", "synthetic-ball", "--config", "1_16_kitti_L1_64", "--denoise", "1"])
-    sdu = SDUtils(weights="synthetic", verbose=False)
+    sdu = SDUtils(weights="synthetic", verbose=False, fp8=a.fp8, dtype=a.dtype)
     ctx = sdu.ctx
     C = a.clips
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -57,7 +60,7 @@ def main():
     for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
         print("  %-10s %6d calls %9.3f ms  %5.1f%%  %7.1f TFLOP/s" % (k, v["calls"], v["ms"], 100 * v["ms"] / tot, v["flops"] / max(v["ms"], 1e-9) / 1e9))
     print("call sites:")
-    for k, v in sorted(det.items(), key=lambda kv: -kv[1]["ms"])[:70]:
+    for k, v in [kv for kv in sorted(det.items(), key=lambda kv: -kv[1]["ms"]) if a.grep in kv[0]][:70]:
         print("  %9.3f ms %5.1f%% %4d x %8.1f us  %7.1f TF/s %6.0f GB/s  %s" % (
             v["ms"], 100 * v["ms"] / tot, v["calls"], 1000 * v["ms"] / v["calls"], v["flops"] / max(v["ms"], 1e-9) / 1e9,
             v["bytes"] / max(v["ms"], 1e-9) / 1e6, k))
