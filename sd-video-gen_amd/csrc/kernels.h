@@ -155,6 +155,9 @@ struct GnStats {
 void groupnorm(svg_ctx* ctx, const h16* x, int C1, const h16* x2, int C2, const float* gamma,
                const float* beta, h16* out, int B, int HW, int groups, float eps, int silu,
                hipStream_t s, const GnStats* st1 = nullptr, const GnStats* st2 = nullptr);
+// the same with an MX fp8 output (norm.hip: gn_apply_mx_kernel) for conv_halo_fp8; false = the caller takes groupnorm() + quant_act_mx()
+bool groupnorm_mx(svg_ctx* ctx, const h16* x, int C1, const h16* x2, int C2, const float* gamma, const float* beta, uint8_t* q, uint8_t* sc,
+                  int B, int HW, int groups, float eps, int silu, hipStream_t s, const GnStats* st1, const GnStats* st2);
 // (mean, rstd) per (sample, group) from producer column sums -> stats[B][groups][2]
 void gn_finish(svg_ctx* ctx, const GnStats& st1, int C1, const GnStats* st2, int C2, float* stats, int B, int HW, int groups, float eps,
                hipStream_t s);

@@ -154,6 +154,88 @@ __global__ void gn_apply_kernel(const h16* __restrict__ x, int C1, const h16* __
   for (; p < p_end; p += PL, sp += sstep, dp += dstep) *(h16x8*)dp = apply(*(const h16x8*)sp);
 }
 
+// ---- The same apply pass with an MX fp8 output (the input of conv_halo_fp8.hip): e4m3 [pixel][Cp] + one E8M0 scale per 32 channels
+// [pixel][Cp / 32], Cp = C rounded up to 128 (padding channels: zero data, scale 1).  A thread owns one 8-channel vector as above; the four
+// threads of a 32-channel block are adjacent lanes and agree on the block's shared exponent with two shuffles (OCP MX v1.0 section 6.3:
+// floor(log2(amax)) - 8, elements RNE + saturation at +-448 — the conversion of quant_mx_kernel / quant_act_mx_kernel, bit for bit).
+// 8 + 0.25 bytes written per vector instead of 16: the pass moves 40 % fewer bytes than the 16-bit one and no quantisation pass follows.
+__global__ void gn_apply_mx_kernel(const h16* __restrict__ x, int C1, const h16* __restrict__ x2, int C2, const float* __restrict__ stats,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, uint8_t* __restrict__ q,
+                                   uint8_t* __restrict__ sc, int HW, int groups, int silu, int CVp, int PL) {
+  __shared__ float mean_s[64], rstd_s[64];
+  const int C = C1 + C2, Cp = CVp * 8;
+  const int b = blockIdx.y;
+  const int cpg = C / groups;
+  for (int g = threadIdx.x; g < groups; g += blockDim.x) {
+    mean_s[g] = stats[((int64_t)b * groups + g) * 2];
+    rstd_s[g] = stats[((int64_t)b * groups + g) * 2 + 1];
+  }
+  __syncthreads();
+  const int tid = threadIdx.x;
+  const bool live = tid < CVp * PL;                      // (idle lanes of the last wave still take part in the shuffles)
+  const int cv = live ? tid % CVp : 0, pl = live ? tid / CVp : 0;
+  const int c0 = cv * 8;
+  const bool real = live && c0 < C;                      // padding vectors write zeros
+  float scl[8], sh[8];
+  if (real) {
+    int g = c0 / cpg, rem = c0 - g * cpg;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (rem == cpg) { rem = 0; ++g; }
+      ++rem;
+      const float a = rstd_s[g] * gamma[c0 + j];
+      scl[j] = a;
+      sh[j] = beta[c0 + j] - mean_s[g] * a;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { scl[j] = 0.f; sh[j] = 0.f; }
+  }
+  const h16* src = x; int ld = C1, coff = c0;
+  if (real && c0 >= C1) { src = x2; ld = C2; coff = c0 - C1; }
+  const int per_blk = (HW + gridDim.x - 1) / gridDim.x;
+  const int p_begin = blockIdx.x * per_blk;
+  const int p_end = min(HW, p_begin + per_blk);
+  const int SB = Cp >> 5;
+  for (int p0 = p_begin; p0 < p_end; p0 += PL) {         // every thread walks the same trips (the shuffles need whole quads)
+    const int p = p0 + pl;
+    const bool on = live && p < p_end;
+    float f[8];
+    if (on && real) {
+      const h16x8 v = *(const h16x8*)(src + ((int64_t)b * HW + p) * ld + coff);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = fmaf((float)v[j], scl[j], sh[j]);
+        if (silu) t = t * __builtin_amdgcn_rcpf(1.f + __expf(-t));
+        f[j] = (float)(h16)t;                            // the value the 16-bit pass would have stored: same numbers into the quantiser
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = 0.f;
+    }
+    float am = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) am = fmaxf(am, fabsf(f[j]));
+    am = fmaxf(am, __shfl_xor(am, 1));
+    am = fmaxf(am, __shfl_xor(am, 2));
+    int e = am > 0.f ? ((__float_as_int(am) >> 23) & 0xff) - 127 - 8 : 0;
+    e = e < -127 ? -127 : (e > 126 ? 126 : e);
+    const float inv = __int_as_float((127 - e) << 23);
+    float t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = fminf(fmaxf(f[j] * inv, -448.f), 448.f);
+    unsigned lo = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], 0, false) & 0xffffu;
+    lo |= ((unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], 0, false) & 0xffffu) << 16;
+    unsigned hi = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(t[4], t[5], 0, false) & 0xffffu;
+    hi |= ((unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(t[6], t[7], 0, false) & 0xffffu) << 16;
+    if (on) {
+      const int64_t pix = (int64_t)b * HW + p;
+      *(uint2*)(q + pix * Cp + c0) = make_uint2(lo, hi);
+      if ((cv & 3) == 0) sc[pix * SB + (cv >> 2)] = (uint8_t)(e + 127);
+    }
+  }
+}
+
 // ---- GroupNorm statistics from the producers' column sums (GemmArgs::gn_part): one workgroup per (group, sample) adds the
 // tiles_per_sample x cpg (sum, sumsq) pairs of its channels in a fixed order; a group may straddle the two sources of a concat.
 __global__ void __launch_bounds__(256) gn_finish_kernel(const float* __restrict__ p1, int C1, int tps1, const float* __restrict__ p2, int C2,
@@ -502,6 +584,35 @@ void groupnorm(svg_ctx* ctx, const h16* x, int C1, const h16* x2, int C2, const 
     }
   }
   ctx->arena.pop();
+}
+
+// GroupNorm (+SiLU) whose output is MX fp8 (e4m3 [B*HW][Cp] + E8M0 [B*HW][Cp/32], Cp = C rounded up to 128): the statistics must
+// come from the producers' epilogues (st1 / st2 valid); returns false when they do not, or the shape does not fit the apply kernel —
+// the caller then runs groupnorm() and quant_act_mx().  tmp_stats: B * groups * 2 floats of workspace.
+bool groupnorm_mx(svg_ctx* ctx, const h16* x, int C1, const h16* x2, int C2, const float* gamma, const float* beta, uint8_t* q, uint8_t* sc,
+                  int B, int HW, int groups, float eps, int silu, hipStream_t s, const GnStats* st1, const GnStats* st2) {
+  const int C = C1 + C2;
+  static const int use_epi = getenv("SVG_GN_EPI") ? atoi(getenv("SVG_GN_EPI")) : 1;
+  static const int fused = getenv("SVG_GN_MX") ? atoi(getenv("SVG_GN_MX")) : 1;
+  if (!fused || !use_epi || !st1 || !st1->valid() || (C2 != 0 && !(st2 && st2->valid()))) return false;
+  if (C % groups != 0 || C % 32 != 0 || C1 % 8 != 0 || groups > 64) return false;
+  const int Cp = (int)align_up(C, 128), CVp = Cp / 8;
+  if (CVp > 1024) return false;
+  const int PL = std::max(1, 256 / CVp);
+  ctx->arena.push();
+  float* stats = ctx->arena.get<float>((int64_t)B * groups * 2);
+  gn_finish(ctx, *st1, C1, C2 ? st2 : nullptr, C2, stats, B, HW, groups, eps, s);
+  if (SVG_LAUNCHING(ctx)) {
+    char tag[96];
+    snprintf(tag, sizeof(tag), "apply_mx_B%d_HW%d_C%d", B, HW, C);
+    ProfScope ps(ctx, PK_GNORM, s, 0, (double)B * HW * (2.0 * C + Cp + Cp / 32), tag);
+    const int threads = std::max((CVp * PL + 63) / 64 * 64, 64);
+    int nblk = std::max(1, std::min(HW / PL, std::max(HW / (PL * 16), (2048 + B - 1) / B)));
+    hipLaunchKernelGGL(gn_apply_mx_kernel, dim3(nblk, B), dim3(threads), 0, s, x, C1, x2, C2, stats, gamma, beta, q, sc, HW, groups, silu, CVp, PL);
+    check_launch("gn_apply_mx");
+  }
+  ctx->arena.pop();
+  return true;
 }
 
 void layernorm(svg_ctx* ctx, const h16* x, const float* gamma, const float* beta, h16* out, int M, int C, float eps,

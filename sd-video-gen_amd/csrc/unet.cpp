@@ -309,28 +309,34 @@ struct UnetRun {
       if (SVG_LAUNCHING(ctx)) { ProfScope ps(ctx, PK_ELT, s, 0, 4.0 * P * Cin); concat_channels(x.p, Cx, skip->p, Cs, cat, P, s); }
       xin = cat;
     }
-    h16* t0 = ctx->arena.get<h16>(P * Cin);
-    if (virt) groupnorm(ctx, x.p, Cx, skip->p, Cs, r.n1.g, r.n1.b, t0, N, HW, m->groups, 1e-5f, 1, s, &x.st, &skip->st);
-    else groupnorm(ctx, xin, Cin, nullptr, 0, r.n1.g, r.n1.b, t0, N, HW, m->groups, 1e-5f, 1, s, skip ? nullptr : &x.st, nullptr);
     h16* t1 = ctx->arena.get<h16>(P * r.c1.Opad);
     GnEmit e1 = emit_for(HW, r.c1.Opad);
-    // MX fp8 convs (fp8=1): the GroupNorm + SiLU output is quantised to e4m3 + one E8M0 scale per 32 channels and the conv runs on
-    // v_mfma_scale_f32_16x16x128_f8f6f4 at twice the 16-bit matrix rate
-    auto conv_mx = [&](const h16* in, const ConvW& cw, h16* o, const float* bbn, int bbn_ld, const h16* res, GnEmit* e) -> bool {
-      if (!conv3x3_fp8_ok(cw, N, H, W)) return false;
+    // GroupNorm + SiLU -> conv.  fp8=1 (MX fp8 convs, conv_halo_fp8.hip): the normalised tensor is written as e4m3 + one E8M0 scale per 32
+    // channels by the apply pass itself (gn_apply_mx) — or, where the statistics do not come from an epilogue, by a quantising pass over
+    // the 16-bit tensor — and the conv runs on v_mfma_scale_f32_16x16x128_f8f6f4 at twice the 16-bit matrix rate.
+    auto norm_conv = [&](const h16* a, int Ca, const h16* a2, int Ca2, const NormW& nw, const GnStats* s1, const GnStats* s2, const ConvW& cw, h16* o,
+                         const float* bbn, int bbn_ld, const h16* resid, GnEmit* e) {
+      const int Cn = Ca + Ca2;
       ctx->arena.push();
-      const int64_t Cp = align_up(cw.Cin, 128);
-      uint8_t* q = ctx->arena.get<uint8_t>(P * Cp);
-      uint8_t* qs = ctx->arena.get<uint8_t>(P * (Cp / 32));
-      quant_act_mx(ctx, in, cw.Cin, q, qs, P, s);
-      conv3x3_fp8(ctx, q, qs, cw, o, N, H, W, bbn, bbn_ld, res, s, e);
+      if (conv3x3_fp8_ok(cw, N, H, W)) {
+        const int64_t Cp = align_up(Cn, 128);
+        uint8_t* q = ctx->arena.get<uint8_t>(P * Cp);
+        uint8_t* qs = ctx->arena.get<uint8_t>(P * (Cp / 32));
+        if (!groupnorm_mx(ctx, a, Ca, a2, Ca2, nw.g, nw.b, q, qs, N, HW, m->groups, 1e-5f, 1, s, s1, s2)) {
+          h16* t = ctx->arena.get<h16>(P * Cn);
+          groupnorm(ctx, a, Ca, a2, Ca2, nw.g, nw.b, t, N, HW, m->groups, 1e-5f, 1, s, s1, s2);
+          quant_act_mx(ctx, t, Cn, q, qs, P, s);
+        }
+        conv3x3_fp8(ctx, q, qs, cw, o, N, H, W, bbn, bbn_ld, resid, s, e);
+      } else {
+        h16* t = ctx->arena.get<h16>(P * Cn);
+        groupnorm(ctx, a, Ca, a2, Ca2, nw.g, nw.b, t, N, HW, m->groups, 1e-5f, 1, s, s1, s2);
+        conv3x3(ctx, t, cw, o, N, H, W, A_CONV_S1, bbn, bbn_ld, resid, 0, s, e);
+      }
       ctx->arena.pop();
-      return true;
     };
-    if (!conv_mx(t0, r.c1, t1, temb + r.temb_off, temb_ld, nullptr, &e1))
-      conv3x3(ctx, t0, r.c1, t1, N, H, W, A_CONV_S1, temb + r.temb_off, temb_ld, nullptr, 0, s, &e1);
-    h16* t2 = ctx->arena.get<h16>(P * r.n2.C);
-    groupnorm(ctx, t1, r.n2.C, nullptr, 0, r.n2.g, r.n2.b, t2, N, HW, m->groups, 1e-5f, 1, s, &e1.st, nullptr);
+    if (virt) norm_conv(x.p, Cx, skip->p, Cs, r.n1, &x.st, &skip->st, r.c1, t1, temb + r.temb_off, temb_ld, nullptr, &e1);
+    else norm_conv(xin, Cin, nullptr, 0, r.n1, skip ? nullptr : &x.st, nullptr, r.c1, t1, temb + r.temb_off, temb_ld, nullptr, &e1);
     const h16* res = xin;
     if (r.has_sc) {
       h16* sc = ctx->arena.get<h16>(P * r.sc.N);
@@ -338,8 +344,7 @@ struct UnetRun {
       else linear(ctx, xin, Cin, r.sc, sc, r.sc.N, (int)P, ACT_NONE, nullptr, 0, 0, s);
       res = sc;
     }
-    if (!conv_mx(t2, r.c2, outp, nullptr, 0, res, &eo))
-      conv3x3(ctx, t2, r.c2, outp, N, H, W, A_CONV_S1, nullptr, 0, res, 0, s, &eo);
+    norm_conv(t1, r.n2.C, nullptr, 0, r.n2, &e1.st, nullptr, r.c2, outp, nullptr, 0, res, &eo);
     ctx->arena.pop();
     out.p = outp;
     out.st = eo.st;
