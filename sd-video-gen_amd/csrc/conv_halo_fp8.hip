@@ -123,25 +123,30 @@ __global__ void __launch_bounds__(512, 2) conv_halo_fp8_kernel(const Fp8ConvArgs
     const bool ok = pp < PPIX8 && (unsigned)yy < (unsigned)OH && (unsigned)xx < (unsigned)OW;
     return ok ? (unsigned)(((b * OH + yy) * OW + xx) * Cp + c * 16) : INVALID;
   };
-  auto dma_patch_piece = [&](int cc, int buf, int i) {
+  // source offset of this lane's share of piece i (computed in a load segment: ~40 VALU instructions with an integer division that
+  // must not sit between the MFMAs of a matrix segment, where nothing else of this wave can cover them)
+  auto patch_piece_voff = [&](int i) -> unsigned {
+    if (i < NPD8) return patch_voff(i);
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int pp = wid * 64 + ln;                         // the scale piece: slot = patch pixel
+    const int py = pp / PW8, px = pp - py * PW8;
+    const int yy = y0 - 1 + py, xx = x0 - 1 + px;
+    const bool ok = pp < PPIX8 && (unsigned)yy < (unsigned)OH && (unsigned)xx < (unsigned)OW;
+    return ok ? (unsigned)(((b * OH + yy) * OW + xx) * SB) : INVALID;      // pixels outside the image read zeros (2^-127 beside zero data)
+  };
+  auto dma_patch_issue = [&](int cc, int buf, int i, unsigned voff) {
     if (i < NPD8 - 1) {
-      dma16(srdA, patch_voff(i), cc * 128, lds0 + buf * PBUF + wave_u * 1024 + i * 8192);
+      dma16(srdA, voff, cc * 128, lds0 + buf * PBUF + wave_u * 1024 + i * 8192);
     } else if (i == NPD8 - 1) {
       if (wave_u == 0) {
-        const unsigned voff = patch_voff(i);
         if (lane < 32) dma16(srdA, voff, cc * 128, lds0 + buf * PBUF + i * 8192);
       }
     } else if (wave_u < 6) {
-      // slot = patch pixel (wave * 64 + lane): the 4 scale bytes of chunk cc; pixels outside the image read zeros (2^-127 beside zero data)
-      int ln = lane;
-      asm volatile("" : "+v"(ln));
-      const int pp = wid * 64 + ln;
-      const int py = pp / PW8, px = pp - py * PW8;
-      const int yy = y0 - 1 + py, xx = x0 - 1 + px;
-      const bool ok = pp < PPIX8 && (unsigned)yy < (unsigned)OH && (unsigned)xx < (unsigned)OW;
-      dma4(srdAs, ok ? (unsigned)(((b * OH + yy) * OW + xx) * SB) : INVALID, cc * 4, lds0 + OFF_PS + buf * PS_BYTES + wave_u * 256);
+      dma4(srdAs, voff, cc * 4, lds0 + OFF_PS + buf * PS_BYTES + wave_u * 256);
     }
   };
+  auto dma_patch_piece = [&](int cc, int buf, int i) { dma_patch_issue(cc, buf, i, patch_piece_voff(i)); };
   // ---- weight slab (tap, chunk): rows r0 + 64 i, chunk swizzled on the source
   const int r0 = tid >> 3;
   const int cB = (tid & 7) ^ (r0 & 7);
@@ -266,6 +271,8 @@ __global__ void __launch_bounds__(512, 2) conv_halo_fp8_kernel(const Fp8ConvArgs
 #pragma unroll
           for (int i = 0; i < BIT; ++i) dma_w_main(wcc, wtap, wst, i);
         }
+        unsigned pvoff = INVALID;
+        if (pp) pvoff = patch_piece_voff(tap);
         STAMP(s1);
         wait_vm(more_w ? BIT : 0);                          // all but the BIT DMAs just issued (every wave issues exactly BIT here)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -281,7 +288,7 @@ __global__ void __launch_bounds__(512, 2) conv_halo_fp8_kernel(const Fp8ConvArgs
             acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv[j], xv[i], acc[i][j], 0, 0, 0, sw[j], 0, sx[i]);
           __builtin_amdgcn_sched_barrier(0);
           if (i == 0 && more_w) dma_w_tail(wcc, wtap, wst);
-          if (i == 1 && pp) dma_patch_piece(cc + 1, pbuf ^ 1, tap);
+          if (i == 1 && pp) dma_patch_issue(cc + 1, pbuf ^ 1, tap, pvoff);
           if (i == 2 && tap == 7 && hn) dma_w_scales(cc + 1, pbuf ^ 1);
           __builtin_amdgcn_sched_barrier(0);
         }

@@ -13,6 +13,7 @@
 // Per hidden chunk and wave: 80 + 40 MFMAs against 120 ds_read_b128 — LDS bandwidth and the matrix pipe saturate together.
 #include "igemm_epi.h"
 #include <cstdlib>
+#include <vector>
 
 namespace SDNS {
 
@@ -243,7 +244,15 @@ constexpr int P_OFF_S1 = P_RING * F_SLAB;
 constexpr int P_OFF_EX = P_OFF_S1 + 2 * 2 * FH * 4;
 constexpr int P_LDS = P_OFF_EX + 8 * 2 * 64 * 16;
 
-__global__ void __launch_bounds__(512, 2) ff_pair_kernel(const FfArgs a) {
+// In-kernel stamps (diagnostic build -DFF_STAMP; VERDICT r03 #1d): per wave, summed over the kernel, the cycles of ring wait (counted
+// vmcnt) / barrier / DMA issue / GEMM1 slab (fragment reads + 16 MFMAs) / GEGLU + swap write / GEMM2 slab — printed by the launcher.
+#ifdef FF_STAMP
+#define FSTAMP(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define FSTAMP(v) do { } while (0)
+#endif
+
+__global__ void __launch_bounds__(512, 2) ff_pair_kernel(const FfArgs a, unsigned long long* stamps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wid);
@@ -339,15 +348,23 @@ __global__ void __launch_bounds__(512, 2) ff_pair_kernel(const FfArgs a) {
   const char* const ex_other = smem + P_OFF_EX + (((wave_u ^ 1) * 2) * 64 + lane) * 16;
 
   int q = 0, slot = 0, slot_in = F_DEPTH;                  // slot of slab q; slot the next DMA goes to
+  unsigned long long t_wait = 0, t_bar = 0, t_dma = 0, t_g1 = 0, t_gelu = 0, t_g2 = 0, t_all0 = 0, t_all1 = 0, t_epi = 0;
   auto step_begin = [&]() {
+    unsigned long long u0 = 0, u1 = 0, u2 = 0, u3 = 0;
+    FSTAMP(u0);
     if (q + F_DEPTH - 1 < NQ) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else wait_vm((NQ - 1 - q) * 2);
+    FSTAMP(u1);
     bar();
+    FSTAMP(u2);
     if (q + F_DEPTH < NQ) dma_slab(q + F_DEPTH, slot_in);
+    FSTAMP(u3);
+    t_wait += u1 - u0; t_bar += u2 - u1; t_dma += u3 - u2;
     slot_in = slot_in + 1 == P_RING ? 0 : slot_in + 1;
   };
   auto step_end = [&]() { ++q; slot = slot + 1 == P_RING ? 0 : slot + 1; };
 
+  FSTAMP(t_all0);
   for (int c = 0; c < F_NCH; ++c) {
     // ---- GEMM1: 32 rows x 64 packed columns (h g h g of this half), K = 320 in 5 slabs
     f32x4 acc1[2][4];
@@ -358,6 +375,8 @@ __global__ void __launch_bounds__(512, 2) ff_pair_kernel(const FfArgs a) {
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
       step_begin();
+      unsigned long long v0 = 0, v1 = 0;
+      FSTAMP(v0);
       const char* sl = smem + slot * F_SLAB;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -369,8 +388,18 @@ __global__ void __launch_bounds__(512, 2) ff_pair_kernel(const FfArgs a) {
 #pragma unroll
           for (int rt = 0; rt < 2; ++rt) acc1[rt][t] = MFMA_16x16x32(wf[t], xf[rt][s * 2 + kk], acc1[rt][t]);
       }
+#ifdef FF_STAMP
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(acc1[rt][t]));
+#endif
+      FSTAMP(v1);
+      t_g1 += v1 - v0;
       step_end();
     }
+    unsigned long long w0 = 0, w1 = 0;
+    FSTAMP(w0);
     // ---- folded LayerNorm + bias, GEGLU on this half's 32 hidden units: the B operand of GEMM2's k-step `half`
     h16x8 pown[2];
 #pragma unroll
@@ -389,11 +418,15 @@ __global__ void __launch_bounds__(512, 2) ff_pair_kernel(const FfArgs a) {
       *(h16x8*)(ex_own + rt * 1024) = pown[rt];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the swap writes have landed before the barrier of the next step
+    FSTAMP(w1);
+    t_gelu += w1 - w0;
     // ---- GEMM2: acc2[160 columns of this half] += P (32 x 64) W2p[:, chunk]^T, 3 slabs of 64 + 64 W2 rows
     h16x8 pf[2][2];
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
       step_begin();
+      unsigned long long v0 = 0, v1 = 0;
+      FSTAMP(v0);
       if (s == 0) {
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
@@ -414,9 +447,18 @@ __global__ void __launch_bounds__(512, 2) ff_pair_kernel(const FfArgs a) {
           }
         }
       }
+#ifdef FF_STAMP
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) if (s * 4 + t < 10) asm volatile("" : "+v"(acc2[rt][s * 4 + t]));
+#endif
+      FSTAMP(v1);
+      t_g2 += v1 - v0;
       step_end();
     }
   }
+  FSTAMP(t_all1);
 
   // ---- epilogue: + b2 + residual, h16 store (4 consecutive columns per lane)
 #pragma unroll
@@ -434,6 +476,13 @@ __global__ void __launch_bounds__(512, 2) ff_pair_kernel(const FfArgs a) {
       *(h16x4*)(a.out + (int64_t)m * a.ldo + n) = to_h16x4(v);
     }
   }
+#ifdef FF_STAMP
+  FSTAMP(t_epi);
+  if (stamps && lane == 0) {
+    unsigned long long* o = stamps + ((size_t)blockIdx.x * 8 + wid) * 8;
+    o[0] = t_wait; o[1] = t_bar; o[2] = t_dma; o[3] = t_g1; o[4] = t_gelu; o[5] = t_g2; o[6] = t_all1 - t_all0; o[7] = t_epi - t_all1;
+  }
+#endif
 }
 
 // W2p[n][32 b + 8 lq + j] = W2[n][32 b + 16 (j >> 2) + 4 lq + (j & 3)]: the k order in which the GEGLU registers of a lane line up
@@ -474,9 +523,29 @@ void ff_fused(svg_ctx* ctx, const h16* X, int ldx, const h16* W1, const float* b
                2.0 * ((double)M * FC * 3 + 3.0 * FC * FH), tag);
   FfArgs a{X, ldx, W1, b1, s1, rs, rm, W2p, b2, residual, ldr, out, ldo, M};
   // SVG_FF_PAIR: 1 (default) the paired 32-row form, 0 the 16-rows-per-wave form
-  if (svg_env_i64("SVG_FF_PAIR", 1) != 0) hipLaunchKernelGGL(ff_pair_kernel, dim3(cdiv(M, 128)), dim3(512), P_LDS, s, a);
+  unsigned long long* stamps = nullptr;
+#ifdef FF_STAMP
+  const size_t n_st = (size_t)cdiv(M, 128) * 64;
+  HIP_OK(hipMalloc(&stamps, n_st * sizeof(unsigned long long)));
+  HIP_OK(hipMemsetAsync(stamps, 0, n_st * sizeof(unsigned long long), s));
+#endif
+  if (svg_env_i64("SVG_FF_PAIR", 1) != 0) hipLaunchKernelGGL(ff_pair_kernel, dim3(cdiv(M, 128)), dim3(512), P_LDS, s, a, stamps);
   else hipLaunchKernelGGL(ff_fused_kernel, dim3(cdiv(M, 128)), dim3(512), F_LDS, s, a);
   check_launch("ff_fused");
+#ifdef FF_STAMP
+  {
+    HIP_OK(hipStreamSynchronize(s));
+    std::vector<unsigned long long> h(n_st);
+    HIP_OK(hipMemcpy(h.data(), stamps, n_st * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_OK(hipFree(stamps));
+    double sum[8] = {0};
+    for (size_t w = 0; w < n_st / 8; ++w) for (int k = 0; k < 8; ++k) sum[k] += (double)h[w * 8 + k];
+    const double nw = (double)(n_st / 8);
+    fprintf(stderr, "[ff stamps] M %d: per wave (cycles, 160 slab steps): ring wait %.0f | barrier %.0f | DMA issue %.0f | GEMM1 slabs (100 x: 8 reads + 16 MFMA) %.0f | "
+            "LN-fold + GEGLU + swap write (20 x) %.0f | GEMM2 slabs (60 x: reads + up to 16 MFMA) %.0f || main loop %.0f, epilogue %.0f; matrix time of the loop = 2400 MFMA x 16 = 38400\n",
+            M, sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw, sum[5] / nw, sum[6] / nw, sum[7] / nw);
+  }
+#endif
 }
 
 }  // namespace SDNS
