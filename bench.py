@@ -536,7 +536,7 @@ def main():
     # what actually ran, read back from the library (the requested string is not evidence)
     ran_dtype = sd_utils.ctx.model_dtype(_lib.SVG_UNET) if denoise else "f32"
     if denoise and fp8:
-        ran_dtype = "fp8 (MX e4m3: 3x3 convs + qualifying projections) + " + ran_dtype
+        ran_dtype = "fp8 (MX e4m3: the resnets' 3x3 convs) + " + ran_dtype
     line = {"metric": metric, "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
