@@ -230,10 +230,11 @@ int svg_op_conv3x3_gn(svg_ctx* ctx, const uint16_t* x, const float* w_oihw, cons
  * are quantised on the device (e4m3 + one E8M0 scale per 32 input channels), the products run on v_mfma_scale_f32_16x16x128_f8f6f4
  * with f32 accumulation; out (B,H,W,Cout) 16-bit = conv + bias (+ residual).  q_out ((B*H*W, Cp) bytes, Cp = Cin rounded up to 128)
  * and s_out ((B*H*W, Cp/32) bytes) optionally receive the quantised activations.  Cin % 64 == 0, Cout % 4 == 0 and >= 128,
- * H % 16 == W % 16 == 0, at least 192 (16 x 16 pixel block, channel tile) pairs.  Replaces F.conv2d of the resnets' convs under
+ * H % 16 == W % 16 == 0 (of the output), at least 192 (16 x 16 pixel block, channel tile) pairs.  mode 0: stride 1 pad 1; mode 3: nearest-2x
+ * upsample fused in front (out (B,2H,2W,Cout)), the UNet's Upsample2D.  Replaces F.conv2d of the resnets' convs under
  * the fp8 = 1 model key (reference call sites: the conv1 / conv2 of diffusers' ResnetBlock2D behind utils/sd_utils.py:253). */
 int svg_op_conv3x3_mx(svg_ctx* ctx, const uint16_t* x, const float* w_oihw, const float* bias, const uint16_t* residual,
-                      uint16_t* out, uint8_t* q_out, uint8_t* s_out, int B, int H, int W, int Cin, int Cout, void* stream);
+                      uint16_t* out, uint8_t* q_out, uint8_t* s_out, int B, int H, int W, int Cin, int Cout, int mode, void* stream);
 /* C[M,N] = [A | A2] * W[N,K]^T + bias with the A operand given as two tensors (A: M x k_split, A2: M x (K - k_split)): the
  * torch.cat([hidden, skip], dim=1) in front of a resnet's 1x1 shortcut, never materialised.  k_split % 64 == 0. */
 /* C[batch*M,N] = A W^T + bias + residual, and the LayerNorm statistics of its rows (rs = rstd, rm = rstd * mean, eps 1e-5) as the
@@ -299,7 +300,7 @@ int svg_op_xattn_fused_f16(svg_ctx* ctx, const uint16_t* x, const uint16_t* a, c
                            const float* ln_gamma, const float* ln_beta, const float* wq, const uint16_t* k, const uint16_t* vt, int Lp,
                            const float* wo, const float* bo, uint16_t* out, int M, int rows_per_sample, int L, void* stream);
 int svg_op_conv3x3_mx_f16(svg_ctx* ctx, const uint16_t* x, const float* w_oihw, const float* bias, const uint16_t* residual,
-                          uint16_t* out, uint8_t* q_out, uint8_t* s_out, int B, int H, int W, int Cin, int Cout, void* stream);
+                          uint16_t* out, uint8_t* q_out, uint8_t* s_out, int B, int H, int W, int Cin, int Cout, int mode, void* stream);
 int svg_op_quant_mx_f16(svg_ctx* ctx, const uint16_t* x, uint8_t* q, uint8_t* scales, int64_t rows, int K, void* stream);
 int svg_op_gemm_fp8_f16(svg_ctx* ctx, const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* residual, void* C,
                         int M, int N, int K, int act, int out_f32, void* stream);

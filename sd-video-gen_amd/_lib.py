@@ -68,7 +68,7 @@ SIGNATURES = {
     "svg_op_ff_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "svg_op_xattn_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "svg_op_dropout_mask": [_vp, C.c_uint64, _i, _f, _vp, _i64, _vp],
-    "svg_op_conv3x3_mx": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "svg_op_conv3x3_mx": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "svg_op_quant_mx": [_vp, _vp, _vp, _vp, _i64, _i, _vp],
     "svg_op_gemm_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "svg_op_groupnorm": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],

@@ -456,7 +456,9 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
         if (n < g.N) *(f32x4*)(g.slabs + ((int64_t)ks * g.M + mr + i * OW) * g.N + n) = acc[i][j];
       }
   } else {
-    epi_tile<MT, NT, false, true>(g, 0, mr, OW, nc, acc, smem, 4, wm, wn, tile_m, n0);      // 16-bit output, no GEGLU: the wide form
+    // 16-bit output, no GEGLU: the wide epilogue — at BN = 128 only: at BN = 160 (NT = 5, the kernel sits at 254 VGPRs) it spills 38
+    // registers and measured 0.193 against 0.190 ms (28 x 64 x 64 x 320 -> 320, profiles/r04_kbench_conv_fp8_vs_fp16.txt)
+    epi_tile<MT, NT, false, (NT % 2 == 0)>(g, 0, mr, OW, nc, acc, smem, 4, wm, wn, tile_m, n0);
   }
 }
 

@@ -75,7 +75,10 @@ __global__ void __launch_bounds__(512, 2) conv_halo_fp8_kernel(const Fp8ConvArgs
   const int l15 = lane & 15, lq = lane >> 4;
 
   const int tiles_n = (g.N + BN - 1) / BN;
-  const int OH = g.H, OW = g.W;
+  // nearest-2x upsample fused in front (A_CONV_UP2, the UNet upsamplers): the conv runs over the OH x OW upsampled image, patch pixel (yy, xx)
+  // of it is source pixel (yy >> 1, xx >> 1) — only the DMA source offsets (data and scales) change, as in conv_halo.hip
+  const bool up2 = g.amode == A_CONV_UP2;
+  const int OH = up2 ? g.Ho : g.H, OW = up2 ? g.Wo : g.W;
   const int bx_n = OW >> 4, by_n = OH >> 4;
   int tile;
   {
@@ -98,8 +101,8 @@ __global__ void __launch_bounds__(512, 2) conv_halo_fp8_kernel(const Fp8ConvArgs
 
   const int Cp = a.Cp, CC = Cp >> 7, SB = Cp >> 5;          // chunks of 128 channels; scale bytes per pixel
   const int nimg = g.M / (OH * OW);
-  const unsigned a_bytes = (unsigned)((int64_t)nimg * OH * OW * Cp);
-  const unsigned as_bytes = (unsigned)((int64_t)nimg * OH * OW * SB);
+  const unsigned a_bytes = (unsigned)((int64_t)nimg * g.H * g.W * Cp);
+  const unsigned as_bytes = (unsigned)((int64_t)nimg * g.H * g.W * SB);
   const unsigned w_bytes = (unsigned)((int64_t)a.Npad * 9 * Cp);
   const unsigned ws_bytes = (unsigned)((int64_t)9 * CC * a.Npad * 4);
   auto mk = [](const void* p, unsigned bytes) -> v4i {
@@ -121,7 +124,8 @@ __global__ void __launch_bounds__(512, 2) conv_halo_fp8_kernel(const Fp8ConvArgs
     const int py = pp / PW8, px = pp - py * PW8;
     const int yy = y0 - 1 + py, xx = x0 - 1 + px;
     const bool ok = pp < PPIX8 && (unsigned)yy < (unsigned)OH && (unsigned)xx < (unsigned)OW;
-    return ok ? (unsigned)(((b * OH + yy) * OW + xx) * Cp + c * 16) : INVALID;
+    const int sy = up2 ? yy >> 1 : yy, sx = up2 ? xx >> 1 : xx;
+    return ok ? (unsigned)(((b * g.H + sy) * g.W + sx) * Cp + c * 16) : INVALID;
   };
   // source offset of this lane's share of piece i (computed in a load segment: ~40 VALU instructions with an integer division that
   // must not sit between the MFMAs of a matrix segment, where nothing else of this wave can cover them)
@@ -133,7 +137,8 @@ __global__ void __launch_bounds__(512, 2) conv_halo_fp8_kernel(const Fp8ConvArgs
     const int py = pp / PW8, px = pp - py * PW8;
     const int yy = y0 - 1 + py, xx = x0 - 1 + px;
     const bool ok = pp < PPIX8 && (unsigned)yy < (unsigned)OH && (unsigned)xx < (unsigned)OW;
-    return ok ? (unsigned)(((b * OH + yy) * OW + xx) * SB) : INVALID;      // pixels outside the image read zeros (2^-127 beside zero data)
+    const int sy = up2 ? yy >> 1 : yy, sx = up2 ? xx >> 1 : xx;
+    return ok ? (unsigned)(((b * g.H + sy) * g.W + sx) * SB) : INVALID;      // pixels outside the image read zeros (2^-127 beside zero data)
   };
   auto dma_patch_issue = [&](int cc, int buf, int i, unsigned voff) {
     if (i < NPD8 - 1) {
@@ -418,6 +423,7 @@ int conv_halo_fp8_bn(int64_t M, int N) {
 }
 
 // stride-1 3x3 convs on images whose sides are multiples of 16 with at least one workgroup per most CUs (as conv_halo_supported)
+// H, W: the OUTPUT image (2x the input under the fused nearest upsample)
 bool conv_halo_fp8_supported(int B, int H, int W, int Cin, int N) {
   static const int min_wg = getenv("SVG_HALO_MIN") ? atoi(getenv("SVG_HALO_MIN")) : 192;
   if (Cin % 64 != 0 || H % 16 != 0 || W % 16 != 0 || N < 128 || N % 4 != 0) return false;
@@ -452,8 +458,9 @@ void pack_conv3x3_mx(const float* w_oihw, uint8_t* q, uint8_t* sc, int O, int I,
 
 // g: the GemmArgs conv3x3() builds for the fp16 conv (M, N, H, W, Ho, Wo, Cin, epilogue); operands in MX fp8
 void conv_halo_fp8(svg_ctx* ctx, const uint8_t* A8, const uint8_t* As, const uint8_t* W8, const uint8_t* Ws, int Npad, const GemmArgs& g0, hipStream_t s) {
-  const int B = g0.M / (g0.H * g0.W);
-  SVG_CHECK(g0.amode == A_CONV_S1 && g0.Ho == g0.H && g0.Wo == g0.W && conv_halo_fp8_supported(B, g0.H, g0.W, g0.Cin, g0.N) && !g0.out_f32 &&
+  const int B = g0.M / (g0.Ho * g0.Wo);
+  const bool s1 = g0.amode == A_CONV_S1 && g0.Ho == g0.H && g0.Wo == g0.W, up = g0.amode == A_CONV_UP2 && g0.Ho == 2 * g0.H && g0.Wo == 2 * g0.W;
+  SVG_CHECK((s1 || up) && conv_halo_fp8_supported(B, g0.Ho, g0.Wo, g0.Cin, g0.N) && !g0.out_f32 &&
             g0.act == ACT_NONE && !g0.ln_rs, "conv_halo_fp8: %dx%d Cin %d N %d unsupported", g0.H, g0.W, g0.Cin, g0.N);
   if (!SVG_LAUNCHING(ctx)) return;
   Fp8ConvArgs a;
@@ -469,7 +476,7 @@ void conv_halo_fp8(svg_ctx* ctx, const uint8_t* A8, const uint8_t* As, const uin
   // weight-heavy (small images, weights larger than the activations): keep one channel tile's weights in an XCD's L2 (as gemm_auto)
   a.g.tn_major = ((int64_t)g0.N * 9 > (int64_t)g0.M) ? 1 : 0;
   char tag[112];
-  snprintf(tag, sizeof(tag), "conv_fp8_B%d_%dx%d_Cin%d_Cout%d_res%d", B, g0.H, g0.W, g0.Cin, g0.N, g0.residual ? 1 : 0);
+  snprintf(tag, sizeof(tag), "conv_fp8%s_B%d_%dx%d_Cin%d_Cout%d_res%d", up ? "_up2" : "", B, g0.H, g0.W, g0.Cin, g0.N, g0.residual ? 1 : 0);
   ProfScope ps(ctx, PK_CONV3, s, 2.0 * g0.M * (double)g0.N * 9.0 * g0.Cin,
                (double)g0.M * a.Cp + (double)g0.N * 9 * a.Cp + 2.0 * g0.M * g0.N * (g0.residual ? 2 : 1), tag);
   const dim3 grid((unsigned)((g0.M / 256) * tiles_n));

@@ -348,7 +348,7 @@ __global__ void pack_geglu_kernel(const float* __restrict__ w, const float* __re
 template <int BN, int AMODE>
 void launch_inst(const GemmArgs& g, dim3 grid, hipStream_t s) {
   constexpr int smem = 2 * (BM * 128 + BN * 128);
-  if constexpr (AMODE == A_DENSE && BN >= 64) {
+  if constexpr (AMODE == A_DENSE && (BN == 64 || BN == 128)) {      // (BN = 160: 48 spilled registers in the wide form — not used there)
     if (g.act != ACT_GEGLU && !g.out_f32) { hipLaunchKernelGGL((igemm_kernel<BN, AMODE, true>), grid, dim3(256), smem, s, g); return; }
   }
   hipLaunchKernelGGL((igemm_kernel<BN, AMODE>), grid, dim3(256), smem, s, g);
@@ -372,7 +372,7 @@ void launch_bn(const GemmArgs& g, dim3 grid, hipStream_t s) {
 template <int BN, int AMODE>
 void attr_inst() {
   HIP_OK(hipFuncSetAttribute((const void*)igemm_kernel<BN, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM * 128 + BN * 128)));
-  if constexpr (AMODE == A_DENSE && BN >= 64)
+  if constexpr (AMODE == A_DENSE && (BN == 64 || BN == 128))
     HIP_OK(hipFuncSetAttribute((const void*)igemm_kernel<BN, AMODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM * 128 + BN * 128)));
 }
 template <int BN>

@@ -251,9 +251,10 @@ void conv3x3(svg_ctx* ctx, const h16* x, const ConvW& cw, void* out, int B, int 
              int bias_bn_ld, const h16* residual, int out_f32, hipStream_t s, GnEmit* emit = nullptr);
 // the same stride-1 conv on MX fp8 operands (conv_halo_fp8.hip): x8 / xs = the quantised input of quant_act_mx (or of the quantising
 // GroupNorm apply pass); the caller asks conv3x3_fp8_ok() first
-bool conv3x3_fp8_ok(const ConvW& cw, int B, int H, int W);
+// up2: nearest-2x upsample fused in front (the UNet's upsamplers): x8 is the H x W source, the output is 2H x 2W
+bool conv3x3_fp8_ok(const ConvW& cw, int B, int H, int W, bool up2 = false);
 void conv3x3_fp8(svg_ctx* ctx, const uint8_t* x8, const uint8_t* xs, const ConvW& cw, h16* out, int B, int H, int W, const float* bias_bn,
-                 int bias_bn_ld, const h16* residual, hipStream_t s, GnEmit* emit = nullptr);
+                 int bias_bn_ld, const h16* residual, hipStream_t s, GnEmit* emit = nullptr, bool up2 = false);
 // C[M,N] = act(A[M,K] W^T + b) [+ residual]
 // emit / rows_per_sample: GroupNorm column sums of the output (M = samples x rows_per_sample).  A2 / k_split: the A operand is the
 // channel concat [A | A2] of two tensors (columns >= k_split come from A2, row stride lda2) without materialising it.

@@ -83,11 +83,14 @@ int SVG_OP(svg_op_conv3x3)(svg_ctx* ctx, const uint16_t* x, const float* w_oihw,
 // conv3x3 (stride 1, pad 1) in MX fp8 (conv_halo_fp8.hip): x (B,H,W,Cin) h16 and the f32 OIHW weights are quantised on the device
 // (e4m3 + E8M0 per 32 channels), the conv runs on v_mfma_scale_f32_16x16x128_f8f6f4; out h16 (B,H,W,Cout) = conv + bias (+ residual).
 // q_out / s_out (optional): the quantised activations ((B*H*W, Cp) bytes, Cp = Cin rounded up to 128) and their scales, for the tests.
+// mode 3: nearest-2x upsample fused in front (out is (B,2H,2W,Cout)), as svg_op_conv3x3.
 int SVG_OP(svg_op_conv3x3_mx)(svg_ctx* ctx, const uint16_t* x, const float* w_oihw, const float* bias, const uint16_t* residual, uint16_t* out,
-                      uint8_t* q_out, uint8_t* s_out, int B, int H, int W, int Cin, int Cout, void* stream) {
+                      uint8_t* q_out, uint8_t* s_out, int B, int H, int W, int Cin, int Cout, int mode, void* stream) {
   API_BEGIN
   hipStream_t s = (hipStream_t)stream;
   SVG_CHECK(Cout % 4 == 0 && Cin % 64 == 0, "conv3x3_mx op: Cout %% 4 and Cin %% 64 must be 0");
+  SVG_CHECK(mode == 0 || mode == 3, "conv3x3_mx op: mode 0 (stride 1) or 3 (nearest-2x upsample in front)");
+  const bool up2 = mode == 3;
   run_planned(ctx, [&]() {
     ConvW cw;
     cw.Cin = Cin; cw.Cout = Cout; cw.Opad = Cout; cw.Cp = (int)align_up(Cin, 128);
@@ -105,7 +108,7 @@ int SVG_OP(svg_op_conv3x3_mx)(svg_ctx* ctx, const uint16_t* x, const float* w_oi
       pack_conv3x3_mx(wdev, cw.w8, cw.w8s, Cout, Cin, Cout, cw.Cp, s);
     }
     quant_act_mx(ctx, (const h16*)x, Cin, q, qs, P, s);
-    conv3x3_fp8(ctx, q, qs, cw, (h16*)out, B, H, W, nullptr, 0, (const h16*)residual, s);
+    conv3x3_fp8(ctx, q, qs, cw, (h16*)out, B, H, W, nullptr, 0, (const h16*)residual, s, nullptr, up2);
     if (SVG_LAUNCHING(ctx)) {
       if (q_out) HIP_OK(hipMemcpyAsync(q_out, q, (size_t)P * cw.Cp, hipMemcpyDeviceToDevice, s));
       if (s_out) HIP_OK(hipMemcpyAsync(s_out, qs, (size_t)P * (cw.Cp / 32), hipMemcpyDeviceToDevice, s));

@@ -96,15 +96,16 @@ static void plan_gn_emit(GemmArgs& g, GnEmit* emit, int rows_per_sample) {
   emit->st.tiles_per_sample = rows_per_sample / rows;
 }
 
-bool conv3x3_fp8_ok(const ConvW& cw, int B, int H, int W) {
-  return cw.w8 != nullptr && conv_halo_fp8_supported(B, H, W, cw.Cin, cw.Opad);
+bool conv3x3_fp8_ok(const ConvW& cw, int B, int H, int W, bool up2) {
+  return cw.w8 != nullptr && conv_halo_fp8_supported(B, up2 ? 2 * H : H, up2 ? 2 * W : W, cw.Cin, cw.Opad);
 }
 
 void conv3x3_fp8(svg_ctx* ctx, const uint8_t* x8, const uint8_t* xs, const ConvW& cw, h16* out, int B, int H, int W, const float* bias_bn,
-                 int bias_bn_ld, const h16* residual, hipStream_t s, GnEmit* emit) {
-  SVG_CHECK(conv3x3_fp8_ok(cw, B, H, W), "conv3x3_fp8: %d x %dx%d x %d -> %d does not qualify", B, H, W, cw.Cin, cw.Opad);
+                 int bias_bn_ld, const h16* residual, hipStream_t s, GnEmit* emit, bool up2) {
+  SVG_CHECK(conv3x3_fp8_ok(cw, B, H, W, up2), "conv3x3_fp8: %d x %dx%d x %d -> %d does not qualify", B, H, W, cw.Cin, cw.Opad);
   GemmArgs g;
-  g.H = H; g.W = W; g.Cin = cw.Cin; g.amode = A_CONV_S1; g.Ho = H; g.Wo = W;
+  g.H = H; g.W = W; g.Cin = cw.Cin; g.amode = up2 ? A_CONV_UP2 : A_CONV_S1; g.Ho = up2 ? 2 * H : H; g.Wo = up2 ? 2 * W : W;
+  H = g.Ho; W = g.Wo;                       // the output image from here on
   g.K = 9 * cw.Cin; g.M = B * H * W; g.N = cw.Opad; g.n_valid = cw.Opad;
   g.bias = cw.b;
   g.bias_bn = bias_bn; g.bias_bn_ld = bias_bn_ld; g.rows_per_batch = H * W;

@@ -225,7 +225,7 @@ void UnetModel::finalize(svg_ctx* ctx, int64_t* n_params) {
       if (attn[bi]) as.push_back(load_xf(ctx, ws, bp + ".attentions." + std::to_string(j), cin, ctx_dim, s));
     }
     up_res.push_back(rs); up_attn.push_back(as);
-    if (i < nb - 1) up_s.push_back(load_conv3x3(ctx, ws, bp + ".upsamplers.0.conv", cin, cin, s));
+    if (i < nb - 1) up_s.push_back(load_conv3x3(ctx, ws, bp + ".upsamplers.0.conv", cin, cin, s, fp8_conv));
   }
   if (fp8_proj) {
     // (round 2-3 placement, off by default since round 4: does not pay, profiles/r03_bench_line_fp8.json) the dense projections that qualify get an MX fp8 copy (attention out-projections, ff.net.2, proj_out,
@@ -627,6 +627,15 @@ void UnetModel::run(svg_ctx* ctx, const float* x, int N, int h, int w, const flo
     if (i < nb - 1) {
       h16* y = ctx->arena.get<h16>((int64_t)N * (2 * H) * (2 * W) * up_s[i].Opad);
       GnEmit e = r.emit_for((int64_t)4 * H * W, up_s[i].Opad);
+      if (conv3x3_fp8_ok(up_s[i], N, H, W, true)) {      // fp8=1: quantise the (small) source image, conv on the MX fp8 path
+        ctx->arena.push();
+        const int64_t Ps = (int64_t)N * H * W, Cp = align_up(up_s[i].Cin, 128);
+        uint8_t* q = ctx->arena.get<uint8_t>(Ps * Cp);
+        uint8_t* qs = ctx->arena.get<uint8_t>(Ps * (Cp / 32));
+        quant_act_mx(ctx, cur.p, up_s[i].Cin, q, qs, Ps, s);
+        conv3x3_fp8(ctx, q, qs, up_s[i], y, N, H, W, nullptr, 0, nullptr, s, &e, true);
+        ctx->arena.pop();
+      } else
       conv3x3(ctx, cur.p, up_s[i], y, N, H, W, A_CONV_UP2, nullptr, 0, nullptr, 0, s, &e);
       cur.p = y; cur.st = e.st; H *= 2; W *= 2;
     }

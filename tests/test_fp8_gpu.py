@@ -93,17 +93,18 @@ def test_gemm_fp8(ctx, M, N, K, act):
     assert rel_l2(outb.float(), out) < 4e-3
 
 
-def _conv_mx(ctx, x, w, b, r, f16=False):
+def _conv_mx(ctx, x, w, b, r, f16=False, mode=0):
     """x (B,H,W,Cin) 16-bit NHWC, w (Cout,Cin,3,3) f32, optional bias / residual -> out (B,H,W,Cout) 16-bit, quantised activations + scales"""
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
     Cp = (Cin + 127) // 128 * 128
-    out = torch.empty(B, H, W, Cout, device="cuda", dtype=x.dtype)
+    up = 2 if mode == 3 else 1
+    out = torch.empty(B, up * H, up * W, Cout, device="cuda", dtype=x.dtype)
     q = torch.empty(B * H * W, Cp, device="cuda", dtype=torch.uint8)
     sc = torch.empty(B * H * W, Cp // 32, device="cuda", dtype=torch.uint8)
     fn = ctx.lib.svg_op_conv3x3_mx_f16 if f16 else ctx.lib.svg_op_conv3x3_mx
     ctx.check(fn(ctx.h, x.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None, r.data_ptr() if r is not None else None,
-                 out.data_ptr(), q.data_ptr(), sc.data_ptr(), B, H, W, Cin, Cout, stream()), "conv3x3_mx")
+                 out.data_ptr(), q.data_ptr(), sc.data_ptr(), B, H, W, Cin, Cout, mode, stream()), "conv3x3_mx")
     return out, q, sc
 
 
@@ -130,6 +131,22 @@ def test_conv3x3_mx_integer_exact(ctx, B, H, W, Cin, Cout):
         assert float(ref.abs().max()) < 2 ** 24
         want = ref.float().to(dt)                              # the only rounding: the 16-bit store
         assert torch.equal(out, want), (dt, float((out.double() - want.double()).abs().max()))
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(28, 8, 8, 1280, 1280), (12, 16, 16, 640, 640), (6, 32, 32, 192, 320)])
+def test_conv3x3_mx_upsample_integer_exact(ctx, B, H, W, Cin, Cout):
+    """the fused nearest-2x upsample in front of the MX fp8 conv (the UNet's upsamplers under fp8=1): exact on integer data against
+    F.conv2d(F.interpolate(x, scale_factor=2))."""
+    g = torch.Generator(device="cuda").manual_seed(B + H + Cin)
+    x = torch.randint(-8, 9, (B, H, W, Cin), device="cuda", generator=g).float()
+    x[..., 32:64] *= 0.5
+    w = torch.randint(-8, 9, (Cout, Cin, 3, 3), device="cuda", generator=g).float() * (torch.rand(Cout, Cin, 3, 3, device="cuda", generator=g) < 0.06).float()
+    bias = torch.randint(-16, 17, (Cout,), device="cuda", generator=g).float()
+    out, _, _ = _conv_mx(ctx, x.to(torch.float16), w, bias, None, True, mode=3)
+    xu = torch.nn.functional.interpolate(x.permute(0, 3, 1, 2).double(), scale_factor=2.0, mode="nearest")
+    ref = torch.nn.functional.conv2d(xu, w.double(), bias.double(), padding=1).permute(0, 2, 3, 1)
+    assert out.shape == ref.shape and float(ref.abs().max()) < 2 ** 15
+    assert torch.equal(out, ref.float().to(torch.float16))
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(6, 64, 64, 320, 320), (12, 32, 32, 1280, 640)])

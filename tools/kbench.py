@@ -66,7 +66,7 @@ def main():
             out = torch.empty(B, H, H, Cout, device="cuda", dtype=f16)
             for r in (None, res):
                 ms8, fl, _ = timeit(ctx, "conv3x3", lambda: ctx.check(ctx.lib.svg_op_conv3x3_mx_f16(
-                    ctx.h, x.data_ptr(), w.data_ptr(), None, r.data_ptr() if r is not None else None, out.data_ptr(), None, None, B, H, H, Cin, Cout, stream()), "convmx"))
+                    ctx.h, x.data_ptr(), w.data_ptr(), None, r.data_ptr() if r is not None else None, out.data_ptr(), None, None, B, H, H, Cin, Cout, 0, stream()), "convmx"))
                 ms16 = float("nan")
                 if r is None:
                     ms16, _, _ = timeit(ctx, "conv3x3", lambda: ctx.check(ctx.lib.svg_op_conv3x3_f16(

@@ -25,9 +25,10 @@ FAMILIES = [("conv3x3", ("conv_halo_kernel", "igemm_kernel<", "conv_")), ("gemm"
 
 def family(name):
     if "igemm_kernel<" in name:
-        # template args <BN, AMODE>: AMODE 0 = dense
+        # template args <BN, AMODE[, WIDE]>: AMODE 0 = dense
         args = name.split("igemm_kernel<", 1)[1].split(">", 1)[0].split(",")
-        return "gemm" if args[-1].strip().startswith("0") or "A_DENSE" in args[-1] else "conv3x3"
+        amode = args[1].strip() if len(args) > 1 else "0"
+        return "gemm" if amode.startswith("0") or "A_DENSE" in amode else "conv3x3"
     for fam, pats in FAMILIES:
         if any(p in name for p in pats):
             return fam
