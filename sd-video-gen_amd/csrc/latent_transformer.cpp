@@ -1,6 +1,7 @@
 // Latent-sequence Transformer graph (reference: models/transformer.py:47-68 over torch.nn.Transformer
 // defaults — post-norm, ReLU, final encoder/decoder LayerNorm, sequence-first).  f32 throughout.
 #include "models.h"
+#include "xf_walk.h"
 #include "../../include/svg_hip.h"
 
 void XfModel::configure(const char* kv) {
@@ -72,6 +73,28 @@ void XfModel::finalize(svg_ctx* ctx, int64_t* n_params) {
   for (auto& kv : ws.map)
     if (kv.first != "positional_encoder.pos_encoding") n += kv.second.numel;
   if (n_params) *n_params = n;
+  auto P = [&](const std::string& name) { return (const float*)ws.get(name).f32; };
+  auto layer = [&](const std::string& p, bool dec) {
+    LayerW w{};
+    w.in_w = P(p + "self_attn.in_proj_weight"); w.in_b = P(p + "self_attn.in_proj_bias");
+    w.out_w = P(p + "self_attn.out_proj.weight"); w.out_b = P(p + "self_attn.out_proj.bias");
+    if (dec) {
+      w.cin_w = P(p + "multihead_attn.in_proj_weight"); w.cin_b = P(p + "multihead_attn.in_proj_bias");
+      w.cout_w = P(p + "multihead_attn.out_proj.weight"); w.cout_b = P(p + "multihead_attn.out_proj.bias");
+    }
+    w.l1_w = P(p + "linear1.weight"); w.l1_b = P(p + "linear1.bias"); w.l2_w = P(p + "linear2.weight"); w.l2_b = P(p + "linear2.bias");
+    for (int i = 0; i < (dec ? 3 : 2); ++i) {
+      w.n_w[i] = P(p + "norm" + std::to_string(i + 1) + ".weight"); w.n_b[i] = P(p + "norm" + std::to_string(i + 1) + ".bias");
+    }
+    return w;
+  };
+  enc_w.clear(); dec_w.clear();
+  for (int i = 0; i < enc_layers; ++i) enc_w.push_back(layer("transformer.encoder.layers." + std::to_string(i) + ".", false));
+  for (int i = 0; i < dec_layers; ++i) dec_w.push_back(layer("transformer.decoder.layers." + std::to_string(i) + ".", true));
+  emb_w = P(std::string(emb_name) + ".weight"); emb_b = P(std::string(emb_name) + ".bias");
+  out_w = P("out.weight"); out_b = P("out.bias");
+  encn_w = P("transformer.encoder.norm.weight"); encn_b = P("transformer.encoder.norm.bias");
+  decn_w = P("transformer.decoder.norm.weight"); decn_b = P("transformer.decoder.norm.bias");
   ready = true;
 }
 
@@ -159,6 +182,138 @@ static void xf_forward_chunk(svg_ctx* ctx, XfModel* m, const float* src, const f
   xf_gemm(ctx, xt, r.W("out.weight"), r.W("out.bias"), out_tb, Mt, m->d_lat, m->d_model, 0, s);
 }
 
+// ---- the same chunk as ONE launch (xf_walk.hip): the stage table --------------------------------------------------------------------
+// Stages per encoder layer: GEMM in_proj | add slabs + bias | attention | GEMM out_proj | add slabs + bias + residual + LayerNorm |
+// GEMM linear1 | add slabs + bias, ReLU | GEMM linear2 | add + LayerNorm.  A decoder layer has the cross-attention block in between; its
+// K / V projection of the encoder memory shares the stage of the self-attention in_proj (no barrier of its own).  The final encoder /
+// decoder LayerNorm rides on the last layer's add + LayerNorm stage (Y2).
+static bool xf_walk_usable(const XfModel* m, int B, int Ts, int Tt) {
+  if (svg_env_i64("SVG_XF_WALK", 1) == 0) return false;
+  const int d = m->d_model, d_img = d - m->text_dim, hd = d / m->heads;
+  const int rows = B * std::max(Ts, Tt);
+  if (!(xf_walk_gemm_ok(d, d) && xf_walk_gemm_ok(m->ffn, d) && xf_walk_gemm_ok(d, m->ffn) && xf_walk_gemm_ok(d_img, m->d_lat) &&
+        xf_walk_gemm_ok(m->d_lat, d)))
+    return false;
+  if (d > 3072 || hd % 4 || m->text_dim % 4) return false;
+  return xf_walk_available(rows, xf_walk_lds_bytes(rows, std::max(Ts, Tt), std::max(Ts, Tt), hd));
+}
+
+static void xf_forward_walk(svg_ctx* ctx, XfModel* m, const float* src, const float* tgt, int B, int Ts, int Tt, const float* mask,
+                            const int32_t* pe_row, float* out_tb, hipStream_t s, const float* text, const float* src_pad,
+                            const float* tgt_pad) {
+  const int d = m->d_model, d_img = d - m->text_dim, ffn = m->ffn, d_lat = m->d_lat, heads = m->heads, hd = d / heads;
+  const int Ms = Ts * B, Mt = Tt * B, Mx = std::max(Ms, Mt);
+  const bool same = (tgt == src && Ts == Tt);
+  auto slabs = [&](int M, int N, int K) { return (int64_t)(K / 128) * M * N; };
+  int64_t sa = std::max(slabs(Mx, 3 * d, d), std::max(slabs(Mx, ffn, d), slabs(Mx, d, ffn)));
+  sa = std::max(sa, std::max(slabs(Mx, d_img, d_lat), slabs(Mx, d_lat, d)));
+  const int64_t sb = std::max(slabs(Ms, 2 * d, d), slabs(Mt, d_img, d_lat));
+  float* slabA = ctx->arena.get<float>(sa);
+  float* slabB = ctx->arena.get<float>(sb);
+  // row buffers with fixed roles (a stage never writes a buffer another workgroup still reads in the same stage): the embeddings; the
+  // encoder's norm1 / norm2 results; the memory; the decoder's norm1 / norm2 / norm3 results
+  float* xs_e = ctx->arena.get<float>((int64_t)Ms * d);
+  float* xt_e = same ? xs_e : ctx->arena.get<float>((int64_t)Mt * d);
+  float* e1 = ctx->arena.get<float>((int64_t)Ms * d);
+  float* e2 = ctx->arena.get<float>((int64_t)Ms * d);
+  float* mem = ctx->arena.get<float>((int64_t)Ms * d);
+  float* t1 = ctx->arena.get<float>((int64_t)Mt * d);
+  float* t2 = ctx->arena.get<float>((int64_t)Mt * d);
+  float* t3 = ctx->arena.get<float>((int64_t)Mt * d);
+  float* o = ctx->arena.get<float>((int64_t)Mx * d);
+  float* h = ctx->arena.get<float>((int64_t)Mx * ffn);
+  float* qkv = ctx->arena.get<float>((int64_t)Mx * 3 * d);     // reduced self-attention projections; the cross-attention's q
+  float* kvm = ctx->arena.get<float>((int64_t)Ms * 2 * d);     // reduced K, V of the encoder memory
+  if (!SVG_LAUNCHING(ctx)) return;
+
+  std::vector<WalkOp> ops;
+  ops.reserve(160);
+  auto gemm = [&](const float* X, int ld, const float* W, float* slab, int M, int N, int K, bool bar = true) {
+    WalkOp op{};
+    op.kind = WK_GEMM; op.bar = bar; op.M = M; op.N = N; op.K = K; op.ld = ld; op.ksplit = K / 128; op.X = X; op.W = W; op.slab = slab;
+    ops.push_back(op);
+  };
+  auto red = [&](const float* slab, int M, int N, int K, const float* bias, float* Y, bool relu, bool bar = true) {
+    WalkOp op{};
+    op.kind = WK_RED; op.bar = bar; op.M = M; op.N = N; op.ksplit = K / 128; op.slab = (float*)slab; op.bias = bias; op.Y = Y; op.relu = relu;
+    ops.push_back(op);
+  };
+  // y = LN(x + (slabs + bias)) g + b [; y2 = LN(y) g2 + b2]
+  auto ln = [&](const float* slab, int M, int K, const float* bias, const float* res, const float* g, const float* b, float* Y,
+                const float* g2 = nullptr, const float* b2 = nullptr, float* Y2 = nullptr) {
+    WalkOp op{};
+    op.kind = WK_LN; op.bar = 1; op.M = M; op.N = d; op.ksplit = slab ? K / 128 : 0; op.slab = (float*)slab; op.bias = bias; op.res = res;
+    op.g1 = g; op.b1 = b; op.Y = Y; op.g2 = g2; op.b2 = b2; op.Y2 = Y2; op.eps = 1e-5f;
+    ops.push_back(op);
+  };
+  // q (Tq*B rows of q_ld floats, q_span floats to the end of its buffer), k / v (Tk*B rows of kv_ld floats)
+  auto attn = [&](const float* q, int q_ld, int64_t q_span, const float* k, const float* v, int kv_ld, int64_t kv_span, int Tq, int Tk, const float* msk,
+                  const float* kpad) {
+    WalkOp op{};
+    op.kind = WK_ATTN; op.bar = 1; op.Tq = Tq; op.Tk = Tk; op.B = B; op.heads = heads; op.hd = hd;
+    op.q_ld = q_ld; op.kv_ld = kv_ld; op.q_span = (int)q_span; op.kv_span = (int)kv_span;
+    op.qs = q; op.ks = k; op.vs = v; op.mask = msk; op.kpad = kpad; op.Y = o;
+    ops.push_back(op);
+  };
+  auto embed = [&](const float* slab, int T, float* Y, bool bar) {
+    WalkOp op{};
+    op.kind = WK_EMBED; op.bar = bar; op.M = B * T; op.N = d_img; op.ksplit = d_lat / 128; op.slab = (float*)slab; op.bias = m->emb_b; op.Y = Y;
+    op.pe = m->pe; op.pe_row = pe_row; op.text = text; op.d_txt = m->text_dim; op.T = T; op.B = B; op.scale = sqrtf((float)d);
+    ops.push_back(op);
+  };
+
+  // embeddings (the launch's inputs: no barrier before the first stage)
+  gemm(src, d_lat, m->emb_w, slabA, B * Ts, d_img, d_lat, false);
+  if (!same) gemm(tgt, d_lat, m->emb_w, slabB, B * Tt, d_img, d_lat, false);
+  embed(slabA, Ts, xs_e, true);
+  if (!same) embed(slabB, Tt, xt_e, false);
+  const float* xs_cur = xs_e;
+  for (int i = 0; i < m->enc_layers; ++i) {
+    const XfModel::LayerW& w = m->enc_w[i];
+    const bool last = (i + 1 == m->enc_layers);
+    gemm(xs_cur, d, w.in_w, slabA, Ms, 3 * d, d);
+    red(slabA, Ms, 3 * d, d, w.in_b, qkv, false);
+    attn(qkv, 3 * d, (int64_t)Ms * 3 * d, qkv + d, qkv + 2 * d, 3 * d, (int64_t)Ms * 3 * d - d, Ts, Ts, nullptr, src_pad);
+    gemm(o, d, w.out_w, slabA, Ms, d, d);
+    ln(slabA, Ms, d, w.out_b, xs_cur, w.n_w[0], w.n_b[0], e1);
+    gemm(e1, d, w.l1_w, slabA, Ms, ffn, d);
+    red(slabA, Ms, ffn, d, w.l1_b, h, true);
+    gemm(h, ffn, w.l2_w, slabA, Ms, d, ffn);
+    if (last) ln(slabA, Ms, ffn, w.l2_b, e1, w.n_w[1], w.n_b[1], nullptr, m->encn_w, m->encn_b, mem);   // + transformer.encoder.norm
+    else ln(slabA, Ms, ffn, w.l2_b, e1, w.n_w[1], w.n_b[1], e2);
+    xs_cur = e2;
+  }
+  if (m->enc_layers == 0) ln(nullptr, Ms, 0, nullptr, xs_cur, m->encn_w, m->encn_b, mem);
+  const float* xt_cur = xt_e;
+  for (int i = 0; i < m->dec_layers; ++i) {
+    const XfModel::LayerW& w = m->dec_w[i];
+    const bool last = (i + 1 == m->dec_layers);
+    gemm(xt_cur, d, w.in_w, slabA, Mt, 3 * d, d);
+    gemm(mem, d, w.cin_w + (int64_t)d * d, slabB, Ms, 2 * d, d, false);                            // K, V of the memory: rows d .. 3d of in_proj
+    red(slabA, Mt, 3 * d, d, w.in_b, qkv, false);
+    red(slabB, Ms, 2 * d, d, w.cin_b + d, kvm, false, false);
+    attn(qkv, 3 * d, (int64_t)Mt * 3 * d, qkv + d, qkv + 2 * d, 3 * d, (int64_t)Mt * 3 * d - d, Tt, Tt, mask, tgt_pad);
+    gemm(o, d, w.out_w, slabA, Mt, d, d);
+    ln(slabA, Mt, d, w.out_b, xt_cur, w.n_w[0], w.n_b[0], t1);
+    gemm(t1, d, w.cin_w, slabA, Mt, d, d);                                                          // q: rows 0 .. d of in_proj
+    red(slabA, Mt, d, d, w.cin_b, qkv, false);
+    attn(qkv, d, (int64_t)Mt * d, kvm, kvm + d, 2 * d, (int64_t)Ms * 2 * d, Tt, Ts, nullptr, nullptr);
+    gemm(o, d, w.cout_w, slabA, Mt, d, d);
+    ln(slabA, Mt, d, w.cout_b, t1, w.n_w[1], w.n_b[1], t2);
+    gemm(t2, d, w.l1_w, slabA, Mt, ffn, d);
+    red(slabA, Mt, ffn, d, w.l1_b, h, true);
+    gemm(h, ffn, w.l2_w, slabA, Mt, d, ffn);
+    if (last) ln(slabA, Mt, ffn, w.l2_b, t2, w.n_w[2], w.n_b[2], nullptr, m->decn_w, m->decn_b, t3);     // + transformer.decoder.norm
+    else ln(slabA, Mt, ffn, w.l2_b, t2, w.n_w[2], w.n_b[2], t3);
+    xt_cur = t3;
+  }
+  if (m->dec_layers == 0) { ln(nullptr, Mt, 0, nullptr, xt_cur, m->decn_w, m->decn_b, t3); xt_cur = t3; }
+  gemm(xt_cur, d, m->out_w, slabA, Mt, d_lat, d);
+  red(slabA, Mt, d_lat, d, m->out_b, out_tb, false);
+  ProfScope ps(ctx, PK_XF_GEMM, s, 0, 0, "walk");
+  xf_walk_launch(ctx, ops.data(), (int)ops.size(), Mx, xf_walk_lds_bytes(Mx, std::max(Ts, Tt), std::max(Ts, Tt), hd), s);
+}
+
 void XfModel::forward(svg_ctx* ctx, const float* src, const float* tgt, int B, int Ts, int Tt, const float* mask,
                       const int32_t* pe_row, float* out, hipStream_t s, const float* text, const float* src_pad, const float* tgt_pad) {
   SVG_CHECK(ready, "transformer: svg_finalize has not been called");
@@ -166,7 +321,15 @@ void XfModel::forward(svg_ctx* ctx, const float* src, const float* tgt, int B, i
   SVG_CHECK(B >= 1 && Ts >= 1 && Tt >= 1 && Ts <= 32 && Tt <= 32, "transformer: B=%d Ts=%d Tt=%d unsupported (sequences up to 32 tokens)", B, Ts, Tt);
   SVG_CHECK(pe_row || B <= 64, "transformer: batch %d > max_len 64 of the positional table", B);
   const int Tmax = std::max(Ts, Tt);
-  const int Bc = std::max(1, 336 / Tmax);       // xf_gemm streams W once for up to 336 rows (56 clips x 6 tokens)
+  // The layer-walking launch (xf_walk.hip) serves up to kWalkMaxRows rows; larger batches go through it in chunks (SVG_XF_WALK_SPLIT=0:
+  // through the per-GEMM kernels instead, which stream W once for up to 336 rows = 56 clips x 6 tokens).
+  const int Bw = std::max(1, (int)std::min<int64_t>(kWalkMaxRows, svg_env_i64("SVG_XF_WALK_ROWS", kWalkMaxRows)) / Tmax);
+  const bool walk = xf_walk_usable(this, std::min(B, Bw), Ts, Tt) && (B <= Bw || svg_env_i64("SVG_XF_WALK_SPLIT", 1) != 0);
+  const int Bc = walk ? Bw : std::max(1, 336 / Tmax);
+  auto chunk = [&](const float* srcc, const float* tgtc, int bc, const int32_t* rows, float* dst, const float* textc, const float* sp, const float* tp) {
+    if (walk) xf_forward_walk(ctx, this, srcc, tgtc, bc, Ts, Tt, mask, rows, dst, s, textc, sp, tp);
+    else xf_forward_chunk(ctx, this, srcc, tgtc, bc, Ts, Tt, mask, rows, dst, s, textc, sp, tp);
+  };
   run_planned(ctx, [&]() {
     // PE rows: the reference indexes the table by batch row (positional_encoding.py:33-35)
     const int32_t* rows = iota;
@@ -176,7 +339,7 @@ void XfModel::forward(svg_ctx* ctx, const float* src, const float* tgt, int B, i
       rows = r;
     }
     if (B <= Bc) {
-      xf_forward_chunk(ctx, this, src, tgt, B, Ts, Tt, mask, rows, out, s, text, src_pad, tgt_pad);
+      chunk(src, tgt, B, rows, out, text, src_pad, tgt_pad);
     } else {
       for (int b0 = 0; b0 < B; b0 += Bc) {
         const int bc = std::min(Bc, B - b0);
@@ -184,8 +347,8 @@ void XfModel::forward(svg_ctx* ctx, const float* src, const float* tgt, int B, i
         float* tmp = ctx->arena.get<float>((int64_t)Tt * bc * d_lat);
         const float* srcc = src + (int64_t)b0 * Ts * d_lat;
         const float* tgtc = (tgt == src) ? srcc : tgt + (int64_t)b0 * Tt * d_lat;
-        xf_forward_chunk(ctx, this, srcc, tgtc, bc, Ts, Tt, mask, rows + b0, tmp, s, text ? text + (int64_t)b0 * text_dim : nullptr,
-                         src_pad ? src_pad + (int64_t)b0 * Ts : nullptr, tgt_pad ? tgt_pad + (int64_t)b0 * Tt : nullptr);
+        chunk(srcc, tgtc, bc, rows + b0, tmp, text ? text + (int64_t)b0 * text_dim : nullptr, src_pad ? src_pad + (int64_t)b0 * Ts : nullptr,
+              tgt_pad ? tgt_pad + (int64_t)b0 * Tt : nullptr);
         if (SVG_LAUNCHING(ctx))
           HIP_OK(hipMemcpy2DAsync(out + (int64_t)b0 * d_lat, (size_t)B * d_lat * sizeof(float), tmp,
                                   (size_t)bc * d_lat * sizeof(float), (size_t)bc * d_lat * sizeof(float), Tt,

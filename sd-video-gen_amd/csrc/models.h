@@ -40,6 +40,16 @@ struct XfModel {
   int pe_d = 0;
   int32_t* iota = nullptr;
   struct XfTrain* train = nullptr;   // gradients + Adam moments (xf_trainer.cpp); dropped whenever weights are (re)loaded
+  // weight pointers by role, resolved once in finalize() (the layer-walking forward builds its stage table from them)
+  struct LayerW {
+    const float *in_w, *in_b, *out_w, *out_b;          // self-attention
+    const float *cin_w, *cin_b, *cout_w, *cout_b;      // decoder: attention over the encoder memory
+    const float *l1_w, *l1_b, *l2_w, *l2_b;
+    const float *n_w[3], *n_b[3];
+  };
+  std::vector<LayerW> enc_w, dec_w;
+  const float *emb_w = nullptr, *emb_b = nullptr, *out_w = nullptr, *out_b = nullptr, *encn_w = nullptr, *encn_b = nullptr, *decn_w = nullptr,
+              *decn_b = nullptr;
   void configure(const char* kv);
   void finalize(svg_ctx* ctx, int64_t* n_params);
   // src_pad (B,Ts) / tgt_pad (B,Tt): additive key-padding biases (models/transformer.py:64) or null

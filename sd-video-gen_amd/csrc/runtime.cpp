@@ -1,6 +1,7 @@
 // Context, workspace arena, weight store, profiler, C-ABI error plumbing.
 #include <mutex>
 #include "models.h"
+#include "xf_walk.h"
 #include "../../include/svg_hip.h"
 #include <algorithm>
 #include <sstream>
@@ -190,6 +191,7 @@ int svg_create(int device_id, svg_ctx** out) {
   sd_f16::sd_init_device();
   xf_train_init_device();
   xformer_init_device();
+  xf_walk_init_device();
   ctx = new svg_ctx();
   ctx->device = device_id;
   ctx->prof_entries.resize(PK_COUNT);

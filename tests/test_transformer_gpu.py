@@ -142,3 +142,80 @@ def test_text_conditioned_variant(ctx):
     assert rel_l2(p, TO.predict(sd, X[:1], 8, txt=txt[:1])) < TOL
     with pytest.raises((RuntimeError, ValueError)):
         m._ctx.transformer_forward(X.cuda(), X.cuda(), None, None)       # text model (in ITS context) called without a text embedding
+
+
+# ---- the layer-walking launch (csrc/xf_walk.hip): one kernel for the whole forward ------------------------------------------------------
+def _walk_model(d=256, heads=4, enc=2, dec=2, seed=11):
+    torch.manual_seed(seed)
+    return build("model_10_26", dict(dim_model=d, num_heads=heads, num_encoder_layers=enc, num_decoder_layers=dec))
+
+
+def _with_walk(on, fn):
+    from sd_video_gen_amd import _lib
+    old = os.environ.get("SVG_XF_WALK")
+    os.environ["SVG_XF_WALK"] = "1" if on else "0"
+    _lib.env_refresh()
+    try:
+        return fn()
+    finally:
+        if old is None:
+            os.environ.pop("SVG_XF_WALK", None)
+        else:
+            os.environ["SVG_XF_WALK"] = old
+        _lib.env_refresh()
+
+
+@pytest.mark.parametrize("B", [1, 3, 8, 11, 16, 28, 30, 60])
+def test_walk_matches_oracle_and_the_per_gemm_kernels(ctx, B):
+    """every accumulator height of the walk (1, 2, 3, 4, 6, 8, 11 tiles of 16 rows), one chunk (<= 176 rows) and several (B = 30, 60):
+    against the CPU oracle on sampled batch rows and against the per-GEMM HIP path on all of them; bit-identical from run to run"""
+    m = _walk_model()
+    sd = {k: v.clone().cpu() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(B)
+    X = torch.randn(B, 6, 256, generator=g)
+    pe0 = torch.zeros(B, dtype=torch.int32)
+    mask = m.get_tgt_mask(6).cuda()
+    run = lambda: m(X.cuda(), X.cuda(), mask, pe_row=pe0).cpu()
+    out = _with_walk(True, run)
+    again = _with_walk(True, run)
+    old = _with_walk(False, run)
+    assert torch.equal(out, again)
+    assert rel_l2(out, old) < 5e-6
+    for b in sorted({0, B // 2, B - 1}):
+        ref = TO.forward(sd, X[b:b + 1], X[b:b + 1], 4, TO.get_tgt_mask(6))
+        assert rel_l2(out[:, b:b + 1], ref) < TOL
+
+
+def test_walk_masks_lengths_and_pe_rows(ctx):
+    """Ts != Tt without a mask, key-padding masks, the reference's PE-row-by-batch-row quirk, zero encoder / decoder-only depth"""
+    m = _walk_model(enc=1, dec=2, seed=12)
+    sd = {k: v.clone().cpu() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    S, T = torch.randn(5, 5, 256, generator=g), torch.randn(5, 6, 256, generator=g)
+    out = _with_walk(True, lambda: m(S.cuda(), T.cuda(), None).cpu())
+    assert rel_l2(out, TO.forward(sd, S, T, 4, None)) < TOL
+    pad_s = torch.rand(5, 5, generator=g) > 0.6
+    pad_t = torch.rand(5, 6, generator=g) > 0.6
+    pad_s[:, 0] = False
+    pad_t[:, 0] = False
+    m6 = m.get_tgt_mask(6)
+    out = _with_walk(True, lambda: m(S.cuda(), T.cuda(), m6.cuda(), pad_s, pad_t).cpu())
+    assert rel_l2(out, TO.forward(sd, S, T, 4, TO.get_tgt_mask(6), src_pad_mask=pad_s, tgt_pad_mask=pad_t)) < TOL
+    old = _with_walk(False, lambda: m(S.cuda(), T.cuda(), m6.cuda(), pad_s, pad_t).cpu())
+    assert rel_l2(out, old) < 5e-6
+
+
+def test_walk_text_conditioned(ctx):
+    from sd_video_gen_amd import config as svg_config
+    from sd_video_gen_amd.transformer_text import Transformer as TextTransformer
+    svg_config.set_args(["--dataset", "ucf", "--config", "model_10_26"])
+    torch.manual_seed(4)
+    m = TextTransformer(dim_model=128, num_heads=8, num_encoder_layers=2, num_decoder_layers=2, st_weights="synthetic").eval()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    X = torch.randn(9, 6, 256)
+    names = ["WallPushups", "PlayingGuitar", "WallPushups"] * 3
+    txt = m.encode_classes(names).cpu()
+    run = lambda: m(X.cuda(), names, X.cuda(), m.get_tgt_mask(6).cuda()).cpu()
+    out = _with_walk(True, run)
+    assert rel_l2(out, TO.forward(sd, X, X, 8, TO.get_tgt_mask(6), txt=txt)) < TOL
+    assert rel_l2(out, _with_walk(False, run)) < 5e-6
