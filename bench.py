@@ -231,7 +231,10 @@ def roofline_pass(args, sd_utils, step, denoise, C, model=None):
         dom = rep["xf_gemm"]
         ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
         fwd_ms = rep["xf_gemm"]["ms"] + rep.get("xf_misc", {"ms": 0})["ms"]
-        out["roofline"] = {"bound": "hbm", "kernel": "xf_gemm_kernel<MT> (f32 weight stream of the latent Transformer, v_mfma_f32_16x16x4_f32)",
+        per_fwd = dom["calls"] <= 4        # the layer-walking launch: one kernel per forward (csrc/xf_walk.hip)
+        out["roofline"] = {"bound": "hbm", "kernel": ("xf_walk_kernel<MT> (the whole forward in one launch: f32 weight stream of the latent Transformer, "
+                                                      "v_mfma_f32_16x16x4_f32)") if per_fwd else
+                           "xf_gemm_kernel<MT> (f32 weight stream of the latent Transformer, v_mfma_f32_16x16x4_f32)",
                            "achieved": ach, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": ach / (PEAK_HBM / 1e9), "traffic": None,
                            "launches": dom["calls"], "avg_launch_ms": dom["ms"] / dom["calls"],
                            "algorithmic_bytes_per_launch": dom["bytes"] / dom["calls"],

@@ -188,7 +188,9 @@ static void xf_forward_chunk(svg_ctx* ctx, XfModel* m, const float* src, const f
 // K / V projection of the encoder memory shares the stage of the self-attention in_proj (no barrier of its own).  The final encoder /
 // decoder LayerNorm rides on the last layer's add + LayerNorm stage (Y2).
 static bool xf_walk_usable(const XfModel* m, int B, int Ts, int Tt) {
-  if (svg_env_i64("SVG_XF_WALK", 1) == 0) return false;
+  // one resident workgroup per compute unit: two processes sharing a device (the one-GPU rehearsal of the N > 1 path, SVG_DEVICE_OVERRIDE)
+  // would starve each other's launches of compute units at their barriers, so the per-GEMM kernels serve there unless asked otherwise
+  if (svg_env_i64("SVG_XF_WALK", getenv("SVG_DEVICE_OVERRIDE") ? 0 : 1) == 0) return false;
   const int d = m->d_model, d_img = d - m->text_dim, hd = d / m->heads;
   const int rows = B * std::max(Ts, Tt);
   if (!(xf_walk_gemm_ok(d, d) && xf_walk_gemm_ok(m->ffn, d) && xf_walk_gemm_ok(d, m->ffn) && xf_walk_gemm_ok(d_img, m->d_lat) &&
@@ -310,7 +312,13 @@ static void xf_forward_walk(svg_ctx* ctx, XfModel* m, const float* src, const fl
   if (m->dec_layers == 0) { ln(nullptr, Mt, 0, nullptr, xt_cur, m->decn_w, m->decn_b, t3); xt_cur = t3; }
   gemm(xt_cur, d, m->out_w, slabA, Mt, d_lat, d);
   red(slabA, Mt, d_lat, d, m->out_b, out_tb, false);
-  ProfScope ps(ctx, PK_XF_GEMM, s, 0, 0, "walk");
+  double flops = 0, bytes = 0;                        // the per-GEMM kernels' accounting: W once, X and the product once
+  for (const WalkOp& op : ops)
+    if (op.kind == WK_GEMM) {
+      flops += 2.0 * op.M * (double)op.N * op.K;
+      bytes += 4.0 * ((double)op.N * op.K + (double)op.M * op.K + (double)op.M * op.N);
+    }
+  ProfScope ps(ctx, PK_XF_GEMM, s, flops, bytes, "walk");
   xf_walk_launch(ctx, ops.data(), (int)ops.size(), Mx, xf_walk_lds_bytes(Mx, std::max(Ts, Tt), std::max(Ts, Tt), hd), s);
 }
 
@@ -321,10 +329,10 @@ void XfModel::forward(svg_ctx* ctx, const float* src, const float* tgt, int B, i
   SVG_CHECK(B >= 1 && Ts >= 1 && Tt >= 1 && Ts <= 32 && Tt <= 32, "transformer: B=%d Ts=%d Tt=%d unsupported (sequences up to 32 tokens)", B, Ts, Tt);
   SVG_CHECK(pe_row || B <= 64, "transformer: batch %d > max_len 64 of the positional table", B);
   const int Tmax = std::max(Ts, Tt);
-  // The layer-walking launch (xf_walk.hip) serves up to kWalkMaxRows rows; larger batches go through it in chunks (SVG_XF_WALK_SPLIT=0:
-  // through the per-GEMM kernels instead, which stream W once for up to 336 rows = 56 clips x 6 tokens).
+  // The layer-walking launch (xf_walk.hip) serves up to kWalkMaxRows rows; larger batches go through the per-GEMM kernels, which stream W once
+  // for up to 336 rows = 56 clips x 6 tokens (SVG_XF_WALK_SPLIT=1: through the walk in chunks).
   const int Bw = std::max(1, (int)std::min<int64_t>(kWalkMaxRows, svg_env_i64("SVG_XF_WALK_ROWS", kWalkMaxRows)) / Tmax);
-  const bool walk = xf_walk_usable(this, std::min(B, Bw), Ts, Tt) && (B <= Bw || svg_env_i64("SVG_XF_WALK_SPLIT", 1) != 0);
+  const bool walk = xf_walk_usable(this, std::min(B, Bw), Ts, Tt) && (B <= Bw || svg_env_i64("SVG_XF_WALK_SPLIT", 0) != 0);
   const int Bc = walk ? Bw : std::max(1, 336 / Tmax);
   auto chunk = [&](const float* srcc, const float* tgtc, int bc, const int32_t* rows, float* dst, const float* textc, const float* sp, const float* tp) {
     if (walk) xf_forward_walk(ctx, this, srcc, tgtc, bc, Ts, Tt, mask, rows, dst, s, textc, sp, tp);

@@ -223,8 +223,11 @@ __global__ void __launch_bounds__(WK_THREADS) xf_walk_kernel(const WalkOp* __res
         // the next tile's weights (the current one again at the end of the table: the counted waits below count on 16 loads)
         jt += (int)nwg;
         settle();
-        if (js < n_ops) load_w(js, jt); else load_w(s, t);
-        asm volatile("" ::: "memory");
+        auto prefetch = [&]() {
+          if (js < n_ops) load_w(js, jt); else load_w(s, t);
+          asm volatile("" ::: "memory");
+        };
+        prefetch();      // (holding the request back until X has landed was tried: neutral within 2 %, profiles/README.md)
 
         f32x4 acc[2][MT];
 #pragma unroll

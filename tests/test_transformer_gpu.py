@@ -152,16 +152,19 @@ def _walk_model(d=256, heads=4, enc=2, dec=2, seed=11):
 
 def _with_walk(on, fn):
     from sd_video_gen_amd import _lib
-    old = os.environ.get("SVG_XF_WALK")
-    os.environ["SVG_XF_WALK"] = "1" if on else "0"
+    keys = ("SVG_XF_WALK", "SVG_XF_WALK_SPLIT")          # SPLIT: batches above 176 rows go through the walk in chunks as well
+    old = {k: os.environ.get(k) for k in keys}
+    for k in keys:
+        os.environ[k] = "1" if on else "0"
     _lib.env_refresh()
     try:
         return fn()
     finally:
-        if old is None:
-            os.environ.pop("SVG_XF_WALK", None)
-        else:
-            os.environ["SVG_XF_WALK"] = old
+        for k in keys:
+            if old[k] is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = old[k]
         _lib.env_refresh()
 
 
