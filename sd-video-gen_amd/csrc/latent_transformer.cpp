@@ -329,9 +329,12 @@ void XfModel::forward(svg_ctx* ctx, const float* src, const float* tgt, int B, i
   SVG_CHECK(B >= 1 && Ts >= 1 && Tt >= 1 && Ts <= 32 && Tt <= 32, "transformer: B=%d Ts=%d Tt=%d unsupported (sequences up to 32 tokens)", B, Ts, Tt);
   SVG_CHECK(pe_row || B <= 64, "transformer: batch %d > max_len 64 of the positional table", B);
   const int Tmax = std::max(Ts, Tt);
-  // The layer-walking launch (xf_walk.hip) serves up to kWalkMaxRows rows; larger batches go through the per-GEMM kernels, which stream W once
-  // for up to 336 rows = 56 clips x 6 tokens (SVG_XF_WALK_SPLIT=1: through the walk in chunks).
-  const int Bw = std::max(1, (int)std::min<int64_t>(kWalkMaxRows, svg_env_i64("SVG_XF_WALK_ROWS", kWalkMaxRows)) / Tmax);
+  // The layer-walking launch (xf_walk.hip) can serve up to kWalkMaxRows rows, and alone on the device it is ahead of the per-GEMM kernels at
+  // every size (28 % at 6-48 rows, 8 % at 168).  But it owns every compute unit while it runs: the sampling loop's two stream groups, whose
+  // 168-row forwards overlap on the per-GEMM path, serialise (4250 vs 4709 frames/s without denoising, profiles/README.md).  So by default
+  // it takes the latency-bound sizes only (SVG_XF_WALK_ROWS, default 96 rows = 16 clips x 6 tokens); larger batches go through the per-GEMM
+  // kernels, which stream W once for up to 336 rows (SVG_XF_WALK_SPLIT=1: through the walk in chunks).
+  const int Bw = std::max(1, (int)std::min<int64_t>(kWalkMaxRows, svg_env_i64("SVG_XF_WALK_ROWS", 96)) / Tmax);
   const bool walk = xf_walk_usable(this, std::min(B, Bw), Ts, Tt) && (B <= Bw || svg_env_i64("SVG_XF_WALK_SPLIT", 0) != 0);
   const int Bc = walk ? Bw : std::max(1, 336 / Tmax);
   auto chunk = [&](const float* srcc, const float* tgtc, int bc, const int32_t* rows, float* dst, const float* textc, const float* sp, const float* tp) {

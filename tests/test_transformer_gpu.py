@@ -152,10 +152,11 @@ def _walk_model(d=256, heads=4, enc=2, dec=2, seed=11):
 
 def _with_walk(on, fn):
     from sd_video_gen_amd import _lib
-    keys = ("SVG_XF_WALK", "SVG_XF_WALK_SPLIT")          # SPLIT: batches above 176 rows go through the walk in chunks as well
+    # ROWS: every accumulator height the kernel is built for (the default stops at 96 rows); SPLIT: larger batches in chunks
+    keys = {"SVG_XF_WALK": "1", "SVG_XF_WALK_SPLIT": "1", "SVG_XF_WALK_ROWS": "176"}
     old = {k: os.environ.get(k) for k in keys}
-    for k in keys:
-        os.environ[k] = "1" if on else "0"
+    for k, v in keys.items():
+        os.environ[k] = v if on else "0"
     _lib.env_refresh()
     try:
         return fn()

@@ -59,7 +59,7 @@ __device__ __forceinline__ bool bar_two(Bar* b, unsigned k, unsigned nwg) {
 // mode 0: barriers only (flat); 1: barriers only (two-level); 2/3: stream 64 KB per workgroup and stage into registers of waves 0..3, the
 // barriers by wave 4 (flat / two-level); 4: stream only (no barriers); 5/6: as 2/3 with the next stage's loads in flight across the barriers
 template <int F, int SLEEP>
-__global__ void __launch_bounds__(320) walk(Bar* b, const f32x4* __restrict__ W, size_t wvec, float* out, int stages, int mode, int bars_per_stage) {
+__global__ void __launch_bounds__(320) walk(Bar* b, const f32x4* __restrict__ W, size_t wvec, float* out, int stages, int mode, int bars_per_stage, int pattern) {
   const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
   const unsigned nwg = gridDim.x;
   unsigned k = 0;
@@ -72,9 +72,27 @@ __global__ void __launch_bounds__(320) walk(Bar* b, const f32x4* __restrict__ W,
   f32x4 w[16];
   auto load = [&](int s) {
     // 64 KB per workgroup and stage: 4 waves x 16 x (64 lanes x 16 B)
-    const size_t base = ((size_t)s * nwg + blockIdx.x) * 4096 + wid * 1024 + lane;
+    if (pattern == 0) {
+      const size_t base = ((size_t)s * nwg + blockIdx.x) * 4096 + wid * 1024 + lane;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) w[i] = W[(base + i * 64) % wvec];
+      for (int i = 0; i < 16; ++i) w[i] = W[(base + i * 64) % wvec];
+    } else {
+      // a 2048 x 2048 f32 matrix per stage (row = 8 KB = 512 vectors); tile t = blockIdx: 128 rows x 512 B; wave -> 32 rows; lane (l15, lq)
+      // loads 16 B at row l15 (+16), vector 4 * step + lq (+ 4 .. : the second half of the 128-byte line)
+      const int nblk = blockIdx.x >> 4, kz = blockIdx.x & 15, l15 = lane & 15, lq = lane >> 4;
+      const size_t mat = (size_t)s * (2048 * 512);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const size_t row = nblk * 128 + wid * 32 + u * 16 + l15;
+            const size_t vec = pattern == 1 ? (size_t)kz * 32 + st * 8 + h * 4 + lq        // the kernel's mapping: 64 B per row and instruction
+                                            : (size_t)kz * 32 + (st * 2 + h) * 4 + lq;
+            w[(u * 4 + st) * 2 + h] = W[(mat + row * 512 + vec) % wvec];
+          }
+    }
   };
   if (pre && wid < 4) load(0);
   for (int s = 0; s < stages; ++s) {
@@ -109,21 +127,23 @@ int main() {
   hipDeviceProp_t prop; OK(hipGetDeviceProperties(&prop, 0));
   const int nwg = prop.multiProcessorCount;
   printf("CUs %d\n", nwg);
-  for (int flav = 0; flav < 5; ++flav) {
+  for (int pattern = 0; pattern < 2; ++pattern)
+  for (int flav = (pattern ? 4 : 0); flav < 5; ++flav) {
     const char* names[5] = {"system fences, sleep", "agent fences, sleep", "no fences, sleep", "agent fences, spin", "no fences, spin"};
     for (int mode = 0; mode <= 6; ++mode) {
       for (int bps : {1, 2}) {
-        if (mode == 4 && (bps == 2 || flav > 0)) continue;
+        if (mode == 4 && (bps == 2 || (flav > 0 && !pattern))) continue;
+        if (pattern && mode < 2) continue;
         float best = 1e9f;
         for (int rep = 0; rep < 4; ++rep) {
           OK(hipMemset(bar, 0, sizeof(Bar)));
           OK(hipEventRecord(e0));
           switch (flav) {
-            case 0: hipLaunchKernelGGL((walk<0, 1>), dim3(nwg), dim3(320), 0, 0, bar, W, wbytes / 16, out, stages, mode, bps); break;
-            case 1: hipLaunchKernelGGL((walk<1, 1>), dim3(nwg), dim3(320), 0, 0, bar, W, wbytes / 16, out, stages, mode, bps); break;
-            case 2: hipLaunchKernelGGL((walk<2, 1>), dim3(nwg), dim3(320), 0, 0, bar, W, wbytes / 16, out, stages, mode, bps); break;
-            case 3: hipLaunchKernelGGL((walk<1, 0>), dim3(nwg), dim3(320), 0, 0, bar, W, wbytes / 16, out, stages, mode, bps); break;
-            default: hipLaunchKernelGGL((walk<2, 0>), dim3(nwg), dim3(320), 0, 0, bar, W, wbytes / 16, out, stages, mode, bps); break;
+            case 0: hipLaunchKernelGGL((walk<0, 1>), dim3(nwg), dim3(320), 0, 0, bar, W, wbytes / 16, out, stages, mode, bps, pattern); break;
+            case 1: hipLaunchKernelGGL((walk<1, 1>), dim3(nwg), dim3(320), 0, 0, bar, W, wbytes / 16, out, stages, mode, bps, pattern); break;
+            case 2: hipLaunchKernelGGL((walk<2, 1>), dim3(nwg), dim3(320), 0, 0, bar, W, wbytes / 16, out, stages, mode, bps, pattern); break;
+            case 3: hipLaunchKernelGGL((walk<1, 0>), dim3(nwg), dim3(320), 0, 0, bar, W, wbytes / 16, out, stages, mode, bps, pattern); break;
+            default: hipLaunchKernelGGL((walk<2, 0>), dim3(nwg), dim3(320), 0, 0, bar, W, wbytes / 16, out, stages, mode, bps, pattern); break;
           }
           OK(hipEventRecord(e1));
           OK(hipEventSynchronize(e1));
@@ -132,7 +152,7 @@ int main() {
         }
         Bar h; OK(hipMemcpy(&h, bar, sizeof(Bar), hipMemcpyDeviceToHost));
         const double us_stage = best * 1e3 / stages;
-        printf("[%-20s] mode %d bars/stage %d: %8.3f ms  %6.2f us/stage  abort %u", names[flav], mode, bps, best, us_stage, h.abort_);
+        printf("pattern %d [%-20s] mode %d bars/stage %d: %8.3f ms  %6.2f us/stage  abort %u", pattern, names[flav], mode, bps, best, us_stage, h.abort_);
         if (mode >= 2) printf("  stream %7.1f GB/s", (double)nwg * 65536 * stages / (best * 1e-3) / 1e9);
         else printf("  %6.2f us/barrier", us_stage / bps);
         printf("\n");
