@@ -41,8 +41,9 @@ static void load_res(int model, const std::string& p, int cin, int cout, int tem
   if (temb) load_lin(model, p + ".time_emb_proj", cout, temb);
 }
 
-static void transformer(int text_dim) {
-  const int d_lat = 64, dm = 32, d = dm + text_dim, ffn = 2048;
+// dm = 128, d_lat = 128, ffn = 256: shapes the layer-walking launch takes (csrc/xf_walk.hip: its stage table is built on the host)
+static void transformer(int text_dim, int dm = 32, int d_lat = 64, int ffn = 2048) {
+  const int d = dm + text_dim;
   char kv[256];
   snprintf(kv, sizeof(kv), "d_lat=%d;d_model=%d;heads=4;enc_layers=1;dec_layers=1;ffn=%d;text_dim=%d", d_lat, d, ffn, text_dim);
   OK(svg_model_configure(ctx, SVG_TRANSFORMER, kv));
@@ -69,7 +70,8 @@ static void transformer(int text_dim) {
   // training step: direct launches (null stream), then the captured-graph branch (any non-null stream token), then Adam
   svg_train_cfg tc;
   memset(&tc, 0, sizeof(tc));
-  tc.frames_to_predict = 2; tc.feat_h = 4; tc.feat_w = 4; tc.w_mse = 1.f; tc.w_gdl = 1.f; tc.gdl_alpha = 2.f; tc.w_contrastive = 0.1f; tc.temperature = 0.07f;
+  tc.frames_to_predict = 2; tc.feat_h = 4; tc.feat_w = d_lat / 16;      // d_lat = 4 channels x feat_h x feat_w
+  tc.w_mse = 1.f; tc.w_gdl = 1.f; tc.gdl_alpha = 2.f; tc.w_contrastive = 0.1f; tc.temperature = 0.07f;
   tc.dropout_p = 0.1f; tc.seed = 3;
   const int B = 4, Ts = 6, Tt = 5;
   auto src = buf((size_t)B * Ts * d_lat), tgt = buf((size_t)B * Tt * d_lat), txt = buf((size_t)B * 384);
@@ -243,6 +245,8 @@ int main() {
   EXPECT_ERR(svg_finalize(ctx, SVG_UNET, nullptr));                       // nothing loaded yet
   transformer(0);
   transformer(384);
+  transformer(0, 128, 128, 256);
+  transformer(384, 128, 128, 256);
   vae(0); vae(1);
   unet(0, 0); unet(1, 0); unet(0, 1);
   text_towers();
