@@ -112,7 +112,7 @@ __device__ __forceinline__ bool wk_barrier(WalkSync* sy, unsigned k, unsigned nw
   return true;
 }
 
-// In-kernel stamps (diagnostic build -DWK_STAMP, tools/build_variant.sh): workgroup 0, per stage, s_memtime (100 MHz) at stage entry, after
+// In-kernel stamps (diagnostic build -DWK_STAMP, tools/build_variant.sh): workgroup 0, per stage, s_memtime (it counts shader clocks here, ≈ 2.2 GHz) at stage entry, after
 // this workgroup's memory operations have drained, after the device-wide barrier, and at the end of the stage's work
 #ifdef WK_STAMP
 #define WSTAMP(slot) do { if (stamps && blockIdx.x == 0 && tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamps[s * 4 + (slot)] = t_; } } while (0)
@@ -503,7 +503,7 @@ void launch(int n_wg, int64_t lds, hipStream_t s, const WalkOp* ops, int n_ops, 
     std::vector<WalkOp> hop(n_ops);
     HIP_OK(hipMemcpy(hop.data(), ops, n_ops * sizeof(WalkOp), hipMemcpyDeviceToHost));
     if (FILE* f = fopen(path, "w")) {
-      fprintf(f, "# stage kind bar M N K | entry drained after_barrier end (s_memtime ticks of 10 ns, relative to stage 0 entry)\n");
+      fprintf(f, "# stage kind bar M N K | entry drained after_barrier end (s_memtime ticks, relative to stage 0 entry)\n");
       for (int i = 0; i < n_ops; ++i)
         fprintf(f, "%d %d %d %d %d %d | %llu %llu %llu %llu\n", i, hop[i].kind, hop[i].bar, hop[i].M, hop[i].N, hop[i].K, h[4 * i] - h[0],
                 h[4 * i + 1] ? h[4 * i + 1] - h[0] : 0ull, h[4 * i + 2] - h[0], h[4 * i + 3] - h[0]);
