@@ -179,7 +179,15 @@ __global__ void __launch_bounds__(WK_THREADS) xf_walk_kernel(const WalkOp* __res
         __hip_atomic_store(host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-mapped word: read without a copy
       }
       __syncthreads();
-      if (dead) return;
+      if (dead) {
+        // gave up: the host learns it at its next launch (host_abort); whoever reads THIS launch's result first must not mistake it for
+        // one — the final stage's output becomes NaN
+        const auto& last = ops[n_ops - 1];
+        const __amdgpu_buffer_rsrc_t rL = rsrc_of(last.Y, (unsigned)(last.M * last.N) * 4u);
+        const float qn = __builtin_nanf("");
+        for (int v = (int)blockIdx.x * WK_THREADS + tid; v < last.M * last.N / 4; v += (int)nwg * WK_THREADS) stc(rL, (unsigned)v * 16u, f32x4{qn, qn, qn, qn});
+        return;
+      }
     }
     WSTAMP(2);
     const int kind = op.kind;

@@ -223,3 +223,23 @@ def test_walk_text_conditioned(ctx):
     out = _with_walk(True, run)
     assert rel_l2(out, TO.forward(sd, X, X, 8, TO.get_tgt_mask(6), txt=txt)) < TOL
     assert rel_l2(out, _with_walk(False, run)) < 5e-6
+
+
+def test_walk_long_sequences_and_odd_head_dim(ctx):
+    """the text loop's shape family (prediction/predict_text.py conditions on 16 frames + SOS = 17 tokens): 289 score pairs per (row, head)
+    (several passes of the 16-pairs-per-pass score loop), head dim 80 (not a power of two), Ts != Tt with a causal mask"""
+    from sd_video_gen_amd import config as svg_config
+    from sd_video_gen_amd.transformer_text import Transformer as TextTransformer
+    svg_config.set_args(["--dataset", "ucf", "--config", "model_10_26"])
+    torch.manual_seed(9)
+    m = TextTransformer(dim_model=256, num_heads=8, num_encoder_layers=1, num_decoder_layers=2, st_weights="synthetic").eval()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(2)
+    S, T = torch.randn(3, 17, 256, generator=g), torch.randn(3, 16, 256, generator=g)
+    names = ["WallPushups", "PlayingGuitar", "Archery"]
+    txt = m.encode_classes(names).cpu()
+    run = lambda: m(S.cuda(), names, T.cuda(), m.get_tgt_mask(16).cuda()).cpu()
+    out = _with_walk(True, run)
+    assert out.shape == (16, 3, 256)
+    assert rel_l2(out, TO.forward(sd, S, T, 8, TO.get_tgt_mask(16), txt=txt)) < TOL
+    assert rel_l2(out, _with_walk(False, run)) < 5e-6
