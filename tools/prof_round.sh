@@ -28,5 +28,5 @@ echo "== the layer-walking launch of the latent Transformer alone: 48 rows (8 cl
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/wtrace -o walk -- python3 tools/xf_walk_check.py 2048 8 4 8 8 256 > $out/${tag}_walk_48rows.log 2>&1
 find $out/wtrace -name "*kernel_stats.csv" -exec cp {} $out/${tag}_walk_48rows_kernel_stats.csv \;
 rm -rf $out/wtrace
-for B in 1 2 4 8 14 20 28; do timeout -k 10 200 python3 tools/xf_walk_check.py 2048 8 4 8 $B 256 2>&1 | grep "rel-L2"; done > $out/${tag}_walk_vs_per_gemm.txt
+for B in 1 2 4 8 14 20 28; do SVG_XF_WALK_ROWS=176 timeout -k 10 200 python3 tools/xf_walk_check.py 2048 8 4 8 $B 256 2>&1 | grep "rel-L2"; done > $out/${tag}_walk_vs_per_gemm.txt
 ls -la $out
