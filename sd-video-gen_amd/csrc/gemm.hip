@@ -390,6 +390,9 @@ int pick_bn(const GemmArgs& g) {
   // per-CU serial work ~ ceil(blocks / 256) * BN (blocks beyond one per CU share the matrix pipe); ties go to the
   // width with fewer padded columns, then to the wider tile (the A panel is re-read once per column tile)
   const int64_t tm = (int64_t)cdiv(g.M, BM) * g.batch;
+  // the 8 x 8 level's convolutions (1792 rows, K = 11520 / 23040): 14 x 8 tiles of 160 columns x split-K 4 = 448 workgroups, two per CU in
+  // one wave of the grid: 0.067 / 0.115 ms against 0.073 / 0.121 for 128 columns x split-K 3 (profiles/r04_kbench_8x8_sweep.txt)
+  if (g.amode != A_DENSE && g.N % 160 == 0 && tm * (g.N / 160) < 192) return 160;
   int best = 128;
   int64_t best_cost = -1, best_pad = 0;
   for (int bn : {128, 160}) {
@@ -518,8 +521,13 @@ static int plan_splitk(const GemmArgs& g) {
   const int bn = pick_bn(g);
   const int64_t blocks = (int64_t)cdiv(g.M, BM) * cdiv(g.N, bn) * g.batch;
   const int KT = cdiv(g.K, BK);
+  {
+    const int force = (int)svg_env_i64("SVG_IGEMM_SK", 0);     // experiments: split-K of the tiled kernel for launches below 192 tiles
+    if (force > 0 && blocks < 192 && KT >= 8) return std::min(force, KT / 4);
+  }
   if (blocks < 192 && KT >= 8) {
-    const int sk = (int)std::min<int64_t>((384 + blocks - 1) / blocks, KT / 4);
+    const int tgt = g.amode != A_DENSE ? 448 : 384;
+    const int sk = (int)std::min<int64_t>((tgt + blocks - 1) / blocks, KT / 4);
     return std::max(1, std::min(sk, 16));
   }
   // about one workgroup (4 waves) per CU and a long K: a single wave per SIMD cannot hide its own load phases, so
