@@ -5,10 +5,11 @@ import collections, csv, glob, json, os, sys
 
 d, out = sys.argv[1], sys.argv[2]
 res = {}
-for name in ("ff", "gemmres", "attn", "conv", "gemm"):
+names = [a.replace(" ", "_") for a in sys.argv[3:]] or ["ff_114688", "gemmres_114688_320_320", "attn_28_4096_4096_40", "conv_28_64_320_320_0", "gemm_7168_1280_5120"]
+for name in names:
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(float)
-    for f in glob.glob(os.path.join(d, name + "_*", "**", "*counter_collection.csv"), recursive=True):
+    for f in glob.glob(os.path.join(d, name + "_[0-9]*", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0][-70:]
             per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
