@@ -243,3 +243,38 @@ def test_walk_long_sequences_and_odd_head_dim(ctx):
     assert out.shape == (16, 3, 256)
     assert rel_l2(out, TO.forward(sd, S, T, 8, TO.get_tgt_mask(16), txt=txt)) < TOL
     assert rel_l2(out, _with_walk(False, run)) < 5e-6
+
+
+def test_walk_from_two_threads_on_two_streams(ctx):
+    """the sampling loop runs its clip groups on worker threads with a stream each: layer-walking launches issued concurrently are
+    ordered on the device (an event chain inside the library) and every one of them reproduces the single-threaded result bit for bit"""
+    import threading
+    m = _walk_model(seed=13)
+    mask = m.get_tgt_mask(6).cuda()
+    Xs = [torch.randn(b, 6, 256, generator=torch.Generator().manual_seed(40 + b)).cuda() for b in (2, 8)]
+    pes = [torch.zeros(x.shape[0], dtype=torch.int32) for x in Xs]
+
+    def body():
+        want = [m(x, x, mask, pe_row=p).clone() for x, p in zip(Xs, pes)]
+        torch.cuda.synchronize()
+        bad = []
+
+        def worker(i):
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for it in range(150):
+                    out = m(Xs[i], Xs[i], mask, pe_row=pes[i])
+                    if it % 10 == 9:
+                        s.synchronize()
+                        if not torch.equal(out, want[i]):
+                            bad.append((i, it))
+                s.synchronize()
+
+        th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return bad
+
+    assert _with_walk(True, body) == []
