@@ -9,6 +9,10 @@ import torch
 import torch.distributed as dist
 
 
+# tests: run the collective even in a one-rank group (an RCCL all_gather of one rank's device tensor is still an RCCL call)
+_FORCE_COLLECTIVE = False
+
+
 def world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
@@ -30,7 +34,7 @@ def gather_clips(local, n_clips):
     """local: (c_local, ...) tensor of this rank's clips -> (n_clips, ...) on every rank, in clip order.
     One all_gather; ragged shards are padded to the largest shard and trimmed."""
     rank, ws = world()
-    if ws == 1:
+    if ws == 1 and not _FORCE_COLLECTIVE:
         return local
     sizes = [shard_range(n_clips, r, ws) for r in range(ws)]
     cmax = max(b - a for a, b in sizes)
@@ -50,7 +54,7 @@ def gather_clips_packed(tensors, n_clips):
     """Several per-clip tensors (same leading clip dimension, any dtypes) in ONE all_gather: each clip's payloads are
     viewed as bytes and laid side by side, gathered once, and split back (predict.main: latents f32 + frames u8)."""
     rank, ws = world()
-    if ws == 1:
+    if ws == 1 and not _FORCE_COLLECTIVE:
         return list(tensors)
     c = tensors[0].shape[0]
     widths = [int(torch.tensor(t.shape[1:]).prod()) * t.element_size() for t in tensors]

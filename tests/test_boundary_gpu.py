@@ -266,3 +266,34 @@ def test_bench_spawns_its_ranks():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_clips"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+
+
+def test_rccl_gathers_device_tensors_in_a_one_rank_group():
+    """The N > 1 path hands DEVICE tensors straight to `all_gather` under RCCL (sharding.gather_clips_packed: latents f32 + frames u8
+    packed as bytes).  A one-GPU box cannot host two RCCL ranks, but a one-rank "nccl" group still goes through RCCL's init
+    (`device_id=`), its uint8 all_gather and the packing / trimming code: run in a child process (a process group per pytest process
+    would outlive the test)."""
+    code = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from sd_video_gen_amd import sharding
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl"
+sharding._FORCE_COLLECTIVE = True
+g = torch.Generator().manual_seed(0)
+lat = torch.randn(3, 6, 256, generator=g).cuda()
+frames = torch.randint(0, 256, (3, 2, 16, 16, 3), generator=g, dtype=torch.uint8).cuda()
+a, b = sharding.gather_clips_packed([lat, frames], 3)
+assert a.is_cuda and b.is_cuda and torch.equal(a, lat) and torch.equal(b, frames)
+t = torch.ones(4, device="cuda")
+dist.all_reduce(t)
+assert float(t.sum()) == 4.0
+dist.barrier()
+dist.destroy_process_group()
+print("rccl one-rank ok")
+""" % ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl one-rank ok" in r.stdout, (r.stdout + r.stderr)[-2000:]
