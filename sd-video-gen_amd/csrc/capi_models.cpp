@@ -1,5 +1,6 @@
 // C ABI: model configure / load / finalize dispatch.
 #include "models.h"
+#include "xf_walk.h"
 #include "../../include/svg_hip.h"
 
 using namespace SDNS;   // ddim_step: storage-independent f32 kernel
@@ -94,6 +95,7 @@ int svg_vae_encode(svg_ctx* ctx, const uint8_t* img, int N, int srcH, int srcW, 
                    float* moments_out, void* stream) {
   try {
     SVG_CHECK(ctx && ctx->vae, "vae: model not configured");
+    xf_walk_check(ctx);                              // an earlier layer-walking forward that gave up surfaces at the next model call
     ctx->vae->encode(ctx, img, N, srcH, srcW, H, W, eps, z_out, moments_out, (hipStream_t)stream);
     return 0;
   } catch (const std::exception& e) { return svg_fail(ctx, e); }
@@ -102,6 +104,7 @@ int svg_vae_decode(svg_ctx* ctx, const float* z, int N, int h, int w, uint8_t* i
                    void* stream) {
   try {
     SVG_CHECK(ctx && ctx->vae, "vae: model not configured");
+    xf_walk_check(ctx);                              // an earlier layer-walking forward that gave up surfaces at the next model call
     ctx->vae->decode(ctx, z, N, h, w, img_out, outH, outW, float_out, (hipStream_t)stream);
     return 0;
   } catch (const std::exception& e) { return svg_fail(ctx, e); }
@@ -110,6 +113,7 @@ int svg_unet_forward(svg_ctx* ctx, const float* x, int N, int h, int w, const fl
                      float* eps_out, void* stream) {
   try {
     SVG_CHECK(ctx && ctx->unet, "unet: model not configured");
+    xf_walk_check(ctx);                              // an earlier layer-walking forward that gave up surfaces at the next model call
     ctx->unet->forward(ctx, x, N, h, w, timesteps, ctx_emb, ctx_len, eps_out, (hipStream_t)stream);
     return 0;
   } catch (const std::exception& e) { return svg_fail(ctx, e); }
@@ -118,6 +122,7 @@ int svg_ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const float* text
                   float guidance, const float* noise, float* hist, void* stream) {
   try {
     SVG_CHECK(ctx && ctx->unet, "unet: model not configured");
+    xf_walk_check(ctx);                              // an earlier layer-walking forward that gave up surfaces at the next model call
     ctx->unet->ddim_loop(ctx, z, N, h, w, text_emb, ctx_len, num_steps, start_step, guidance, noise, hist, (hipStream_t)stream);
     return 0;
   } catch (const std::exception& e) { return svg_fail(ctx, e); }

@@ -482,7 +482,7 @@ bool conv_halo_supported(const GemmArgs& g) {
   if (off || !(s1 || up) || g.Cin % 64 != 0 || g.Ho % 16 != 0 || g.Wo % 16 != 0 || g.batch != 1 || g.out_f32 ||
       g.act == ACT_GEGLU || g.N < 128)
     return false;
-  static const int min_wg = getenv("SVG_HALO_MIN") ? atoi(getenv("SVG_HALO_MIN")) : 192;
+  const int min_wg = (int)svg_env_i64("SVG_HALO_MIN", 192);      // (cached lookup; svg_env_refresh re-reads it: the parity tests force the kernel at batch 1-2)
   return (int64_t)(g.M / 256) * cdiv(g.N, conv_halo_bn(g)) >= min_wg;
 }
 

@@ -425,7 +425,7 @@ int conv_halo_fp8_bn(int64_t M, int N) {
 // stride-1 3x3 convs on images whose sides are multiples of 16 with at least one workgroup per most CUs (as conv_halo_supported)
 // H, W: the OUTPUT image (2x the input under the fused nearest upsample)
 bool conv_halo_fp8_supported(int B, int H, int W, int Cin, int N) {
-  static const int min_wg = getenv("SVG_HALO_MIN") ? atoi(getenv("SVG_HALO_MIN")) : 192;
+  const int min_wg = (int)svg_env_i64("SVG_HALO_MIN", 192);      // (cached lookup; svg_env_refresh re-reads it: the parity tests force the kernel at batch 1-2)
   if (Cin % 64 != 0 || H % 16 != 0 || W % 16 != 0 || N < 128 || N % 4 != 0) return false;
   const int64_t M = (int64_t)B * H * W;
   const int64_t Cp = align_up(Cin, 128);

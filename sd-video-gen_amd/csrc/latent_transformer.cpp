@@ -187,11 +187,14 @@ static void xf_forward_chunk(svg_ctx* ctx, XfModel* m, const float* src, const f
 // GEMM linear1 | add slabs + bias, ReLU | GEMM linear2 | add + LayerNorm.  A decoder layer has the cross-attention block in between; its
 // K / V projection of the encoder memory shares the stage of the self-attention in_proj (no barrier of its own).  The final encoder /
 // decoder LayerNorm rides on the last layer's add + LayerNorm stage (Y2).
-static bool xf_walk_usable(const XfModel* m, int B, int Ts, int Tt) {
-  // one resident workgroup per compute unit: two processes sharing a device (the one-GPU rehearsal of the N > 1 path, SVG_DEVICE_OVERRIDE)
-  // would starve each other's launches of compute units at their barriers, so the per-GEMM kernels serve there unless asked otherwise
-  if (svg_env_i64("SVG_XF_WALK", getenv("SVG_DEVICE_OVERRIDE") ? 0 : 1) == 0) return false;
+static bool xf_walk_usable(const XfModel* m, int B, int Ts, int Tt, hipStream_t s) {
+  // off for this device (SVG_XF_WALK=0, ranks sharing it, an earlier give-up, a grid the device cannot hold) or a stream under capture:
+  // residency and the knobs are facts established at svg_create (xf_walk.hip: xf_walk_init_device), not looked up per forward
+  if (!xf_walk_enabled(s)) return false;
   const int d = m->d_model, d_img = d - m->text_dim, hd = d / m->heads;
+  // the stage table: 3 (+2 for a separate target) embedding stages, 9 per encoder layer, 16 per decoder layer, 2 for the output projection,
+  // 1 each for an empty encoder / decoder stack
+  if (5 + 9 * m->enc_layers + 16 * m->dec_layers + 2 + 2 > kWalkMaxOps) return false;
   const int rows = B * std::max(Ts, Tt);
   if (!(xf_walk_gemm_ok(d, d) && xf_walk_gemm_ok(m->ffn, d) && xf_walk_gemm_ok(d, m->ffn) && xf_walk_gemm_ok(d_img, m->d_lat) &&
         xf_walk_gemm_ok(m->d_lat, d)))
@@ -335,7 +338,7 @@ void XfModel::forward(svg_ctx* ctx, const float* src, const float* tgt, int B, i
   // it takes the latency-bound sizes only (SVG_XF_WALK_ROWS, default 96 rows = 16 clips x 6 tokens); larger batches go through the per-GEMM
   // kernels, which stream W once for up to 336 rows (SVG_XF_WALK_SPLIT=1: through the walk in chunks).
   const int Bw = std::max(1, (int)std::min<int64_t>(kWalkMaxRows, svg_env_i64("SVG_XF_WALK_ROWS", 96)) / Tmax);
-  const bool walk = xf_walk_usable(this, std::min(B, Bw), Ts, Tt) && (B <= Bw || svg_env_i64("SVG_XF_WALK_SPLIT", 0) != 0);
+  const bool walk = xf_walk_usable(this, std::min(B, Bw), Ts, Tt, s) && (B <= Bw || svg_env_i64("SVG_XF_WALK_SPLIT", 0) != 0);
   const int Bc = walk ? Bw : std::max(1, 336 / Tmax);
   auto chunk = [&](const float* srcc, const float* tgtc, int bc, const int32_t* rows, float* dst, const float* textc, const float* sp, const float* tp) {
     if (walk) xf_forward_walk(ctx, this, srcc, tgtc, bc, Ts, Tt, mask, rows, dst, s, textc, sp, tp);
@@ -374,6 +377,7 @@ extern "C" int svg_transformer_forward_text(svg_ctx* ctx, const float* src, cons
                                             const float* mask, const int32_t* pe_row, float* out, void* stream) {
   try {
     SVG_CHECK(ctx && ctx->xf, "transformer: model not configured");
+    xf_walk_check(ctx);
     ctx->xf->forward(ctx, src, tgt, B, Ts, Tt, mask, pe_row, out, (hipStream_t)stream, text);
     return 0;
   } catch (const std::exception& e) { return svg_fail(ctx, e); }
@@ -384,6 +388,7 @@ extern "C" int svg_transformer_forward_padded(svg_ctx* ctx, const float* src, co
                                               void* stream) {
   try {
     SVG_CHECK(ctx && ctx->xf, "transformer: model not configured");
+    xf_walk_check(ctx);
     ctx->xf->forward(ctx, src, tgt, B, Ts, Tt, mask, pe_row, out, (hipStream_t)stream, text, src_pad, tgt_pad);
     return 0;
   } catch (const std::exception& e) { return svg_fail(ctx, e); }
@@ -393,6 +398,7 @@ extern "C" int svg_transformer_forward(svg_ctx* ctx, const float* src, const flo
                                        const int32_t* pe_row, float* out, void* stream) {
   try {
     SVG_CHECK(ctx && ctx->xf, "transformer: model not configured");
+    xf_walk_check(ctx);
     ctx->xf->forward(ctx, src, tgt, B, Ts, Tt, mask, pe_row, out, (hipStream_t)stream);
     return 0;
   } catch (const std::exception& e) { return svg_fail(ctx, e); }

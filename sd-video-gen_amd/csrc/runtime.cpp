@@ -169,8 +169,11 @@ int64_t svg_env_i64(const char* name, int64_t dflt) {
 extern "C" {
 
 void svg_env_refresh(void) {
-  std::lock_guard<std::mutex> lk(g_env_mu);
-  g_env.clear();
+  {
+    std::lock_guard<std::mutex> lk(g_env_mu);
+    g_env.clear();
+  }
+  xf_walk_env_refresh();
 }
 
 const char* svg_version(void) { return "svg_hip 0.3 (gfx950, bf16+fp16) src " SVG_SRC_HASH; }

@@ -35,6 +35,7 @@ struct alignas(16) WalkOp {
 
 // rows one launch serves (the accumulator tiles of a workgroup: 11 x 16) and the shapes a GEMM stage takes
 constexpr int kWalkMaxRows = 176;
+constexpr int kWalkMaxOps = 512;                      // stages of one launch (the pinned / device table ring is sized for it)
 inline bool xf_walk_gemm_ok(int N, int K) { return N % 128 == 0 && K % 128 == 0 && N >= 128 && K >= 128; }
 // dynamic LDS of a launch: the X tile of a GEMM stage (rows rounded to 16, 4 steps of 128 B) + a sink for padding DMAs, or the q/k/v
 // slices of one attention job
@@ -44,5 +45,10 @@ bool xf_walk_available(int rows, int64_t lds_bytes);
 // stream (two resident walks could starve each other of compute units while spinning at their barriers)
 void xf_walk_launch(svg_ctx* ctx, const WalkOp* ops, int n_ops, int rows, int64_t lds_bytes, hipStream_t s);
 void xf_walk_init_device();
-// raises when an earlier walk on this device gave up at a barrier (a workgroup never became resident)
+// false when the layer-walking launch must not be used now: off for this device ($SVG_XF_WALK=0, ranks sharing the device, an earlier
+// give-up, a device that cannot hold the grid) or the stream is being captured
+bool xf_walk_enabled(hipStream_t s);
+void xf_walk_env_refresh();                           // svg_env_refresh(): re-reads $SVG_XF_WALK* for every initialised device (re-arms the walk after a give-up)
+// When an earlier walk on this device gave up at a barrier (a workgroup never became resident): clears the flag, turns the walk off for
+// the device (later forwards take the per-GEMM kernels) and raises ONCE.  Called at the head of every model entry point of the C ABI.
 void xf_walk_check(svg_ctx* ctx);

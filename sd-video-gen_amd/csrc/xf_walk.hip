@@ -93,9 +93,9 @@ __device__ __forceinline__ void slab_sum2(__amdgpu_buffer_rsrc_t r, unsigned off
 
 // Device-wide barrier number k (1-based), called by ONE lane per workgroup after the workgroup's stores have completed.  Two levels:
 // the workgroups of group g = blockIdx & 7 (one XCD under round-robin dispatch) count on grp[g]; the last of a group counts on cnt; the
-// last overall releases every group.  Gives up (and tells everybody) after ~2 s: a workgroup that never became resident must not hang
-// the device.
-__device__ __forceinline__ bool wk_barrier(WalkSync* sy, unsigned k, unsigned nwg) {
+// last overall releases every group.  Gives up (and tells everybody) after `timeout` ticks of the 100 MHz steady counter (2 s by default,
+// wall clock, not iterations): a workgroup that never became resident must not hang the device.
+__device__ __forceinline__ bool wk_barrier(WalkSync* sy, unsigned k, unsigned nwg, unsigned long long timeout) {
   const unsigned g = blockIdx.x & 7, per = nwg >> 3;
   const unsigned a = __hip_atomic_fetch_add(&sy->grp[g][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (a == k * per - 1) {
@@ -104,10 +104,15 @@ __device__ __forceinline__ bool wk_barrier(WalkSync* sy, unsigned k, unsigned nw
       for (int i = 0; i < 8; ++i) __hip_atomic_store(&sy->rel[i][0], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   unsigned spins = 0;
+  unsigned long long t0 = 0;
   while (__hip_atomic_load(&sy->rel[g][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k) {
     __builtin_amdgcn_s_sleep(1);
-    if (++spins > (1u << 21)) { __hip_atomic_store(&sy->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
-    if ((spins & 255) == 0 && __hip_atomic_load(&sy->abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+    if ((++spins & 255) == 0) {                       // every 256 polls (~30 us): the clock and the give-up word of the others
+      const unsigned long long now = __builtin_readsteadycounter();
+      if (t0 == 0) t0 = now;
+      if (now - t0 > timeout) { __hip_atomic_store(&sy->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+      if (__hip_atomic_load(&sy->abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+    }
   }
   return true;
 }
@@ -123,7 +128,8 @@ __device__ __forceinline__ bool wk_barrier(WalkSync* sy, unsigned k, unsigned nw
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int MT>
-__global__ void __launch_bounds__(WK_THREADS) xf_walk_kernel(const WalkOp* __restrict__ ops_g, int n_ops, WalkSync* sy, unsigned* host_abort, unsigned long long* stamps) {
+__global__ void __launch_bounds__(WK_THREADS) xf_walk_kernel(const WalkOp* __restrict__ ops_g, int n_ops, WalkSync* sy, unsigned* host_abort, unsigned long long* stamps,
+                                                              unsigned expect_wg, unsigned long long timeout) {
   // the stage table is read-only for the whole launch: through the constant address space every (uniform) field read is a scalar load,
   // which neither waits on nor disturbs the vector-memory counter the pipeline below counts on
   typedef const __attribute__((address_space(4))) WalkOp* cops_t;
@@ -139,6 +145,8 @@ __global__ void __launch_bounds__(WK_THREADS) xf_walk_kernel(const WalkOp* __res
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
   const unsigned nwg = gridDim.x;
+  // workgroups the barrier counts: gridDim.x — except under the give-up test hook ($SVG_XF_WALK_TEST_GIVEUP), which asks for 8 more than exist
+  const unsigned bar_wg = expect_wg;
   unsigned bar_k = 0;
   if (tid == 0) dead = 0;
   __syncthreads();
@@ -174,7 +182,7 @@ __global__ void __launch_bounds__(WK_THREADS) xf_walk_kernel(const WalkOp* __res
       __builtin_amdgcn_s_barrier();
       WSTAMP(1);
       ++bar_k;
-      if (tid == 0 && !wk_barrier(sy, bar_k, nwg)) {
+      if (tid == 0 && !wk_barrier(sy, bar_k, bar_wg, timeout)) {
         dead = 1;
         __hip_atomic_store(host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-mapped word: read without a copy
       }
@@ -184,7 +192,7 @@ __global__ void __launch_bounds__(WK_THREADS) xf_walk_kernel(const WalkOp* __res
         // one — the final stage's output becomes NaN
         const auto& last = ops[n_ops - 1];
         const __amdgpu_buffer_rsrc_t rL = rsrc_of(last.Y, (unsigned)(last.M * last.N) * 4u);
-        const float qn = __builtin_nanf("");
+        const float qn = __builtin_bit_cast(float, 0x7FC00000u);   // the bit pattern (this file is built with -fno-honor-nans: no NaN literal)
         for (int v = (int)blockIdx.x * WK_THREADS + tid; v < last.M * last.N / 4; v += (int)nwg * WK_THREADS) stc(rL, (unsigned)v * 16u, f32x4{qn, qn, qn, qn});
         return;
       }
@@ -470,11 +478,16 @@ __global__ void __launch_bounds__(WK_THREADS) xf_walk_kernel(const WalkOp* __res
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------------
-constexpr int kRing = 4;
-constexpr int kMaxOps = 512;
+constexpr int kRing = 16;                              // table / barrier-word slots: a launch reuses the slot of the 16th launch before it
+constexpr int kMts[] = {1, 2, 3, 4, 6, 8, 11};        // the instantiated accumulator heights
 struct WalkDev {
   bool init = false;
-  int n_wg = 0;
+  bool disabled = false;             // set when a launch gave up at a barrier, or when ranks share the device: the per-GEMM kernels serve
+  bool coop_ok = false;              // the device reports hipDeviceAttributeCooperativeLaunch
+  bool coop = false;                 // launches go through hipLaunchCooperativeKernel (the runtime refuses a grid that cannot be co-resident)
+  bool test_giveup = false;
+  int n_wg = 0;                      // grid: min over the instantiations of (resident workgroups per compute unit at the launch's LDS) x compute units
+  unsigned long long timeout = 0;    // barrier give-up time in 100 MHz ticks
   WalkSync* sync[kRing] = {};
   WalkOp* dops[kRing] = {};
   WalkOp* hops[kRing] = {};          // pinned
@@ -483,26 +496,50 @@ struct WalkDev {
   bool used[kRing] = {};
   int next = 0;
   int last = -1;                     // slot of the previous launch (its `done` event orders the next one)
-  int cap_ops = 0;
 };
 std::mutex g_mu;
 WalkDev g_dev[16];
 constexpr int64_t kMaxLds = 150 * 1024;
+constexpr int64_t kMinLds = 84 * 1024;                // above half a compute unit's LDS: exactly one workgroup per compute unit
+
+// The knobs, looked up once per device at svg_create (and again at svg_env_refresh), never on the forward path:
+//   SVG_XF_WALK          0 = per-GEMM kernels only.  Default 1 — except when ranks share the device (the one-GPU rehearsal of the N > 1 path sets
+//                        SVG_DEVICE_OVERRIDE): their resident grids would starve each other of compute units
+//   SVG_XF_WALK_COOP     1 = launch through hipLaunchCooperativeKernel.  Default 0: measured +23 ... +31 us per forward (1.049 -> 1.080 ms at 6
+//                        rows, 1.416 -> 1.439 at 48; profiles/r05_walk_coop_ab.txt) for a check the occupancy query at init already makes — a
+//                        plain launch of the same grid has the same residency (MI355X_MICROARCH.md, coop-launch row)
+//   SVG_XF_WALK_TIMEOUT_MS  wall-clock give-up time of a barrier (default 2000)
+//   SVG_XF_WALK_TEST_GIVEUP  test hook: barriers wait for 8 workgroups more than the grid has
+void apply_env(WalkDev& D) {
+  D.coop = D.coop_ok && svg_env_i64("SVG_XF_WALK_COOP", 0) != 0;
+  D.timeout = (unsigned long long)std::max<int64_t>(1, svg_env_i64("SVG_XF_WALK_TIMEOUT_MS", 2000)) * 100000ull;
+  D.test_giveup = svg_env_i64("SVG_XF_WALK_TEST_GIVEUP", 0) != 0;
+  D.disabled = D.n_wg < 8 || svg_env_i64("SVG_XF_WALK", getenv("SVG_DEVICE_OVERRIDE") ? 0 : 1) == 0;
+}
 
 template <int MT>
-void set_attr() {
+int resident_per_cu() {
   HIP_OK(hipFuncSetAttribute((const void*)xf_walk_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+  int n = 0;
+  HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)xf_walk_kernel<MT>, WK_THREADS, (size_t)kMaxLds));
+  return n;
 }
 template <int MT>
-void launch(int n_wg, int64_t lds, hipStream_t s, const WalkOp* ops, int n_ops, WalkSync* sy, unsigned* habort) {
+void launch(const WalkDev& D, int64_t lds, hipStream_t s, const WalkOp* ops, int n_ops, WalkSync* sy, unsigned* habort, unsigned expect_wg) {
   unsigned long long* stamps = nullptr;
 #ifdef WK_STAMP
   static unsigned long long* g_stamps = nullptr;
-  if (!g_stamps) HIP_OK(hipMalloc((void**)&g_stamps, 4 * kMaxOps * sizeof(unsigned long long)));
-  HIP_OK(hipMemsetAsync(g_stamps, 0, 4 * kMaxOps * sizeof(unsigned long long), s));
+  if (!g_stamps) HIP_OK(hipMalloc((void**)&g_stamps, 4 * kWalkMaxOps * sizeof(unsigned long long)));
+  HIP_OK(hipMemsetAsync(g_stamps, 0, 4 * kWalkMaxOps * sizeof(unsigned long long), s));
   stamps = g_stamps;
 #endif
-  hipLaunchKernelGGL((xf_walk_kernel<MT>), dim3(n_wg), dim3(WK_THREADS), (size_t)lds, s, ops, n_ops, sy, habort, stamps);
+  unsigned long long timeout = D.timeout;
+  if (D.coop) {
+    void* args[] = {(void*)&ops, (void*)&n_ops, (void*)&sy, (void*)&habort, (void*)&stamps, (void*)&expect_wg, (void*)&timeout};
+    HIP_OK(hipLaunchCooperativeKernel((const void*)xf_walk_kernel<MT>, dim3(D.n_wg), dim3(WK_THREADS), args, (unsigned)lds, s));
+  } else {
+    hipLaunchKernelGGL((xf_walk_kernel<MT>), dim3(D.n_wg), dim3(WK_THREADS), (size_t)lds, s, ops, n_ops, sy, habort, stamps, expect_wg, timeout);
+  }
 #ifdef WK_STAMP
   if (const char* path = getenv("SVG_XF_WALK_STAMPS")) {       // diagnostic build only: synchronous dump of the last launch
     HIP_OK(hipStreamSynchronize(s));
@@ -520,12 +557,52 @@ void launch(int n_wg, int64_t lds, hipStream_t s, const WalkOp* ops, int n_ops, 
   }
 #endif
 }
-int walk_mt(int rows) {                               // the instantiated accumulator heights
+int walk_mt(int rows) {
   const int mt = (rows + 15) / 16;
   return mt <= 4 ? mt : (mt <= 6 ? 6 : (mt <= 8 ? 8 : 11));
 }
-const char* kGaveUp = "xf_walk: a launch gave up at a device-wide barrier (a workgroup never became resident — is another process holding "
-                      "compute units?); its output is invalid.  SVG_XF_WALK=0 selects the per-GEMM kernels";
+const char* kGaveUp = "xf_walk: a layer-walking launch gave up at a device-wide barrier (a workgroup never became resident: something else is "
+                      "holding compute units of this device).  The output of that forward is invalid (NaN-filled).  The layer-walking launch "
+                      "is now OFF for this device in this process — later forwards run the per-GEMM kernels; re-issue the failed forward";
+
+// Every stage against what the kernel assumes about it.  The kernel reads its operands through exact-size descriptors (a wrong index
+// returns zeros instead of faulting), but a table that breaks these rules would still compute garbage or overrun LDS: refuse it on the host.
+void validate_table(const WalkOp* ops, int n_ops, int rows, int64_t lds) {
+  const int mt = walk_mt(rows);
+  auto span_ok = [](int64_t elems) { return elems > 0 && elems * 4 < (int64_t)1 << 31; };
+  for (int i = 0; i < n_ops; ++i) {
+    const WalkOp& op = ops[i];
+    switch (op.kind) {
+      case WK_GEMM:
+        SVG_CHECK(xf_walk_gemm_ok(op.N, op.K) && op.M >= 1 && op.M <= mt * 16 && op.ld >= op.K && op.ksplit == op.K / 128 && op.X && op.W && op.slab,
+                  "xf_walk: stage %d: GEMM %d x %d x %d (ld %d) does not fit the kernel (tiles of 128 x 128, at most %d rows)", i, op.M, op.N, op.K, op.ld, mt * 16);
+        SVG_CHECK(span_ok((int64_t)op.N * op.K) && span_ok((int64_t)(op.M - 1) * op.ld + op.K) && span_ok((int64_t)op.ksplit * op.M * op.N),
+                  "xf_walk: stage %d: an operand of GEMM %d x %d x %d exceeds a 2 GB buffer descriptor", i, op.M, op.N, op.K);
+        SVG_CHECK((int64_t)4 * mt * 16 * 128 + 4096 <= lds, "xf_walk: stage %d: X tile of %d rows needs more than %lld bytes of LDS", i, mt * 16, (long long)lds);
+        break;
+      case WK_RED:
+        SVG_CHECK(op.M >= 1 && op.N % 4 == 0 && op.slab && op.Y && op.ksplit >= 1 && span_ok((int64_t)op.ksplit * op.M * op.N), "xf_walk: stage %d: reduce %d x %d x %d slabs", i, op.M, op.N, op.ksplit);
+        break;
+      case WK_LN:
+        SVG_CHECK(op.M >= 1 && op.N % 4 == 0 && op.N <= 3072 && op.g1 && op.b1 && (op.Y || op.Y2) && (!op.g2 || (op.b2 && op.Y2)) && (op.ksplit == 0 || op.slab) &&
+                      span_ok((int64_t)std::max(op.ksplit, 1) * op.M * op.N),
+                  "xf_walk: stage %d: LayerNorm over %d x %d (at most 3072 columns)", i, op.M, op.N);
+        break;
+      case WK_ATTN:
+        SVG_CHECK(op.Tq >= 1 && op.Tq <= 32 && op.Tk >= 1 && op.Tk <= 32 && op.hd % 4 == 0 && op.heads >= 1 && op.B >= 1 && op.qs && op.ks && op.vs && op.Y &&
+                      op.vs >= op.ks && op.q_span > 0 && op.kv_span > (int)(op.vs - op.ks),
+                  "xf_walk: stage %d: attention Tq %d Tk %d head dim %d", i, op.Tq, op.Tk, op.hd);
+        SVG_CHECK(((int64_t)(op.Tq + 2 * op.Tk) * op.hd + 2 * 32 * 33 + 32) * 4 <= lds, "xf_walk: stage %d: attention slices exceed %lld bytes of LDS", i, (long long)lds);
+        break;
+      case WK_EMBED:
+        SVG_CHECK(op.M == op.B * op.T && op.N % 4 == 0 && op.d_txt % 4 == 0 && op.slab && op.Y && op.pe && op.bias && op.ksplit >= 1 && (op.d_txt == 0 || op.text),
+                  "xf_walk: stage %d: embedding %d x %d (+%d)", i, op.M, op.N, op.d_txt);
+        break;
+      default: SVG_CHECK(false, "xf_walk: stage %d: unknown kind %d", i, op.kind);
+    }
+  }
+  SVG_CHECK(!ops[0].bar, "xf_walk: the first stage reads the launch's inputs and takes no barrier");
+}
 
 }  // namespace
 
@@ -545,15 +622,23 @@ void xf_walk_init_device() {
   SVG_CHECK(dev >= 0 && dev < 16, "xf_walk: device index %d", dev);
   WalkDev& D = g_dev[dev];
   if (D.init) return;
-  set_attr<1>(); set_attr<2>(); set_attr<3>(); set_attr<4>(); set_attr<6>(); set_attr<8>(); set_attr<11>();
   hipDeviceProp_t prop;
   HIP_OK(hipGetDeviceProperties(&prop, dev));
-  D.n_wg = (prop.multiProcessorCount / 8) * 8;        // one workgroup per compute unit (LDS > 80 KB keeps it at one), a multiple of 8
-  SVG_CHECK(D.n_wg >= 8, "xf_walk: %d compute units", prop.multiProcessorCount);
+  // Residency is a launch-time fact, not an assumption: the grid is what the occupancy calculator says is co-resident for EVERY instantiation at
+  // the largest LDS a launch may ask for, capped at one workgroup per compute unit (the kernel's tiling: a 2048 x 2048 matrix = 256 tiles), a
+  // multiple of 8 (the barrier's per-XCD groups).  With $SVG_XF_WALK_COOP=1 the launch itself goes through
+  // hipLaunchCooperativeKernel, which repeats that check per launch (and costs 23-31 us per forward: off by default).
+  const int per_cu = std::min({resident_per_cu<1>(), resident_per_cu<2>(), resident_per_cu<3>(), resident_per_cu<4>(), resident_per_cu<6>(),
+                               resident_per_cu<8>(), resident_per_cu<11>()});
+  D.n_wg = per_cu >= 1 ? (prop.multiProcessorCount / 8) * 8 : 0;
+  int coop_attr = 0;
+  HIP_OK(hipDeviceGetAttribute(&coop_attr, hipDeviceAttributeCooperativeLaunch, dev));
+  D.coop_ok = coop_attr != 0;
+  apply_env(D);
   for (int i = 0; i < kRing; ++i) {
     HIP_OK(hipMalloc((void**)&D.sync[i], sizeof(WalkSync)));
-    HIP_OK(hipMalloc((void**)&D.dops[i], sizeof(WalkOp) * kMaxOps));
-    HIP_OK(hipHostMalloc((void**)&D.hops[i], sizeof(WalkOp) * kMaxOps, hipHostMallocDefault));
+    HIP_OK(hipMalloc((void**)&D.dops[i], sizeof(WalkOp) * kWalkMaxOps));
+    HIP_OK(hipHostMalloc((void**)&D.hops[i], sizeof(WalkOp) * kWalkMaxOps, hipHostMallocDefault));
     HIP_OK(hipEventCreateWithFlags(&D.done[i], hipEventDisableTiming));
   }
   HIP_OK(hipHostMalloc((void**)&D.habort, sizeof(unsigned) * kRing, hipHostMallocDefault));
@@ -561,20 +646,51 @@ void xf_walk_init_device() {
   D.init = true;
 }
 
+void xf_walk_env_refresh() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (WalkDev& D : g_dev)
+    if (D.init) apply_env(D);
+}
+
+bool xf_walk_enabled(hipStream_t s) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const WalkDev& D = g_dev[dev];
+    if (!D.init || D.disabled) return false;
+  }
+  // a launch stages its table through a pinned ring slot, waits on other streams' events and may block the host on a slot's event: none of
+  // that belongs in a stream capture (the graph would bake a stale table) — the per-GEMM kernels serve there
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;
+  return true;
+}
+
 void xf_walk_check(svg_ctx* ctx) {
   (void)ctx;
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return;
   std::lock_guard<std::mutex> lk(g_mu);
   WalkDev& D = g_dev[dev];
   if (!D.init) return;
-  for (int i = 0; i < kRing; ++i) SVG_CHECK(__atomic_load_n(&D.habort[i], __ATOMIC_RELAXED) == 0, "%s", kGaveUp);
+  bool gave_up = false;
+  for (int i = 0; i < kRing; ++i)
+    if (__atomic_load_n(&D.habort[i], __ATOMIC_RELAXED) != 0) { gave_up = true; __atomic_store_n(&D.habort[i], 0u, __ATOMIC_RELAXED); }
+  if (gave_up) {
+    D.disabled = true;                                 // one contention event must not make every later forward raise: fall back for good
+    throw SvgHipError(std::string(kGaveUp));          // a device-side failure (SVG_ERR_RUNTIME), not a bad argument
+  }
 }
 
 void xf_walk_launch(svg_ctx* ctx, const WalkOp* ops, int n_ops, int rows, int64_t lds_bytes, hipStream_t s) {
   (void)ctx;
-  SVG_CHECK(n_ops >= 1 && n_ops <= kMaxOps, "xf_walk: %d stages (at most %d)", n_ops, kMaxOps);
+  SVG_CHECK(n_ops >= 1 && n_ops <= kWalkMaxOps, "xf_walk: %d stages (at most %d)", n_ops, kWalkMaxOps);
   SVG_CHECK(xf_walk_available(rows, lds_bytes), "xf_walk: %d rows / %lld bytes of LDS unsupported", rows, (long long)lds_bytes);
+  // LDS above half the compute unit's: one workgroup per compute unit
+  const int64_t lds = std::max<int64_t>(lds_bytes, kMinLds);
+  validate_table(ops, n_ops, rows, lds);
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(g_mu);
@@ -582,8 +698,9 @@ void xf_walk_launch(svg_ctx* ctx, const WalkOp* ops, int n_ops, int rows, int64_
   SVG_CHECK(D.init, "xf_walk: xf_walk_init_device() has not run on device %d", dev);
   const int slot = D.next;
   D.next = (D.next + 1) % kRing;
-  if (D.used[slot]) HIP_OK(hipEventSynchronize(D.done[slot]));        // the pinned table and the barrier words of this slot are free again
-  for (int i = 0; i < kRing; ++i) SVG_CHECK(__atomic_load_n(&D.habort[i], __ATOMIC_RELAXED) == 0, "%s", kGaveUp);
+  // the slot's previous launch (16 launches ago) must be over before its pinned table and barrier words are reused — in practice it is:
+  // the query succeeds and the host never blocks here
+  if (D.used[slot] && hipEventQuery(D.done[slot]) != hipSuccess) HIP_OK(hipEventSynchronize(D.done[slot]));
   memcpy(D.hops[slot], ops, sizeof(WalkOp) * n_ops);
   for (int i = n_ops - 1, nxt = n_ops; i >= 0; --i) {     // the weight stream's chain: the next GEMM stage after each stage
     D.hops[slot][i].next_gemm = nxt;
@@ -593,20 +710,20 @@ void xf_walk_launch(svg_ctx* ctx, const WalkOp* ops, int n_ops, int rows, int64_
   if (D.last >= 0 && D.last != slot) HIP_OK(hipStreamWaitEvent(s, D.done[D.last], 0));
   HIP_OK(hipMemcpyAsync(D.dops[slot], D.hops[slot], sizeof(WalkOp) * n_ops, hipMemcpyHostToDevice, s));
   HIP_OK(hipMemsetAsync(D.sync[slot], 0, sizeof(WalkSync), s));
-  // LDS above half the compute unit's: one workgroup per compute unit, so the grid is resident as a whole on an otherwise idle device
-  const int64_t lds = std::max<int64_t>(lds_bytes, 84 * 1024);
   const int mt = walk_mt(rows);
   WalkOp* dops = D.dops[slot];
   WalkSync* sy = D.sync[slot];
   unsigned* ha = D.habort + slot;
+  // test hook: a barrier that waits for 8 workgroups more than the grid has never completes — exercises the give-up path end to end
+  const unsigned expect = (unsigned)D.n_wg + (D.test_giveup ? 8u : 0u);
   switch (mt) {
-    case 1: launch<1>(D.n_wg, lds, s, dops, n_ops, sy, ha); break;
-    case 2: launch<2>(D.n_wg, lds, s, dops, n_ops, sy, ha); break;
-    case 3: launch<3>(D.n_wg, lds, s, dops, n_ops, sy, ha); break;
-    case 4: launch<4>(D.n_wg, lds, s, dops, n_ops, sy, ha); break;
-    case 6: launch<6>(D.n_wg, lds, s, dops, n_ops, sy, ha); break;
-    case 8: launch<8>(D.n_wg, lds, s, dops, n_ops, sy, ha); break;
-    default: launch<11>(D.n_wg, lds, s, dops, n_ops, sy, ha); break;
+    case 1: launch<1>(D, lds, s, dops, n_ops, sy, ha, expect); break;
+    case 2: launch<2>(D, lds, s, dops, n_ops, sy, ha, expect); break;
+    case 3: launch<3>(D, lds, s, dops, n_ops, sy, ha, expect); break;
+    case 4: launch<4>(D, lds, s, dops, n_ops, sy, ha, expect); break;
+    case 6: launch<6>(D, lds, s, dops, n_ops, sy, ha, expect); break;
+    case 8: launch<8>(D, lds, s, dops, n_ops, sy, ha, expect); break;
+    default: launch<11>(D, lds, s, dops, n_ops, sy, ha, expect); break;
   }
   check_launch("xf_walk");
   HIP_OK(hipEventRecord(D.done[slot], s));

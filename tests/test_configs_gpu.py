@@ -60,11 +60,52 @@ def nets():
 
 
 def _sdu(cfg_name, nets, dtype="bf16"):
+    """dtype 'fp8' = what `bench.py --dtype fp8` / `--workload cfg4` builds: SDUtils(fp8=True, dtype='fp16') — MX-fp8 (e4m3 + E8M0
+    block scales) operands on the resnets' / upsamplers' 3x3 convs, fp16 storage everywhere else (BASELINE configs[4]'s arithmetic)."""
     from sd_video_gen_amd import config as svg_config
     from sd_video_gen_amd.sd_utils import SDUtils
     svg_config.set_args(["--dataset", "synthetic-ball", "--config", cfg_name, "--denoise", "1"])
     usd, vsd = nets
-    return SDUtils(weights={"vae": vsd, "unet": usd, "text_encoder": "synthetic"}, verbose=False, dtype=dtype)
+    fp8 = dtype == "fp8"
+    return SDUtils(weights={"vae": vsd, "unet": usd, "text_encoder": "synthetic"}, verbose=False, dtype="fp16" if fp8 else dtype, fp8=fp8)
+
+
+class _arith:
+    """fp8 legs: the MX-fp8 conv kernel takes a conv only when it fills the chip (>= 192 workgroups: the bench's 28-clip groups do, the
+    fixtures' single clip does not and would silently run fp16).  The kernel and its arithmetic do not depend on the batch, so the fp8
+    legs lower the threshold ($SVG_HALO_MIN=1) — and check_fp8() proves from the library's own launch records that the e4m3 kernels ran."""
+
+    def __init__(self, dtype):
+        self.on = dtype == "fp8"
+
+    def __enter__(self):
+        if self.on:
+            self.old = os.environ.get("SVG_HALO_MIN")
+            os.environ["SVG_HALO_MIN"] = "1"
+            _lib.env_refresh()
+        return self
+
+    def __exit__(self, *a):
+        if self.on:
+            if self.old is None:
+                os.environ.pop("SVG_HALO_MIN", None)
+            else:
+                os.environ["SVG_HALO_MIN"] = self.old
+            _lib.env_refresh()
+
+    def check_fp8(self, c, batch):
+        """one more UNet call of the same batch under the per-site profile: the resnets' convs must have launched conv_halo_fp8"""
+        if not self.on:
+            return
+        c.prof_enable(True, detail=True)
+        c.prof_reset()
+        c.unet_forward(torch.zeros(batch, 4, 64, 64).cuda(), torch.full((batch,), 500.0).cuda(), torch.zeros(batch, 77, 768).cuda())
+        torch.cuda.synchronize()
+        rep = c.prof_report()
+        c.prof_enable(False)
+        n8 = sum(v["calls"] for k, v in rep.items() if "conv_fp8" in k)
+        print("[parity] fp8 leg: %d of the UNet call's conv launches ran conv_halo_fp8 (e4m3 x e4m3, E8M0 block scales)" % n8)
+        assert n8 >= 40, "the fp8 leg did not run the MX-fp8 conv kernel (%d launches)" % n8
 
 
 def _rollout(cfg_name, g, nets, dtype="bf16"):
@@ -132,7 +173,7 @@ def test_config2_full_frame_50_steps(ctx, nets, dtype, tol_cond, tol_forced):
           % (table[-1][1], e_frame))
 
 
-@pytest.mark.parametrize("dtype,tol_loop,tol_frame", [("fp16", 5e-3, 1.5e-2), ("bf16", 3e-2, 6e-2)])
+@pytest.mark.parametrize("dtype,tol_loop,tol_frame", [("fp16", 5e-3, 1.5e-2), ("bf16", 3e-2, 6e-2), ("fp8", 1.2e-1, 1.2e-1)])
 def test_config2_free_running_contractive(ctx, nets, dtype, tol_loop, tol_frame):
     """configs[2] END TO END, free-running, at a real tolerance: the headline workload (one generated frame = VAE passes at 512 x 512 +
     all 50 DDIM steps of the full-size UNet, nothing teacher-forced) against the fp32 oracle, in the synthetic-weight regime whose
@@ -143,8 +184,15 @@ def test_config2_free_running_contractive(ctx, nets, dtype, tol_loop, tol_frame)
     g = gold("sd_cfg2_contractive.pt")
     usd, vsd = nets
     cnets = (GG.contractive_unet(usd), vsd)
+    with _arith(dtype) as ar:
+        _config2_free_running(g, cnets, dtype, tol_loop, tol_frame, ar)
+
+
+def _config2_free_running(g, cnets, dtype, tol_loop, tol_frame, ar):
     lat, sdu = _rollout("1_16_kitti_L1_64", g, cnets, dtype)
-    assert sdu.ctx.model_dtype(_lib.SVG_UNET) == dtype and sdu.ctx.model_dtype(_lib.SVG_VAE) == dtype
+    ar.check_fp8(sdu.unet.ctx, 1)
+    store = "fp16" if dtype == "fp8" else dtype
+    assert sdu.ctx.model_dtype(_lib.SVG_UNET) == store and sdu.ctx.model_dtype(_lib.SVG_VAE) == store and sdu.fp8 == (dtype == "fp8")
     e_frame = rel_l2(lat[:, 4:], g["all_latents"][:, 4:])
     emb = GG.text_emb().cuda()
     ks = g["hist_steps"]
@@ -222,7 +270,7 @@ def test_config3_full_length_contractive(ctx, nets, dtype, tol_first, tol_all, t
     margin("cfg3 FULL length (%s): last frame (16 autoregressive steps)" % dtype, per[-1], tol_last)
 
 
-@pytest.mark.parametrize("dtype,tol_first,tol_all", [("fp16", 2e-2, 2.9e-2), ("bf16", 1.2e-1, 1.6e-1)])   # measured fp16: 7.5e-3, 9.6e-3; bf16: 5.3e-2, 5.6e-2 (guidance 7.5 amplifies the per-call error)
+@pytest.mark.parametrize("dtype,tol_first,tol_all", [("fp16", 2e-2, 2.9e-2), ("bf16", 1.2e-1, 1.6e-1), ("fp8", 3e-1, 3e-1)])   # measured fp16: 7.5e-3, 9.6e-3; bf16: 5.3e-2, 5.6e-2 (guidance 7.5 amplifies the per-call error); fp8: see profiles/r05_parity.md
 def test_config4_full_ddim_length_text_guided(ctx, nets, dtype, tol_first, tol_all):
     """configs[4] at the full DDIM length: 11_27_ucf_text_final (text-conditioned Transformer, d = 2432), guidance_scale 7.5 with
     distinct uncond / cond embeddings, four autoregressive frames of 50 steps each (200 batch-2 UNet calls in the oracle fixture,
@@ -232,10 +280,12 @@ def test_config4_full_ddim_length_text_guided(ctx, nets, dtype, tol_first, tol_a
     assert g["pred_frames"] == 4 and g["start_step"] == 0 and g["guidance_scale"] == 7.5 and g["unet_calls"] == 200
     usd, vsd = nets
     m, cfg = GG.build_text_transformer()
-    sdu = _sdu("11_27_ucf_text_final", (GG.contractive_unet(usd), vsd), dtype)
-    clip = bouncing_ball_clips(1, cfg.FRAME_SIZE, 5, seed=GG.CLIP_SEED)
-    lat = sample_clips(m, sdu, clip.cuda(), 4, denoise=True, start_step=0, seeds=[GG.NOISE_SEED], text_embeddings=GG.text_emb_pair().cuda(),
-                       guidance_scale=7.5, cls_list=[g["class"]], cpu_noise=True).cpu()
+    with _arith(dtype) as ar:
+        sdu = _sdu("11_27_ucf_text_final", (GG.contractive_unet(usd), vsd), dtype)
+        clip = bouncing_ball_clips(1, cfg.FRAME_SIZE, 5, seed=GG.CLIP_SEED)
+        lat = sample_clips(m, sdu, clip.cuda(), 4, denoise=True, start_step=0, seeds=[GG.NOISE_SEED], text_embeddings=GG.text_emb_pair().cuda(),
+                           guidance_scale=7.5, cls_list=[g["class"]], cpu_noise=True).cpu()
+        ar.check_fp8(sdu.unet.ctx, 2)
     assert lat.shape == g["all_latents"].shape
     per = [rel_l2(lat[:, 4 + k], g["all_latents"][:, 4 + k]) for k in range(4)]
     print("[parity] cfg4 full DDIM length (%s) per-frame rel-L2: " % dtype + " ".join("%.2e" % e for e in per))
@@ -243,12 +293,19 @@ def test_config4_full_ddim_length_text_guided(ctx, nets, dtype, tol_first, tol_a
     margin("cfg4 text + guidance 7.5, 50 steps per frame (%s): all four generated frames" % dtype, rel_l2(lat[:, 4:], g["all_latents"][:, 4:]), tol_all)
 
 
-def test_config4_guidance_7p5_full_size(ctx, nets):
+@pytest.mark.parametrize("fp8,tol_call,tol_guided,tol_steps", [(0, 2.5e-2, 2e-1, 1.5e-2), (1, 9e-2, 6e-1, 1.2e-1)])
+def test_config4_guidance_7p5_full_size(ctx, nets, fp8, tol_call, tol_guided, tol_steps):
     """configs[4]: a real prompt + guidance_scale 7.5 (evaluation/predict_fvd2_denoise.py:203,227-229): the batch-2 UNet call
-    with DIFFERENT uncond / cond embeddings, the CFG combine and three scheduler steps, full-size UNet."""
+    with DIFFERENT uncond / cond embeddings, the CFG combine and three scheduler steps, full-size UNet.  fp8 = 1: the same rows in the
+    arithmetic configs[4] names (MX-fp8 3x3 convs, fp16 storage elsewhere)."""
+    with _arith("fp8" if fp8 else "fp16") as ar:
+        _config4_guidance(ctx, nets, fp8, tol_call, tol_guided, tol_steps, ar)
+
+
+def _config4_guidance(ctx, nets, fp8, tol_call, tol_guided, tol_steps, ar):
     usd, _ = nets
     c = SO.SD_UNET
-    ctx.configure(_lib.SVG_UNET, block_out=list(c["block_out"]), layers=2, heads=8, ctx_dim=768, groups=32, attn=list(c["attn"]))
+    ctx.configure(_lib.SVG_UNET, block_out=list(c["block_out"]), layers=2, heads=8, ctx_dim=768, groups=32, attn=list(c["attn"]), fp8=fp8, f16=fp8)
     ctx.load_state_dict(_lib.SVG_UNET, usd)
     ctx.finalize(_lib.SVG_UNET)
     g = torch.Generator().manual_seed(11)
@@ -258,12 +315,14 @@ def test_config4_guidance_7p5_full_size(ctx, nets):
     x2 = torch.cat([z, z])
     e = ctx.unet_forward(x2.cuda(), torch.tensor([500.0, 500.0]).cuda(), emb.cuda()).cpu()
     ref = SO.unet_forward(usd, x2, 500, emb)
-    margin("cfg4 batch-2 UNet call (uncond/cond rows), full size", rel_l2(e, ref), 2.5e-2)      # measured 1.05e-2
-    margin("cfg4 guided noise u + 7.5 (c - u)", rel_l2(e[:1] + 7.5 * (e[1:] - e[:1]), ref[:1] + 7.5 * (ref[1:] - ref[:1])), 2e-1)
+    tag = " [fp8 convs]" if fp8 else ""
+    margin("cfg4 batch-2 UNet call (uncond/cond rows), full size" + tag, rel_l2(e, ref), tol_call)      # measured 1.05e-2 (bf16)
+    margin("cfg4 guided noise u + 7.5 (c - u)" + tag, rel_l2(e[:1] + 7.5 * (e[1:] - e[:1]), ref[:1] + 7.5 * (ref[1:] - ref[:1])), tol_guided)
     S = 47
     got = ctx.ddim_loop(z.cuda(), emb.cuda(), num_steps=50, start_step=S, guidance=7.5, noise=noise.cuda()).cpu()
     want = SO.gen_i2i_latents(usd, emb, z, 50, 7.5, S, noise=noise)
-    margin("cfg4 3 DDIM steps at guidance 7.5", rel_l2(got, want), 1.5e-2)                       # measured 5.5e-3
+    margin("cfg4 3 DDIM steps at guidance 7.5" + tag, rel_l2(got, want), tol_steps)                       # measured 5.5e-3 (bf16)
+    ar.check_fp8(ctx, 2)
 
 
 def test_config4_text_loop_with_prompt_and_guidance(ctx, nets):

@@ -278,3 +278,63 @@ def test_walk_from_two_threads_on_two_streams(ctx):
         return bad
 
     assert _with_walk(True, body) == []
+
+
+def test_walk_deep_narrow_model_more_workgroups_than_tiles(ctx):
+    """The shape class of `config_test` (d = 256, 8 heads, 6 + 6 layers, 128 x 128 frames: D_lat 1024) — the class the walk's first run
+    aborted in: 156 stages; every GEMM has 4 ... 32 tiles of 128 x 128 for 256 workgroups, so most workgroups own no tile in
+    any stage (their weight stream ends before it starts), a few own tiles in the feed-forward stages only, and the embedding / output
+    projections have a different K (1024) than the layers (256).  Walk forced ON, against the per-GEMM kernels and the CPU oracle."""
+    from sd_video_gen_amd import config as svg_config
+    from sd_video_gen_amd.transformer import Transformer
+    svg_config.set_args(["--dataset", "ball", "--config", "config_test"])          # FRAME_SIZE 128 -> D_lat = 4 * 16 * 16
+    torch.manual_seed(21)
+    m = Transformer(dim_model=256, num_heads=8, num_encoder_layers=6, num_decoder_layers=6).eval()
+    assert m.d_lat == 1024
+    sd = {k: v.clone().cpu() for k, v in m.state_dict().items()}
+    mask = m.get_tgt_mask(6).cuda()
+    for B in (1, 3, 9):
+        g = torch.Generator().manual_seed(100 + B)
+        X = torch.randn(B, 6, 1024, generator=g)
+        pe0 = torch.zeros(B, dtype=torch.int32)
+        run = lambda: m(X.cuda(), X.cuda(), mask, pe_row=pe0).cpu()
+        out = _with_walk(True, run)
+        assert torch.equal(out, _with_walk(True, run))
+        assert rel_l2(out, _with_walk(False, run)) < 5e-6
+        for b in sorted({0, B - 1}):
+            assert rel_l2(out[:, b:b + 1], TO.forward(sd, X[b:b + 1], X[b:b + 1], 8, TO.get_tgt_mask(6))) < TOL
+
+
+def test_walk_give_up_is_reported_once_and_the_device_falls_back(ctx):
+    """a layer-walking launch that gives up at a device-wide barrier (test hook: the barrier waits for 8 workgroups more
+    than the grid has; 20 ms wall-clock give-up time) NaN-fills its output, is reported by the NEXT model call of the C ABI — once — and
+    turns the walk off for the device: the calls after that run the per-GEMM kernels and are correct.  svg_env_refresh re-arms it."""
+    from sd_video_gen_amd import _lib
+    m = _walk_model(seed=14)
+    sd = {k: v.clone().cpu() for k, v in m.state_dict().items()}
+    X = torch.randn(2, 6, 256, generator=torch.Generator().manual_seed(3))
+    pe0 = torch.zeros(2, dtype=torch.int32)
+    mask = m.get_tgt_mask(6).cuda()
+    run = lambda: m(X.cuda(), X.cuda(), mask, pe_row=pe0).cpu()
+    good = _with_walk(True, run)
+    keys = {"SVG_XF_WALK": "1", "SVG_XF_WALK_TEST_GIVEUP": "1", "SVG_XF_WALK_TIMEOUT_MS": "20"}
+    old = {k: os.environ.get(k) for k in keys}
+    os.environ.update(keys)
+    _lib.env_refresh()
+    try:
+        bad = run()                                        # the launch itself succeeds; its result is poisoned
+        assert torch.isnan(bad).all()
+        with pytest.raises(RuntimeError, match="gave up"):
+            run()
+        os.environ["SVG_XF_WALK_TEST_GIVEUP"] = "0"        # (not refreshed: the library must already have fallen back by itself)
+        after = run()                                      # no raise any more, per-GEMM kernels
+        assert torch.isfinite(after).all() and rel_l2(after, good) < 5e-6
+        assert rel_l2(after[:, :1], TO.forward(sd, X[:1], X[:1], 4, TO.get_tgt_mask(6))) < TOL
+    finally:
+        for k in keys:
+            if old[k] is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = old[k]
+        _lib.env_refresh()
+    assert torch.equal(_with_walk(True, run), good)        # re-armed by the refresh: the walk again, same bits

@@ -50,6 +50,11 @@ hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipSuccess; }
 hipError_t hipGraphExecDestroy(hipGraphExec_t e) { free((void*)e); return hipSuccess; }
 hipError_t hipGraphDestroy(hipGraph_t g) { free((void*)g); return hipSuccess; }
 hipError_t hipLaunchKernel(const void*, dim3, dim3, void**, size_t, hipStream_t) { return hipSuccess; }
+hipError_t hipLaunchCooperativeKernel(const void*, dim3, dim3, void**, unsigned, hipStream_t) { return hipSuccess; }
+hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void*, int, size_t) { *n = 1; return hipSuccess; }
+hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 1; return hipSuccess; }
+hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* st) { *st = hipStreamCaptureStatusNone; return hipSuccess; }
 // launch plumbing of the host-side kernel stubs
 static thread_local struct { dim3 g, b; size_t s; hipStream_t st; } g_cfg;
 hipError_t __hipPushCallConfiguration(dim3 g, dim3 b, size_t s, hipStream_t st) { g_cfg.g = g; g_cfg.b = b; g_cfg.s = s; g_cfg.st = st; return hipSuccess; }
