@@ -80,6 +80,8 @@ def parse():
                         "one step = forward in train mode + criterion + backward + Adam on the config's own batch")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--no-fp8-extra", action="store_true",
+                   help="skip extras.fp8_same_box (one step of the same workload with the MX-fp8 convs, rank 0, after the headline is computed)")
     args = p.parse_args()
     wl = WORKLOADS[args.workload]
     if args.dtype is None:
@@ -315,6 +317,55 @@ def roofline_pass(args, sd_utils, step, denoise, C, model=None):
     return out
 
 
+def fp8_same_box(args, cfg, local_rank, build_model, clips, seeds, kw_s, cls_emb, fps_fp16):
+    """extras.fp8_same_box: the SAME workload, clips and process, with the UNet's resnet / upsampler 3x3 convs on MX-fp8
+    operands (SDUtils(fp8=True): e4m3 x e4m3 + E8M0 block scales, fp16 storage elsewhere) — ONE warm-up and ONE timed step after the
+    headline has been computed.  The headline stays fp16 (the reference's autocast arithmetic); fp8 is narrower than the reference and is
+    BASELINE configs[4]'s arithmetic only.  Parity of that arithmetic at the loop level: tests/test_configs_gpu.py [fp8] legs."""
+    import torch
+    from sd_video_gen_amd import _lib
+    from sd_video_gen_amd.predict import sample_clips, sample_clips_streams
+    from sd_video_gen_amd.sd_utils import SDUtils
+    workers = []
+    for _ in range(args.streams):
+        c8 = _lib.Context(local_rank)
+        torch.manual_seed(0)
+        workers.append((build_model(c8), SDUtils(weights="synthetic", seed=0, verbose=False, ctx=c8, fp8=True, dtype="fp16"), torch.cuda.Stream()))
+
+    def step8():
+        return sample_clips_streams(workers, clips, args.pred_frames, seeds, cls_list=cls_emb, **kw_s)
+    step8()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = step8()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    # one stream group alone under the library's hipEvent brackets: the UNet call of the fp8 build
+    m0, sdu0, _ = workers[0]
+    n1 = max(1, clips.shape[0] // args.streams)
+    kw1 = dict(kw_s)
+    emb = kw1.get("text_embeddings")
+    n = clips.shape[0]
+    if emb is not None and emb.shape[0] == 2 * n and n > 1:
+        kw1["text_embeddings"] = torch.cat([emb[:n1], emb[n:n + n1]])
+    sdu0.ctx.prof_reset(); sdu0.ctx.prof_enable(True)
+    sample_clips(m0, sdu0, clips[:n1], 1, seeds=seeds[:n1], cls_list=(cls_emb[:n1] if cls_emb is not None else None), **kw1)
+    torch.cuda.synchronize()
+    rep = sdu0.ctx.prof_report(); sdu0.ctx.prof_enable(False)
+    outer = rep.get("unet_step")
+    fps8 = clips.shape[0] * args.pred_frames / dt
+    rec = {"frames_per_s": fps8, "ms_per_step": dt * 1e3, "steps": 1, "warmup": 1, "vs_fp16_headline": fps8 / fps_fp16,
+           "dtype": "fp8 (MX e4m3 x e4m3, E8M0 scale per 32 channels: the UNet's resnet + upsampler 3x3 convs) + " + sdu0.ctx.model_dtype(_lib.SVG_UNET) + " storage elsewhere",
+           "note": "same process, clips and stream groups as the headline; NOT the headline (narrower than the reference's fp16 autocast)"}
+    if outer and outer["calls"]:
+        rec["unet_step"] = {"ms_per_call": outer["ms"] / outer["calls"], "samples": n1 * (2 if args.guidance != 0.0 else 1), "calls": outer["calls"]}
+    if "conv3x3" in rep:
+        rec["conv3x3_family"] = {"ms": rep["conv3x3"]["ms"], "tflops": rep["conv3x3"]["flops"] / max(rep["conv3x3"]["ms"], 1e-9) / 1e9}
+    del workers
+    return rec
+
+
 def train_bench(args, rank, local_rank, world, dist):
     """Training-step line.  The reference's trainer is single-GPU (no DDP): with N ranks every rank trains its own replica
     (DESIGN.md section 6 'replicas only'), value = iterations of all ranks / max-over-ranks time."""
@@ -457,6 +508,8 @@ def main():
     sd_dtype = "fp16" if args.dtype in ("fp16", "fp8") else "bf16"      # fp8: e4m3 operands where they pay, fp16 storage elsewhere
     if os.environ.get("SVG_FP8_BASE"):
         sd_dtype = os.environ["SVG_FP8_BASE"]
+        if sd_dtype not in ("fp16", "bf16"):
+            raise SystemExit("bench.py: SVG_FP8_BASE=%r is not one of fp16, bf16" % sd_dtype)
     guidance = args.guidance if denoise else 0.0
 
     def build_model(ctx=None):
@@ -552,16 +605,20 @@ def main():
                        "clips_per_gpu": C, "streams_per_gpu": args.streams, "pred_frames": args.pred_frames, "global_clips": n_global, "parallelism": "clip-sharded dp%d" % world,
                        "weights": "seeded random init (SD v1.4 architecture, %s)" % args.config}}
 
+    # The job is over for the other ranks: every collective of the run (gathers, the timing all-reduce) is behind this barrier.  Rank 0's
+    # instrumented pass, fp8 pass and CPU baseline are single-process work (no collective) and may take minutes: nobody waits for them
+    # inside an RCCL barrier under its watchdog.  `ranks_seen` was read while the group was alive.
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
     if rank == 0 and not args.no_roofline:
         line.update(roofline_pass(args, sd_utils, step, denoise, C, model))
+    if rank == 0 and denoise and args.dtype == "fp16" and not args.no_fp8_extra:
+        line.setdefault("extras", {})["fp8_same_box"] = fp8_same_box(args, cfg, local_rank, build_model, clips, seeds, kw_s, cls_emb, fps)
     if rank == 0 and not args.no_cpu_baseline:
-        # rank 0 only; at N > 1 the other ranks wait in the barrier below (the N > 1 lines carry the baseline too)
         line["cpu_baseline"] = cpu_baseline(args.config, args.start_step, denoise, guidance, args.text)
     if rank == 0:
         print(json.dumps(line))
-    if world > 1:
-        dist.barrier()            # the other ranks stay in the group until rank 0's instrumented pass is over
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -20,6 +20,11 @@
 //   * a wave sees whole rows of its column group: LayerNorm row partials (GemmArgs::ln_part, one per row and column group) are
 //     per-lane sums + two shuffles; GroupNorm column sums (gn_part, 128-row tiles) meet in LDS in wave order.
 // v_mfma_f32_16x16x32 with the W fragment as the A operand (D[i = n][j = m]: 4 consecutive columns per lane, as gemm.hip).
+//   * 16-byte epilogue traffic (round 5): the rows of W are dealt to the MFMA A-operand rows of an n-tile PAIR (2p, 2p + 1) so that a
+//     lane's accumulator quads of the two tiles are 8 CONSECUTIVE output columns — tile 2p + h, operand row r <-> column
+//     32 p + 8 (r >> 2) + 4 h + (r & 3).  W is fetched by per-lane DMA addresses, so this is an address map, not a repack; the residual
+//     comes in and the result goes out as ONE 16-byte access per lane and tile pair instead of two 8-byte ones (22 instead of 32
+//     vector-memory instructions per 16 x 160 wave-tile: the launch is bound by the CU's address path, SQ counters in DESIGN.md §4.1).
 #include "igemm_epi.h"
 #include <cstdlib>
 
@@ -36,6 +41,10 @@ template <int KS, bool RES, bool QKV = false>
 __global__ void __launch_bounds__(512, 2) gemm_ws_kernel(const GemmArgs g, int n_groups, int n_slices) {
   constexpr int NTG = WS_PIECES / KS;           // n-tiles (16 columns) per column group
   constexpr int GC = NTG * 16;                  // columns per group
+  static_assert(NTG % 2 == 0, "n-tiles are processed in pairs (K = 320: 10 tiles of 16 columns)");
+  constexpr int NTP = NTG / 2;                  // n-tile pairs
+  // column (inside the group) of operand row r of n-tile j
+  auto col_of = [](int j, int r) { return 32 * (j >> 1) + 8 * (r >> 2) + 4 * (j & 1) + (r & 3); };
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // LDS: W group [100 KiB] | bias f32[GC] | ln_s f32[GC] | GroupNorm scratch 2 x [8 waves][GC][2] f32
   float* s_bias = (float*)(smem + WS_W_BYTES);
@@ -63,7 +72,7 @@ __global__ void __launch_bounds__(512, 2) gemm_ws_kernel(const GemmArgs g, int n
     const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
     for (int p = wid; p < WS_PIECES; p += 8) {
       const int j = p / KS, ks = p - j * KS;
-      const int n = n0 + j * 16 + l15;
+      const int n = n0 + col_of(j, l15);
       const unsigned voff = n < g.n_valid ? (unsigned)(n * g.ldb + ks * 32 + lq * 8) * 2u : 0x80000000u;
       dma16(srdW, voff, 0, lds0 + (unsigned)p * 1024u);
     }
@@ -78,7 +87,6 @@ __global__ void __launch_bounds__(512, 2) gemm_ws_kernel(const GemmArgs g, int n
   // out-of-range offset — loads return zeros, stores are dropped — so no load sits behind a branch (hipcc waits vmcnt(0) around
   // conditional loads, which would serialise the prefetch) and every wave issues the same instruction stream.
   typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-  typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
   constexpr unsigned OOB = 0x80000000u;
   const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (unsigned)((((int64_t)g.M - 1) * g.lda + g.K) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t srdR = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? g.residual : g.A), 0,
@@ -87,7 +95,7 @@ __global__ void __launch_bounds__(512, 2) gemm_ws_kernel(const GemmArgs g, int n
   const __amdgpu_buffer_rsrc_t srdC = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (unsigned)((((int64_t)g.M - 1) * g.ldc + n_c) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t srdS = __builtin_amdgcn_make_buffer_rsrc((void*)(fold ? g.ln_rs : (const float*)g.A), 0, fold ? (unsigned)g.M * 4u : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t srdT = __builtin_amdgcn_make_buffer_rsrc((void*)(fold ? g.ln_rm : (const float*)g.A), 0, fold ? (unsigned)g.M * 4u : 0u, 0x00020000);
-  auto load_tile = [&](int t, h16x8 (&af)[KS], uint2 (&rf)[NTG], float& lrs, float& lrm) {
+  auto load_tile = [&](int t, h16x8 (&af)[KS], uint4 (&rf)[NTP], float& lrs, float& lrm) {
     const int m = t * WS_ROWS + wid * 16 + l15;
     const bool ok = t < tiles && m < g.M;
     const unsigned a_off = ok ? (unsigned)(m * g.lda + lq * 8) * 2u : OOB;
@@ -97,11 +105,11 @@ __global__ void __launch_bounds__(512, 2) gemm_ws_kernel(const GemmArgs g, int n
       af[ks] = *(const h16x8*)&v;
     }
     if (RES) {
-      const unsigned r_off = ok ? (unsigned)(m * g.ldr + n0 + lq * 4) * 2u : OOB;
+      const unsigned r_off = ok ? (unsigned)(m * g.ldr + n0 + lq * 8) * 2u : OOB;
 #pragma unroll
-      for (int j = 0; j < NTG; ++j) {
-        const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(srdR, r_off, j * 32, 0);
-        rf[j] = make_uint2(v.x, v.y);
+      for (int p = 0; p < NTP; ++p) {
+        const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(srdR, r_off, p * 64, 0);
+        rf[p] = make_uint4(v.x, v.y, v.z, v.w);
       }
     }
     const unsigned s_off = ok ? (unsigned)m * 4u : OOB;
@@ -110,7 +118,7 @@ __global__ void __launch_bounds__(512, 2) gemm_ws_kernel(const GemmArgs g, int n
   };
 
   h16x8 af0[KS], af1[KS];
-  uint2 rf0[NTG], rf1[NTG];
+  uint4 rf0[NTP], rf1[NTP];
   float rs0, rm0, rs1, rm1;
   load_tile(slice, af0, rf0, rs0, rm0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // W landed (and the first tile's fragments)
@@ -118,7 +126,7 @@ __global__ void __launch_bounds__(512, 2) gemm_ws_kernel(const GemmArgs g, int n
   bar();
 
   // one 128-row tile: prefetch the next one into the other register set, multiply, finish, store
-  auto step = [&](int t, h16x8 (&af)[KS], uint2 (&rf)[NTG], float lrs, float lrm, int tn, h16x8 (&afn)[KS], uint2 (&rfn)[NTG],
+  auto step = [&](int t, h16x8 (&af)[KS], uint4 (&rf)[NTP], float lrs, float lrm, int tn, h16x8 (&afn)[KS], uint4 (&rfn)[NTP],
                   float& lrsn, float& lrmn, int parity) {
     load_tile(tn, afn, rfn, lrsn, lrmn);
     const int m = t * WS_ROWS + wid * 16 + l15;
@@ -143,7 +151,7 @@ __global__ void __launch_bounds__(512, 2) gemm_ws_kernel(const GemmArgs g, int n
           const h16x8 wf = *(const h16x8*)(wl + (j * KS + ks) * 1024);
           acc = MFMA_16x16x32(af[ks], wf, acc);
         }
-        const int c = j * 16 + l15;                                  // this lane's column inside the group
+        const int c = col_of(j, l15);                                // this lane's column inside the group
         const float bv = s_bias[c], sv = s_lns[c];
         h16x4 w;
 #pragma unroll
@@ -158,50 +166,58 @@ __global__ void __launch_bounds__(512, 2) gemm_ws_kernel(const GemmArgs g, int n
       return;
     }
 #pragma unroll
-    for (int j = 0; j < NTG; ++j) {
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < NTP; ++p) {
+      h16x8 w8;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const h16x8 wf = *(const h16x8*)(wl + (j * KS + ks) * 1024);
-        acc = MFMA_16x16x32(wf, af[ks], acc);
-      }
-      const int c = j * 16 + lq * 4;                      // column inside the group
-      f32x4 v = acc * g.alpha;
-      if (fold) v = v * lrs - *(const f32x4*)(s_lns + c) * lrm;
-      v += *(const f32x4*)(s_bias + c);
-      if (RES) {
-        const h16x4 r = *(const h16x4*)&rf[j];
-        v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
-      }
-      if (g.act == ACT_SILU) {
+      for (int hh = 0; hh < 2; ++hh) {
+        const int j = 2 * p + hh;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-      } else if (g.act == ACT_GELU) {
+        for (int ks = 0; ks < KS; ++ks) {
+          const h16x8 wf = *(const h16x8*)(wl + (j * KS + ks) * 1024);
+          acc = MFMA_16x16x32(wf, af[ks], acc);
+        }
+        const int c = 32 * p + 8 * lq + 4 * hh;             // column inside the group: the lane's quads of the pair are 8 consecutive columns
+        f32x4 v = acc * g.alpha;
+        if (fold) v = v * lrs - *(const f32x4*)(s_lns + c) * lrm;
+        v += *(const f32x4*)(s_bias + c);
+        if (RES) {
+          const uint2 rr = hh ? make_uint2(rf[p].z, rf[p].w) : make_uint2(rf[p].x, rf[p].y);
+          const h16x4 r = *(const h16x4*)&rr;
+          v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+        }
+        if (g.act == ACT_SILU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-      }
-      const h16x4 w = to_h16x4(v);
-      rf[j] = *(const uint2*)&w;                          // kept until the stores below (after the last MFMA of the tile)
-      __builtin_amdgcn_sched_barrier(0);                  // one n-tile's fragment reads at a time (the scheduler otherwise hoists tens of them: spills)
-      if (emit_ln || emit_gn) {
-        float x[4];
+          for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+        } else if (g.act == ACT_GELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { x[e] = m_ok ? (float)w[e] : 0.f; ln1 += x[e]; ln2 += x[e] * x[e]; }
-        if (emit_gn) {
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        }
+        const h16x4 w = to_h16x4(v);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float a = row16_sum(x[e]), b = row16_sum(x[e] * x[e]);
-            if (l15 == 0) *(float2*)(sc + (wid * GC + c + e) * 2) = make_float2(a, b);
+        for (int e = 0; e < 4; ++e) w8[4 * hh + e] = w[e];
+        __builtin_amdgcn_sched_barrier(0);                  // one n-tile's fragment reads at a time (the scheduler otherwise hoists tens of them: spills)
+        if (emit_ln || emit_gn) {
+          float x[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { x[e] = m_ok ? (float)w[e] : 0.f; ln1 += x[e]; ln2 += x[e] * x[e]; }
+          if (emit_gn) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float a = row16_sum(x[e]), b = row16_sum(x[e] * x[e]);
+              if (l15 == 0) *(float2*)(sc + (wid * GC + c + e) * 2) = make_float2(a, b);
+            }
           }
         }
       }
+      rf[p] = *(const uint4*)&w8;                         // kept until the stores below (after the last MFMA of the tile)
     }
     {
-      const unsigned c_off = m_ok ? (unsigned)(m * g.ldc + n0 + lq * 4) * 2u : OOB;
+      const unsigned c_off = m_ok ? (unsigned)(m * g.ldc + n0 + lq * 8) * 2u : OOB;
 #pragma unroll
-      for (int j = 0; j < NTG; ++j) {
-        u32x2v v; v.x = rf[j].x; v.y = rf[j].y;
-        __builtin_amdgcn_raw_buffer_store_b64(v, srdC, c_off, j * 32, 0);
+      for (int p = 0; p < NTP; ++p) {
+        u32x4v v; v.x = rf[p].x; v.y = rf[p].y; v.z = rf[p].z; v.w = rf[p].w;
+        __builtin_amdgcn_raw_buffer_store_b128(v, srdC, c_off, p * 64, 0);
       }
     }
     if (emit_ln) {
@@ -248,8 +264,8 @@ bool gemm_ws_supported(const GemmArgs& g) {
   if (g.K != 320) return false;
   const int gc = WS_PIECES / (g.K / 32) * 16;
   if (g.N % gc != 0 || g.N > 1280 || (g.n_valid > 0 && g.n_valid < g.N)) return false;
-  if (g.residual && (g.ldr & 3)) return false;
-  if ((g.lda & 7) || (g.ldc & 3) || (g.ldb & 7)) return false;
+  if (g.residual && (g.ldr & 7)) return false;            // 16-byte residual loads / stores (8 consecutive columns per lane)
+  if ((g.lda & 7) || (g.ldc & 7) || (g.ldb & 7)) return false;
   if (g.vt_out && (g.vt_n0 % gc != 0 || g.vt_rows % 16 != 0 || (g.vt_ld & 3) || g.residual || g.gn_part || g.ln_part || g.act != ACT_NONE)) return false;
   if (g.M < 16384) return false;                        // the tiled kernel's territory: too few 128-row tiles per CU to amortise the W load
   return true;
@@ -260,8 +276,6 @@ void gemm_ws_init_device() {
   HIP_OK(hipFuncSetAttribute((const void*)gemm_ws_kernel<10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   HIP_OK(hipFuncSetAttribute((const void*)gemm_ws_kernel<10, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   HIP_OK(hipFuncSetAttribute((const void*)gemm_ws_kernel<10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-  HIP_OK(hipFuncSetAttribute((const void*)gemm_ws_kernel<20, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-  HIP_OK(hipFuncSetAttribute((const void*)gemm_ws_kernel<20, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   int dev = 0;
   hipDeviceProp_t prop;
   HIP_OK(hipGetDevice(&dev));
@@ -282,12 +296,10 @@ void launch_gemm_ws(svg_ctx* ctx, const GemmArgs& g, hipStream_t s) {
   const bool res = g.residual != nullptr;
   if (g.vt_out) {
     hipLaunchKernelGGL((gemm_ws_kernel<10, false, true>), grid, dim3(512), smem, s, g, ng, n_slices);
-  } else if (g.K == 320) {
+  } else {                                               // K = 320 (gemm_ws_supported: the K = 640 form lost to the tiled kernel and is gone)
+    SVG_CHECK(g.K == 320, "gemm_ws: K = %d", g.K);
     if (res) hipLaunchKernelGGL((gemm_ws_kernel<10, true>), grid, dim3(512), smem, s, g, ng, n_slices);
     else hipLaunchKernelGGL((gemm_ws_kernel<10, false>), grid, dim3(512), smem, s, g, ng, n_slices);
-  } else {
-    if (res) hipLaunchKernelGGL((gemm_ws_kernel<20, true>), grid, dim3(512), smem, s, g, ng, n_slices);
-    else hipLaunchKernelGGL((gemm_ws_kernel<20, false>), grid, dim3(512), smem, s, g, ng, n_slices);
   }
 }
 

@@ -159,7 +159,7 @@ struct ConvW {
   uint8_t* w8 = nullptr; uint8_t* w8s = nullptr; int Cp = 0;
 };
 struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
-struct ResW { NormW n1, n2; ConvW c1, c2; PackedLinear sc; bool has_sc = false; int temb_off = -1; };
+struct ResW { NormW n1, n2; ConvW c1, c2; PackedLinear sc; bool has_sc = false; int temb_off = -1; int site = 0; /* UNet: bit of its block in the fp8 placement masks */ };
 struct VaeAttnW { NormW gn; PackedLinear qk, v, proj; int C = 0; };
 
 struct VaeModel : VaeIface {
@@ -209,7 +209,8 @@ struct UnetModel : UnetIface {
   std::vector<int> block_out{320, 640, 1280, 1280};
   std::vector<int> attn{1, 1, 1, 0};
   int layers = 2, heads = 8, ctx_dim = 768, groups = 32, in_ch = 4, out_ch = 4;
-  int fp8 = 0;                       // configure key fp8=1: qualifying dense projections run in MX block-scaled fp8
+  int fp8 = 0;                       // configure key fp8=1: the resnets' / upsamplers' 3x3 convs run on MX block-scaled fp8 operands
+  int64_t fp8_sites_run = -1;        // placement mask in force for the running call (unet.cpp: $SVG_FP8_SITES_GUIDED under guidance)
   const char* dtype() const override { return SD_F16 ? "fp16" : "bf16"; }
   int temb_dim = 0;
   PackedLinear time1, time2, temb_all;     // temb_all: every resnet's time_emb_proj stacked [sum Cout][temb_dim]

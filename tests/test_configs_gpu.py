@@ -105,7 +105,7 @@ class _arith:
         c.prof_enable(False)
         n8 = sum(v["calls"] for k, v in rep.items() if "conv_fp8" in k)
         print("[parity] fp8 leg: %d of the UNet call's conv launches ran conv_halo_fp8 (e4m3 x e4m3, E8M0 block scales)" % n8)
-        assert n8 >= 40, "the fp8 leg did not run the MX-fp8 conv kernel (%d launches)" % n8
+        assert n8 >= 30, "the fp8 leg did not run the MX-fp8 conv kernel (%d launches)" % n8
 
 
 def _rollout(cfg_name, g, nets, dtype="bf16"):
