@@ -53,6 +53,8 @@ __device__ __forceinline__ void dma4(v4i srd, unsigned voff, int soff, unsigned 
 #define STAMP(v) do { } while (0)
 #endif
 
+constexpr int fp8_ws_bytes(int bn) { return (9 * bn * 4 + 1023) / 1024 * 1024; }
+
 template <int BN>
 __global__ void __launch_bounds__(512, 2) conv_halo_fp8_kernel(const Fp8ConvArgs a) {
   constexpr int NT = BN / 32;            // 16-wide channel tiles per wave
@@ -63,7 +65,9 @@ __global__ void __launch_bounds__(512, 2) conv_halo_fp8_kernel(const Fp8ConvArgs
   constexpr int NWS = 3;
   constexpr bool B_TAIL = (BN % 64) != 0;          // BN = 160: a last group of 32 rows, served by waves 0-3
   constexpr int PS_BYTES = 6 * 256;                // patch scales: 324 pixels x 4 B, one dword DMA of waves 0-5
-  constexpr int WS_BYTES = 9 * BN * 4;             // weight scales of a chunk: [tap][row][4 B]
+  // weight scales of a chunk: [tap][row][4 B], padded to whole 1-KiB DMA pieces — the last participating wave issues a full 64-lane DMA whose
+  // surplus lanes (INVALID offset) write zeros: they must land inside the buffer, not on the next one or past the allocation
+  constexpr int WS_BYTES = fp8_ws_bytes(BN);
   constexpr int OFF_B = 2 * PBUF, OFF_PS = OFF_B + NWS * B_BYTES, OFF_WS = OFF_PS + 2 * PS_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr unsigned INVALID = 0x80000000u;
@@ -330,7 +334,7 @@ __global__ void __launch_bounds__(512, 2) conv_halo_fp8_kernel(const Fp8ConvArgs
 }
 
 template <int BN>
-constexpr int fp8_halo_smem() { return 2 * PPIX8 * 128 + 3 * BN * 128 + 2 * 6 * 256 + 2 * 9 * BN * 4; }
+constexpr int fp8_halo_smem() { return 2 * PPIX8 * 128 + 3 * BN * 128 + 2 * 6 * 256 + 2 * fp8_ws_bytes(BN); }
 
 // ---- quantisers --------------------------------------------------------------------------------------------------------------
 // activations: x [P][C] h16 -> q [P][Cp] e4m3 + sc [P][Cp / 32] E8M0 (OCP MX v1.0 section 6.3, like quant_mx_kernel); one thread per

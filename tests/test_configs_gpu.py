@@ -270,30 +270,49 @@ def test_config3_full_length_contractive(ctx, nets, dtype, tol_first, tol_all, t
     margin("cfg3 FULL length (%s): last frame (16 autoregressive steps)" % dtype, per[-1], tol_last)
 
 
-@pytest.mark.parametrize("dtype,tol_first,tol_all", [("fp16", 2e-2, 2.9e-2), ("bf16", 1.2e-1, 1.6e-1), ("fp8", 3e-1, 3e-1)])   # measured fp16: 7.5e-3, 9.6e-3; bf16: 5.3e-2, 5.6e-2 (guidance 7.5 amplifies the per-call error); fp8: see profiles/r05_parity.md
+@pytest.mark.parametrize("dtype,tol_first,tol_all", [("fp16", 2e-2, 2.9e-2), ("bf16", 1.2e-1, 1.6e-1), ("fp8", 1e-1, 1e-1)])   # measured fp16: 7.5e-3, 9.6e-3; bf16: 5.3e-2, 5.6e-2 (guidance 7.5 amplifies the per-call error); fp8: profiles/r05_parity.md
 def test_config4_full_ddim_length_text_guided(ctx, nets, dtype, tol_first, tol_all):
     """configs[4] at the full DDIM length: 11_27_ucf_text_final (text-conditioned Transformer, d = 2432), guidance_scale 7.5 with
     distinct uncond / cond embeddings, four autoregressive frames of 50 steps each (200 batch-2 UNet calls in the oracle fixture,
-    oracle/gen_golden_sd.py cfg4c), free-running on the non-chaotic weights."""
+    oracle/gen_golden_sd.py cfg4c), free-running on the non-chaotic weights.
+    fp8 leg = the arithmetic configs[4] names, built exactly as `bench.py --workload cfg4` builds it (SDUtils(fp8=True,
+    dtype='fp16')): under guidance the library's DDIM loop keeps e4m3 operands on the 16 x 16 level's convs only (csrc/unet.cpp
+    kFp8SitesGuided; per-site study profiles/r05_fp8_sites.txt) — asserted <= 1e-1; the same loop with EVERY eligible conv in e4m3
+    ($SVG_FP8_SITES_GUIDED=4095, round 4's placement) is run too and printed (1.8e-1: why it is not the default)."""
     from sd_video_gen_amd.predict import sample_clips, bouncing_ball_clips
     g = gold("sd_cfg4_text_guided_contractive.pt")
     assert g["pred_frames"] == 4 and g["start_step"] == 0 and g["guidance_scale"] == 7.5 and g["unet_calls"] == 200
     usd, vsd = nets
     m, cfg = GG.build_text_transformer()
-    with _arith(dtype) as ar:
+
+    def run(ar):
         sdu = _sdu("11_27_ucf_text_final", (GG.contractive_unet(usd), vsd), dtype)
         clip = bouncing_ball_clips(1, cfg.FRAME_SIZE, 5, seed=GG.CLIP_SEED)
         lat = sample_clips(m, sdu, clip.cuda(), 4, denoise=True, start_step=0, seeds=[GG.NOISE_SEED], text_embeddings=GG.text_emb_pair().cuda(),
                            guidance_scale=7.5, cls_list=[g["class"]], cpu_noise=True).cpu()
         ar.check_fp8(sdu.unet.ctx, 2)
-    assert lat.shape == g["all_latents"].shape
-    per = [rel_l2(lat[:, 4 + k], g["all_latents"][:, 4 + k]) for k in range(4)]
-    print("[parity] cfg4 full DDIM length (%s) per-frame rel-L2: " % dtype + " ".join("%.2e" % e for e in per))
-    margin("cfg4 text + guidance 7.5, 50 steps per frame (%s): first generated frame" % dtype, per[0], tol_first)
-    margin("cfg4 text + guidance 7.5, 50 steps per frame (%s): all four generated frames" % dtype, rel_l2(lat[:, 4:], g["all_latents"][:, 4:]), tol_all)
+        assert lat.shape == g["all_latents"].shape
+        return [rel_l2(lat[:, 4 + k], g["all_latents"][:, 4 + k]) for k in range(4)], rel_l2(lat[:, 4:], g["all_latents"][:, 4:])
+
+    with _arith(dtype) as ar:
+        per, e_all = run(ar)
+        print("[parity] cfg4 full DDIM length (%s) per-frame rel-L2: " % dtype + " ".join("%.2e" % e for e in per))
+        margin("cfg4 text + guidance 7.5, 50 steps per frame (%s): first generated frame" % dtype, per[0], tol_first)
+        margin("cfg4 text + guidance 7.5, 50 steps per frame (%s): all four generated frames" % dtype, e_all, tol_all)
+        if dtype == "fp8":
+            os.environ["SVG_FP8_SITES_GUIDED"] = "4095"
+            _lib.env_refresh()
+            try:
+                per_all, e_all_sites = run(ar)
+            finally:
+                os.environ.pop("SVG_FP8_SITES_GUIDED", None)
+                _lib.env_refresh()
+            print("[parity] cfg4 full DDIM length, EVERY eligible conv in e4m3 under guidance (not the default) per-frame rel-L2: " + " ".join("%.2e" % e for e in per_all))
+            margin("cfg4 text + guidance 7.5 (fp8, all 33 eligible convs e4m3 — round 4's placement, printed for the record): all four frames", e_all_sites, 3e-1)
+            assert e_all_sites > e_all, "the guided placement must be the more accurate one"
 
 
-@pytest.mark.parametrize("fp8,tol_call,tol_guided,tol_steps", [(0, 2.5e-2, 2e-1, 1.5e-2), (1, 9e-2, 6e-1, 1.2e-1)])
+@pytest.mark.parametrize("fp8,tol_call,tol_guided,tol_steps", [(0, 2.5e-2, 2e-1, 1.5e-2), (1, 9e-2, 6e-1, 2.5e-2)])   # fp8 = 1 measured: 8.4e-2 (all 33 e4m3 convs: a direct call), 4.1e-1, 7.4e-3 (the guided loop keeps the 16 x 16 level only)
 def test_config4_guidance_7p5_full_size(ctx, nets, fp8, tol_call, tol_guided, tol_steps):
     """configs[4]: a real prompt + guidance_scale 7.5 (evaluation/predict_fvd2_denoise.py:203,227-229): the batch-2 UNet call
     with DIFFERENT uncond / cond embeddings, the CFG combine and three scheduler steps, full-size UNet.  fp8 = 1: the same rows in the
