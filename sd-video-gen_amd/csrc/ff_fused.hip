@@ -349,20 +349,38 @@ __global__ void __launch_bounds__(512, 2) ff_pair_kernel(const FfArgs a, unsigne
 
   int q = 0, slot = 0, slot_in = F_DEPTH;                  // slot of slab q; slot the next DMA goes to
   unsigned long long t_wait = 0, t_bar = 0, t_dma = 0, t_g1 = 0, t_gelu = 0, t_g2 = 0, t_all0 = 0, t_all1 = 0, t_epi = 0;
-  auto step_begin = [&]() {
-    unsigned long long u0 = 0, u1 = 0, u2 = 0, u3 = 0;
+  // A slab step = wait for the slab (counted vmcnt) + barrier, then the refill DMA of the slot F_DEPTH ahead.  The two are separate
+  // because the LATE waves (below) put matrix work between them.
+  auto step_sync = [&]() {
+    unsigned long long u0 = 0, u1 = 0, u2 = 0;
     FSTAMP(u0);
     if (q + F_DEPTH - 1 < NQ) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else wait_vm((NQ - 1 - q) * 2);
     FSTAMP(u1);
     bar();
     FSTAMP(u2);
+    t_wait += u1 - u0; t_bar += u2 - u1;
+  };
+  auto step_dma = [&]() {
+    unsigned long long u2 = 0, u3 = 0;
+    FSTAMP(u2);
     if (q + F_DEPTH < NQ) dma_slab(q + F_DEPTH, slot_in);
     FSTAMP(u3);
-    t_wait += u1 - u0; t_bar += u2 - u1; t_dma += u3 - u2;
+    t_dma += u3 - u2;
     slot_in = slot_in + 1 == P_RING ? 0 : slot_in + 1;
   };
   auto step_end = [&]() { ++q; slot = slot + 1 == P_RING ? 0 : slot + 1; };
+  // Stagger (round 5; MI355X_MICROARCH.md "two waves that run the SAME program with one barrier per block"): the eight waves walk the
+  // slabs in lock step, and the two waves of a SIMD (w and w + 4) used to reach their fragment reads, their MFMAs, the DMA issue and the
+  // GEGLU at the same time — matrix pipe idle while both read, contended while both multiply (stamps of round 4: 566 cycles per slab for
+  // 256 matrix cycles, barrier waits 18 %).  Waves 4-7 (LATE) now run half a slab behind: they carry the fragments of a slab's second k
+  // half across the barrier and multiply them FIRST in the next interval, while their SIMD partner issues its DMA and waits for its
+  // reads; then they issue their own DMA and read while the partner multiplies.  Same MFMAs into the same accumulators in the same
+  // order (bit-identical results), no extra LDS, one more fragment set live across the barrier in the late waves only.
+#ifndef FF_STAGGER
+#define FF_STAGGER 1
+#endif
+  const bool late = FF_STAGGER && wave_u >= 4;
 
   FSTAMP(t_all0);
   for (int c = 0; c < F_NCH; ++c) {
@@ -372,22 +390,34 @@ __global__ void __launch_bounds__(512, 2) ff_pair_kernel(const FfArgs a, unsigne
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc1[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    h16x8 wpend[4];                                        // late waves: the k-half-1 fragments of the previous slab
+    auto rd1 = [&](const char* sl, int kk, h16x8 (&wf)[4]) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) wf[t] = *(const h16x8*)(sl + t * 2048 + fsw[kk]);
+    };
+    auto mm1 = [&](int ks, const h16x8 (&wf)[4]) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) acc1[rt][t] = MFMA_16x16x32(wf[t], xf[rt][ks], acc1[rt][t]);
+    };
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
-      step_begin();
+      step_sync();
       unsigned long long v0 = 0, v1 = 0;
       FSTAMP(v0);
       const char* sl = smem + slot * F_SLAB;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
+      // one instruction stream for both kinds of wave (two copies of the slab body cost 113 spilled registers): the k-half-1 MFMAs sit
+      // behind a wave-uniform branch, before the DMA for the late waves (previous slab's fragments) and after the reads for the early ones
+      if (late && s > 0) mm1((s - 1) * 2 + 1, wpend);
+      step_dma();
+      {
         h16x8 wf[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) wf[t] = *(const h16x8*)(sl + t * 2048 + fsw[kk]);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int rt = 0; rt < 2; ++rt) acc1[rt][t] = MFMA_16x16x32(wf[t], xf[rt][s * 2 + kk], acc1[rt][t]);
+        rd1(sl, 0, wf);
+        mm1(s * 2, wf);
       }
+      rd1(sl, 1, wpend);
+      if (!late || s == 4) mm1(s * 2 + 1, wpend);              // (s == 4: the chunk's GEMM1 is complete before the GEGLU)
 #ifdef FF_STAMP
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
@@ -422,9 +452,22 @@ __global__ void __launch_bounds__(512, 2) ff_pair_kernel(const FfArgs a, unsigne
     t_gelu += w1 - w0;
     // ---- GEMM2: acc2[160 columns of this half] += P (32 x 64) W2p[:, chunk]^T, 3 slabs of 64 + 64 W2 rows
     h16x8 pf[2][2];
+    auto rd2 = [&](const char* sl, int kk, h16x8 (&wf)[4]) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) wf[t] = *(const h16x8*)(sl + t * 2048 + fsw[kk]);
+    };
+    auto mm2 = [&](int s, int kk, const h16x8 (&wf)[4]) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (s * 4 + t < 10) {
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) acc2[rt][s * 4 + t] = MFMA_16x16x32(wf[t], pf[rt][kk], acc2[rt][s * 4 + t]);
+        }
+      }
+    };
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-      step_begin();
+      step_sync();
       unsigned long long v0 = 0, v1 = 0;
       FSTAMP(v0);
       if (s == 0) {
@@ -436,17 +479,15 @@ __global__ void __launch_bounds__(512, 2) ff_pair_kernel(const FfArgs a, unsigne
         }
       }
       const char* sl = smem + slot * F_SLAB;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          if (s * 4 + t < 10) {
-            const h16x8 wf = *(const h16x8*)(sl + t * 2048 + fsw[kk]);
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) acc2[rt][s * 4 + t] = MFMA_16x16x32(wf, pf[rt][kk], acc2[rt][s * 4 + t]);
-          }
-        }
+      if (late && s > 0) mm2(s - 1, 1, wpend);
+      step_dma();
+      {
+        h16x8 wf[4];
+        rd2(sl, 0, wf);
+        mm2(s, 0, wf);
       }
+      rd2(sl, 1, wpend);
+      if (!late || s == 2) mm2(s, 1, wpend);
 #ifdef FF_STAMP
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)

@@ -345,10 +345,15 @@ __global__ void pack_geglu_kernel(const float* __restrict__ w, const float* __re
   }
 }
 
+// instantiations that take the wide (16-byte) tile epilogue: the dense 64 / 128-column tiles, and the 8-channel-input conv at 128 columns
+// (the VAE's conv_in at 512 x 512: 1.9 GB of output per 28-clip launch — a store-bound launch)
+template <int BN, int AMODE>
+constexpr bool kWideInst = (AMODE == A_DENSE && (BN == 64 || BN == 128)) || (AMODE == A_CONV_SMALLC && BN == 128);
+
 template <int BN, int AMODE>
 void launch_inst(const GemmArgs& g, dim3 grid, hipStream_t s) {
   constexpr int smem = 2 * (BM * 128 + BN * 128);
-  if constexpr (AMODE == A_DENSE && (BN == 64 || BN == 128)) {      // (BN = 160: 48 spilled registers in the wide form — not used there)
+  if constexpr (kWideInst<BN, AMODE>) {      // (BN = 160: 48 spilled registers in the wide form — not used there)
     if (g.act != ACT_GEGLU && !g.out_f32) { hipLaunchKernelGGL((igemm_kernel<BN, AMODE, true>), grid, dim3(256), smem, s, g); return; }
   }
   hipLaunchKernelGGL((igemm_kernel<BN, AMODE>), grid, dim3(256), smem, s, g);
@@ -372,7 +377,7 @@ void launch_bn(const GemmArgs& g, dim3 grid, hipStream_t s) {
 template <int BN, int AMODE>
 void attr_inst() {
   HIP_OK(hipFuncSetAttribute((const void*)igemm_kernel<BN, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM * 128 + BN * 128)));
-  if constexpr (AMODE == A_DENSE && (BN == 64 || BN == 128))
+  if constexpr (kWideInst<BN, AMODE>)
     HIP_OK(hipFuncSetAttribute((const void*)igemm_kernel<BN, AMODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM * 128 + BN * 128)));
 }
 template <int BN>
