@@ -338,11 +338,43 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
   //         s + 1 and the previous patch piece have landed; lgkmcnt(0).
   if (MODE == 2 && cc_begin < cc_end) {
     const int grp = wave_u >> 2;
+    // HALO_NOPAD = 1: no padding DMAs (round 5, VERDICT r04 #5: the scheme of conv_halo_fp8.hip).  The counted vmcnt of a load segment only
+    // has to leave THIS wave's just-issued DMAs in flight — a wave's counter sees its own operations, in order — so the waves need not
+    // issue equal numbers: at BN = 160 the slab's last 32 rows are DMA'd by waves 0-3 alone, the 6th patch piece (32 slots) by wave 0
+    // alone, instead of every other wave issuing those instructions with an out-of-range source into the sink region (10 of the 33 DMAs of
+    // a 64-channel chunk in waves 4-7).  Built, bit-identical, and SLOWER on every BN = 160 shape of the UNet (same box, 28 clips,
+    // profiles/r05_halo_nopad_ab.txt): 64^2 x 320 -> 320 0.187 -> 0.193 ms, 32^2 x 1920 -> 640 0.459 -> 0.478, 16^2 x 2560 -> 1280
+    // 0.295 -> 0.311 (-3 ... -5 %); BN = 128 shapes unchanged.  A reading, not a measurement: with unequal DMA counts the two wave
+    // groups' load segments differ in length; the second group's shorter segment cannot shorten the step (the barrier waits for the
+    // first group's), it only shifts its MFMAs against the first group's.  The padding DMAs stay (HALO_NOPAD 0).
+#ifndef HALO_NOPAD
+#define HALO_NOPAD 0
+#endif
+    const bool tail_w = B_TAIL && wave_u < 4;              // this wave carries a piece of the slab's 32-row tail
+    auto dma_w_own = [&](int cc, int tap, int stage) {
+      if (!HALO_NOPAD) { dma_weights(cc, tap, stage); return; }
+      const unsigned dst = lds0 + OFF_B + stage * B_BYTES + wave_u * 1024;
+      const int soff = (tap * g.Cin + cc * 64) * 2;
 #pragma unroll
-    for (int i = 0; i < NPD; ++i) dma_patch_piece(cc_begin, 0, i);
-    dma_weights(cc_begin, 0, 0);
-    dma_weights(cc_begin, 1, 1);
-    wait_vm(NW);                                          // patch and slab 0 have landed; slab 1 may be in flight
+      for (int i = 0; i < BIT; ++i) dma16(srdB, b_voff[i], soff, dst + i * 8192);
+      if (tail_w) dma16(srdB, b_voff_tail, soff, dst + BIT * 8192);
+    };
+    auto dma_p_own = [&](int cc, int buf, int i) {          // patch piece i; the last piece exists on wave 0 only
+      if (!HALO_NOPAD) { dma_patch_piece(cc, buf, i); return; }
+      const unsigned dst = lds0 + buf * PBUF + wave_u * 1024;
+      const unsigned voff = patch_voff(i);
+      if (i < NPD - 1) dma16(srdA, voff, cc * 128, dst + i * 8192);
+      else if (wave_u == 0 && lane < 32) dma16(srdA, voff, cc * 128, dst + (NPD - 1) * 8192);
+    };
+    // DMAs this wave issues for a slab / for patch piece i
+    const int nw_own = HALO_NOPAD ? BIT + (tail_w ? 1 : 0) : NW;
+    auto np_own = [&](int i) { return (!HALO_NOPAD || i < NPD - 1 || wave_u == 0) ? 1 : 0; };
+#pragma unroll
+    for (int i = 0; i < NPD; ++i) dma_p_own(cc_begin, 0, i);
+    dma_w_own(cc_begin, 0, 0);
+    dma_w_own(cc_begin, 1, 1);
+    wait_vm(nw_own);                                      // patch and slab 0 have landed; slab 1 may be in flight
+
     bar();
     if (grp == 1) bar();
 
@@ -384,9 +416,9 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
         h16x8 x0[MT], x1[MT], w0[NT], w1[NT];
         rd_x(tap, 0, x0); rd_w(tap % NWS, 0, w0);
         rd_x(tap, 1, x1); rd_w(tap % NWS, 1, w1);
-        if (more_w) dma_weights(wcc, wtap, (tap + 2) % NWS);
-        if (pp) dma_patch_piece(cc + 1, pbuf ^ 1, tap);
-        wait_vm((more_w ? NW : 0) + (pp ? 1 : 0));
+        if (more_w) dma_w_own(wcc, wtap, (tap + 2) % NWS);
+        if (pp) dma_p_own(cc + 1, pbuf ^ 1, tap);
+        wait_vm((more_w ? nw_own : 0) + (pp ? np_own(tap) : 0));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         bar();
         __builtin_amdgcn_sched_barrier(0);
