@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=${1:-r02}; clips=${2:-28}
 out=gpurun_out/$tag; rm -rf $out; mkdir -p $out
 echo "== kernel trace, one group of $clips clips alone"
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ktrace -o bench -- python3 bench.py --steps 1 --warmup 1 --clips $clips --streams 1 --no-cpu-baseline > $out/bench_under_rocprof.log 2>&1 || { echo "FAILED kernel trace"; exit 1; }
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ktrace -o bench -- python3 bench.py --steps 1 --warmup 1 --clips $clips --streams 1 --no-cpu-baseline --no-fp8-extra > $out/bench_under_rocprof.log 2>&1 || { echo "FAILED kernel trace"; exit 1; }
 find $out/ktrace -name "*kernel_stats.csv" -exec cp {} $out/${tag}_kernel_stats_one_group.csv \;
 grep "^{" $out/bench_under_rocprof.log > $out/${tag}_bench_line_under_rocprof.json
 rm -rf $out/ktrace
