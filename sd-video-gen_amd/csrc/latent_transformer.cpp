@@ -325,6 +325,133 @@ static void xf_forward_walk(svg_ctx* ctx, XfModel* m, const float* src, const fl
   xf_walk_launch(ctx, ops.data(), (int)ops.size(), Mx, xf_walk_lds_bytes(Mx, std::max(Ts, Tt), std::max(Ts, Tt), hd), s);
 }
 
+// ---- the small-row form (xf_walk.hip: xf_walk_small_kernel): at most 8 rows per forward — single-clip sampling ------------------------
+// Stages per encoder layer: in_proj (LayerNorm of its input folded in; q, k, v as column blocks of one stage) | attention | out_proj + bias +
+// residual | linear1 (LayerNorm 1 folded in) + bias + ReLU | linear2 + bias + residual — 5 device-wide barriers instead of 9; a decoder layer
+// has 8 instead of 16 (the K / V projection of the encoder memory rides on the self-attention in_proj's barrier, with the encoder's two final
+// LayerNorms folded into its input).  What flows between layers is the PRE-LayerNorm sum; the consumer normalises its own LDS copy of the rows
+// and publishes the normalised rows (Yln) for the residual of the stage after next.
+static bool xf_walk_small_usable(const XfModel* m, int B, int Ts, int Tt, hipStream_t s) {
+  // $SVG_XF_WALK_SMALL: 1 always (where the shapes fit), 0 never, unset: where it is ahead of the split-K walk — d_model <= 1024 (measured, one
+  // clip of 6 tokens, profiles/r05_walk_small_vs_splitk.txt: d = 256 0.789 -> 0.618 ms, 512 0.811 -> 0.637, 1024 0.897 -> 0.785; d = 2048
+  // 1.053 vs 1.059: there a stage is bound by the 64 KB of weights a compute unit has to pull per column block, not by the stage count)
+  const int64_t mode = svg_env_i64("SVG_XF_WALK_SMALL", -1);
+  if (!xf_walk_enabled(s) || mode == 0 || (mode < 0 && m->d_model > 1024)) return false;
+  const int d = m->d_model, hd = d / m->heads;
+  if (m->text_dim != 0 || B * std::max(Ts, Tt) > kWalkSmallRows || hd % 4) return false;
+  for (int K : {d, m->ffn, m->d_lat})
+    if (K % 256 != 0 || K < 256 || K > kWalkSmallMaxK) return false;
+  if (4 + 7 * m->enc_layers + 14 * m->dec_layers + 4 > kWalkMaxOps) return false;       // column blocks of wide matrices count as stages
+  const int T = std::max(Ts, Tt);
+  const int64_t lds = std::max<int64_t>((int64_t)kWalkSmallRows * (kWalkSmallMaxK * 4 + 64) + 4 * kWalkSmallMaxK * 4, ((int64_t)3 * T * hd + 2 * 32 * 33 + 32) * 4);
+  return xf_walk_grid() >= 8 && xf_walk_available(kWalkSmallRows, lds);
+}
+
+static void xf_forward_walk_small(svg_ctx* ctx, XfModel* m, const float* src, const float* tgt, int B, int Ts, int Tt, const float* mask,
+                                  const int32_t* pe_row, float* out_tb, hipStream_t s, const float* src_pad, const float* tgt_pad) {
+  const int d = m->d_model, ffn = m->ffn, d_lat = m->d_lat, heads = m->heads, hd = d / heads;
+  const int Ms = Ts * B, Mt = Tt * B, Mx = std::max(Ms, Mt);
+  const bool same = (tgt == src && Ts == Tt);
+  float* xs_e = ctx->arena.get<float>((int64_t)Ms * d);                   // embeddings
+  float* xt_e = same ? xs_e : ctx->arena.get<float>((int64_t)Mt * d);
+  float* qkv = ctx->arena.get<float>((int64_t)Mx * 3 * d);
+  float* kvm = ctx->arena.get<float>((int64_t)Ms * 2 * d);
+  float* o = ctx->arena.get<float>((int64_t)Mx * d);
+  float* h = ctx->arena.get<float>((int64_t)Mx * ffn);
+  float* pA = ctx->arena.get<float>((int64_t)Mx * d);                     // pre-LayerNorm sums: attention block, cross-attention block,
+  float* pB = ctx->arena.get<float>((int64_t)Mx * d);
+  float* pC = ctx->arena.get<float>((int64_t)Mx * d);                     // feed-forward block (the next layer's input)
+  float* pM = ctx->arena.get<float>((int64_t)Ms * d);                     // the last encoder layer's (the memory, before its two norms)
+  float* lA = ctx->arena.get<float>((int64_t)Mx * d);                     // the normalised rows the consumers publish
+  float* lB = ctx->arena.get<float>((int64_t)Mx * d);
+  float* lC = ctx->arena.get<float>((int64_t)Mx * d);
+  if (!SVG_LAUNCHING(ctx)) return;
+  const int blk = 8 * xf_walk_grid();                                     // widest column block a stage serves (8 columns per workgroup)
+
+  std::vector<WalkOp> ops;
+  ops.reserve(128);
+  struct Ln { const float* g1 = nullptr; const float* b1 = nullptr; const float* g2 = nullptr; const float* b2 = nullptr; float* Yln = nullptr; };
+  // Y[:, 0..N) = act(LN(X) W^T + bias) (+ res); first block of a stage: barrier (unless `nobar`), X staged and normalised; further blocks reuse it
+  auto gemmf = [&](const float* X, int ld, int M, int K, const float* W, const float* bias, int N, float* Y, int ldy, const Ln& ln, bool relu,
+                   const float* res, int ld_res, bool bar) -> WalkOp& {
+    size_t first = ops.size();
+    for (int n0 = 0; n0 < N; n0 += blk) {
+      WalkOp op{};
+      op.kind = WK_GEMMF; op.bar = (n0 == 0 && bar) ? 1 : 0; op.reuse_x = n0 == 0 ? 0 : 1;
+      op.M = M; op.N = std::min(blk, N - n0); op.K = K; op.ld = ld; op.X = X; op.W = W + (int64_t)n0 * K; op.bias = bias ? bias + n0 : nullptr;
+      op.Y = Y + n0; op.ldy = ldy; op.res = res ? res + n0 : nullptr; op.ld_res = ld_res; op.relu = relu ? 1 : 0; op.eps = 1e-5f;
+      if (n0 == 0) { op.g1 = ln.g1; op.b1 = ln.b1; op.g2 = ln.g2; op.b2 = ln.b2; op.Yln = ln.Yln; }
+      ops.push_back(op);
+    }
+    return ops[first];
+  };
+  auto attn = [&](const float* q, int q_ld, int64_t q_span, const float* k, const float* v, int kv_ld, int64_t kv_span, int Tq, int Tk, const float* msk,
+                  const float* kpad) {
+    WalkOp op{};
+    op.kind = WK_ATTN; op.bar = 1; op.Tq = Tq; op.Tk = Tk; op.B = B; op.heads = heads; op.hd = hd;
+    op.q_ld = q_ld; op.kv_ld = kv_ld; op.q_span = (int)q_span; op.kv_span = (int)kv_span;
+    op.qs = q; op.ks = k; op.vs = v; op.mask = msk; op.kpad = kpad; op.Y = o;
+    ops.push_back(op);
+  };
+  auto embed = [&](const float* x, int T, float* Y, bool bar) {
+    WalkOp& op = gemmf(x, d_lat, B * T, d_lat, m->emb_w, m->emb_b, d, Y, d, Ln{}, false, nullptr, 0, bar);
+    int n0 = 0;
+    for (size_t i = &op - ops.data(); i < ops.size(); ++i) {          // every column block: rows in (b, t) order, out (t, b); scale + PE
+      ops[i].perm = 1; ops[i].B = B; ops[i].T = T; ops[i].scale = sqrtf((float)d); ops[i].pe = m->pe + n0; ops[i].ld_res = d; ops[i].pe_row = pe_row;
+      n0 += ops[i].N;
+    }
+  };
+
+  embed(src, Ts, xs_e, false);                                           // the launch's inputs: no barrier before the first stage
+  if (!same) embed(tgt, Tt, xt_e, false);
+  // ---- encoder.  `cur` = the layer's input rows before their LayerNorm (`cln`: its parameters; none for the embedding), `curl` = where
+  // the normalised rows are published (the embedding itself when there is no norm)
+  const float* cur = xs_e; Ln cln; const float* curl = xs_e;
+  for (int i = 0; i < m->enc_layers; ++i) {
+    const XfModel::LayerW& w = m->enc_w[i];
+    const bool last = (i + 1 == m->enc_layers);
+    Ln l0 = cln; if (l0.g1) { l0.Yln = lA; curl = lA; }
+    gemmf(cur, d, Ms, d, w.in_w, w.in_b, 3 * d, qkv, 3 * d, l0, false, nullptr, 0, true);
+    attn(qkv, 3 * d, (int64_t)Ms * 3 * d, qkv + d, qkv + 2 * d, 3 * d, (int64_t)Ms * 3 * d - d, Ts, Ts, nullptr, src_pad);
+    gemmf(o, d, Ms, d, w.out_w, w.out_b, d, pA, d, Ln{}, false, curl, d, true);
+    gemmf(pA, d, Ms, d, w.l1_w, w.l1_b, ffn, h, ffn, Ln{w.n_w[0], w.n_b[0], nullptr, nullptr, lB}, true, nullptr, 0, true);
+    float* pout = last ? pM : pC;
+    gemmf(h, ffn, Ms, ffn, w.l2_w, w.l2_b, d, pout, d, Ln{}, false, lB, d, true);
+    cur = pout; cln = Ln{w.n_w[1], w.n_b[1], nullptr, nullptr, nullptr}; curl = nullptr;
+  }
+  // the memory = encoder.norm(norm2(last sum)) (or encoder.norm(embedding) for an empty encoder): folded into every consumer
+  Ln lmem = m->enc_layers ? Ln{cln.g1, cln.b1, m->encn_w, m->encn_b, nullptr} : Ln{m->encn_w, m->encn_b, nullptr, nullptr, nullptr};
+  const float* memp = cur;
+  // ---- decoder
+  cur = xt_e; cln = Ln{}; curl = xt_e;
+  for (int i = 0; i < m->dec_layers; ++i) {
+    const XfModel::LayerW& w = m->dec_w[i];
+    Ln l0 = cln; if (l0.g1) { l0.Yln = lA; curl = lA; }
+    gemmf(cur, d, Mt, d, w.in_w, w.in_b, 3 * d, qkv, 3 * d, l0, false, nullptr, 0, true);
+    gemmf(memp, d, Ms, d, w.cin_w + (int64_t)d * d, w.cin_b + d, 2 * d, kvm, 2 * d, lmem, false, nullptr, 0, false);     // K, V of the memory
+    attn(qkv, 3 * d, (int64_t)Mt * 3 * d, qkv + d, qkv + 2 * d, 3 * d, (int64_t)Mt * 3 * d - d, Tt, Tt, mask, tgt_pad);
+    gemmf(o, d, Mt, d, w.out_w, w.out_b, d, pA, d, Ln{}, false, curl, d, true);
+    gemmf(pA, d, Mt, d, w.cin_w, w.cin_b, d, qkv, d, Ln{w.n_w[0], w.n_b[0], nullptr, nullptr, lB}, false, nullptr, 0, true);   // q of the cross-attention
+    attn(qkv, d, (int64_t)Mt * d, kvm, kvm + d, 2 * d, (int64_t)Ms * 2 * d, Tt, Ts, nullptr, nullptr);
+    gemmf(o, d, Mt, d, w.cout_w, w.cout_b, d, pB, d, Ln{}, false, lB, d, true);
+    gemmf(pB, d, Mt, d, w.l1_w, w.l1_b, ffn, h, ffn, Ln{w.n_w[1], w.n_b[1], nullptr, nullptr, lC}, true, nullptr, 0, true);
+    gemmf(h, ffn, Mt, ffn, w.l2_w, w.l2_b, d, pC, d, Ln{}, false, lC, d, true);
+    cur = pC; cln = Ln{w.n_w[2], w.n_b[2], nullptr, nullptr, nullptr}; curl = nullptr;
+  }
+  Ln lout = m->dec_layers ? Ln{cln.g1, cln.b1, m->decn_w, m->decn_b, nullptr} : Ln{m->decn_w, m->decn_b, nullptr, nullptr, nullptr};
+  gemmf(cur, d, Mt, d, m->out_w, m->out_b, d_lat, out_tb, d_lat, lout, false, nullptr, 0, true);
+  double flops = 0, bytes = 0;
+  for (const WalkOp& op : ops)
+    if (op.kind == WK_GEMMF) {
+      flops += 2.0 * op.M * (double)op.N * op.K;
+      bytes += 4.0 * ((double)op.N * op.K + (op.reuse_x ? 0.0 : (double)op.M * op.K) + (double)op.M * op.N);
+    }
+  ProfScope ps(ctx, PK_XF_GEMM, s, flops, bytes, "walk_small");
+  const int T = std::max(Ts, Tt);
+  xf_walk_small_launch(ctx, ops.data(), (int)ops.size(),
+                       std::max<int64_t>((int64_t)kWalkSmallRows * (kWalkSmallMaxK * 4 + 64) + 4 * kWalkSmallMaxK * 4, ((int64_t)3 * T * hd + 2 * 32 * 33 + 32) * 4), s);
+}
+
 void XfModel::forward(svg_ctx* ctx, const float* src, const float* tgt, int B, int Ts, int Tt, const float* mask,
                       const int32_t* pe_row, float* out, hipStream_t s, const float* text, const float* src_pad, const float* tgt_pad) {
   SVG_CHECK(ready, "transformer: svg_finalize has not been called");
@@ -339,9 +466,13 @@ void XfModel::forward(svg_ctx* ctx, const float* src, const float* tgt, int B, i
   // kernels, which stream W once for up to 336 rows (SVG_XF_WALK_SPLIT=1: through the walk in chunks).
   const int Bw = std::max(1, (int)std::min<int64_t>(kWalkMaxRows, svg_env_i64("SVG_XF_WALK_ROWS", 96)) / Tmax);
   const bool walk = xf_walk_usable(this, std::min(B, Bw), Ts, Tt, s) && (B <= Bw || svg_env_i64("SVG_XF_WALK_SPLIT", 0) != 0);
+  // at most 8 rows (one clip): the small-row form — whole-K GEMM stages with LayerNorm / bias / residual folded in, 5 + 8 instead of 9 + 16
+  // stages per encoder / decoder layer
+  const bool walk_small = walk && !text && xf_walk_small_usable(this, B, Ts, Tt, s);
   const int Bc = walk ? Bw : std::max(1, 336 / Tmax);
   auto chunk = [&](const float* srcc, const float* tgtc, int bc, const int32_t* rows, float* dst, const float* textc, const float* sp, const float* tp) {
-    if (walk) xf_forward_walk(ctx, this, srcc, tgtc, bc, Ts, Tt, mask, rows, dst, s, textc, sp, tp);
+    if (walk_small) xf_forward_walk_small(ctx, this, srcc, tgtc, bc, Ts, Tt, mask, rows, dst, s, sp, tp);
+    else if (walk) xf_forward_walk(ctx, this, srcc, tgtc, bc, Ts, Tt, mask, rows, dst, s, textc, sp, tp);
     else xf_forward_chunk(ctx, this, srcc, tgtc, bc, Ts, Tt, mask, rows, dst, s, textc, sp, tp);
   };
   run_planned(ctx, [&]() {

@@ -12,6 +12,10 @@ enum WalkKind : int {
   WK_LN = 2,      // Y = LN(sum_z slab[z] + bias + res) g1 + b1;  Y2 = LN(Y) g2 + b2          (a row per workgroup)
   WK_ATTN = 3,    // o = softmax(q k^T / sqrt(hd) + mask + kpad) v per (batch row, head)
   WK_EMBED = 4,   // Y[t][b] = [sum_z slab[z][b][t] + bias | text[b]] * scale + pe[pe_row[b]]
+  // small-row launch (xf_walk_small_kernel, at most 8 rows): a whole-K GEMM with the LayerNorm of its input and its bias / ReLU / residual
+  // (or the embedding's scale + positional row) folded in — no split-K slabs, so no reduce stages:
+  //   x = LN2(LN1(X)) (each optional; Yln <- the normalised rows);  Y[m][n] = act(x[m] . W[n] + bias[n]) (+ res[m][n])
+  WK_GEMMF = 5,
 };
 
 struct alignas(16) WalkOp {
@@ -31,6 +35,10 @@ struct alignas(16) WalkOp {
   const float* mask; const float* kpad;
   // EMBED
   const float* pe; const int32_t* pe_row; const float* text; int d_txt, T; float scale;
+  // GEMMF: X rows are (b, t) batch-first when perm (the launch's inputs), output rows (t, b); ldy / ld_res: row strides of Y / res;
+  // reuse_x: the X tile (and its LayerNorm) of the previous stage is still in LDS; Yln: where the normalised rows go (M x K)
+  int ldy, ld_res, reuse_x, perm;
+  float* Yln;
 };
 
 // rows one launch serves (the accumulator tiles of a workgroup: 11 x 16) and the shapes a GEMM stage takes
@@ -44,6 +52,12 @@ bool xf_walk_available(int rows, int64_t lds_bytes);
 // ops: host array (copied to the device through a pinned ring); the launch is ordered after the previous walk of this process on any
 // stream (two resident walks could starve each other of compute units while spinning at their barriers)
 void xf_walk_launch(svg_ctx* ctx, const WalkOp* ops, int n_ops, int rows, int64_t lds_bytes, hipStream_t s);
+// the small-row form (WK_GEMMF / WK_ATTN stages only): at most kWalkSmallRows rows, K <= 2048 in multiples of 128, at most 8 output
+// columns per workgroup and stage (N <= 8 x workgroups: the host cuts wider matrices into column blocks)
+constexpr int kWalkSmallRows = 8;
+constexpr int kWalkSmallMaxK = 2048;
+int xf_walk_grid();                                     // workgroups of a launch on the current device (0: walk unavailable)
+void xf_walk_small_launch(svg_ctx* ctx, const WalkOp* ops, int n_ops, int64_t lds_bytes, hipStream_t s);
 void xf_walk_init_device();
 // false when the layer-walking launch must not be used now: off for this device ($SVG_XF_WALK=0, ranks sharing the device, an earlier
 // give-up, a device that cannot hold the grid) or the stream is being captured

@@ -127,6 +127,88 @@ __device__ __forceinline__ bool wk_barrier(WalkSync* sy, unsigned k, unsigned nw
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// ---- attention stage (shared by both walking kernels): q (Tq*B rows, stride q_ld) and k, v (Tk*B rows, stride kv_ld) are projections
+// already reduced (+ bias) by the stage before; one (batch row, head) job per workgroup at a time
+template <class Op>
+__device__ __forceinline__ void wk_attention_stage(const Op& op, char* smem, unsigned nwg) {
+  const int tid = threadIdx.x, lane = tid & 63;
+
+  // q (Tq*B rows, stride q_ld) and k, v (Tk*B rows, stride kv_ld): projections already reduced (+ bias) by the stage before
+  const int Tq = op.Tq, Tk = op.Tk, B = op.B, heads = op.heads, hd = op.hd;
+  const int d = heads * hd, hv = hd / 4;
+  float* sq = (float*)smem;
+  float* sk = sq + Tq * hd;
+  float* sv = sk + Tk * hd;
+  float* sc = sv + Tk * hd;                              // [32][33]
+  float* smk = sc + 32 * 33;                             // [32][33] the (Tq, Tk) mask
+  float* skp = smk + 32 * 33;                            // [32] this batch row's key-padding bias
+  const float scale = rsqrtf((float)hd);
+  const __amdgpu_buffer_rsrc_t rQ = rsrc_of(op.qs, (unsigned)op.q_span * 4u), rK = rsrc_of(op.ks, (unsigned)op.kv_span * 4u),
+                               rV = rsrc_of(op.vs, (unsigned)(op.kv_span - (int)(op.vs - op.ks)) * 4u), rO = rsrc_of(op.Y, (unsigned)(Tq * B * d) * 4u);
+  for (int job = (int)blockIdx.x; job < B * heads; job += (int)nwg) {
+    const int b = job / heads, hh = job - b * heads;
+    __syncthreads();                                     // the previous job's LDS reads are done
+    for (int idx = tid; idx < Tq * Tk; idx += WK_THREADS) smk[(idx / Tk) * 33 + idx % Tk] = op.mask ? ldr1(op.mask, Tq * Tk, idx) : 0.f;
+    if (tid < Tk) skp[tid] = op.kpad ? ldr1(op.kpad, B * Tk, b * Tk + tid) : 0.f;
+    for (int idx0 = 0; idx0 < (Tq + 2 * Tk) * hv; idx0 += 8 * WK_THREADS) {
+      f32x4 a[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {                      // up to 8 rounds' worth of loads in flight at once
+        const int idx = idx0 + i * WK_THREADS + tid;
+        const int r = idx / hv, c = (idx - r * hv) * 4;
+        unsigned off = INVALID;
+        if (r < Tq) off = (unsigned)(((r * B + b) * op.q_ld + hh * hd + c) * 4);
+        else if (r < Tq + 2 * Tk) off = (unsigned)((((r < Tq + Tk ? r - Tq : r - Tq - Tk) * B + b) * op.kv_ld + hh * hd + c) * 4);
+        a[i] = r < Tq ? ldc(rQ, off) : (r < Tq + Tk ? ldc(rK, off) : ldc(rV, off));
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int idx = idx0 + i * WK_THREADS + tid;
+        if (idx < (Tq + 2 * Tk) * hv) *(f32x4*)(sq + idx * 4) = a[i];          // sq, sk, sv are contiguous: row r at r * hd
+      }
+    }
+    __syncthreads();
+    // scores: a 16-lane row per (i, j) pair, lane l takes channels 4 l + 64 k; the row sum by four DPP steps (a 64-lane butterfly of
+    // ds_bpermute shuffles per pair cost ~0.4 us each: stamps)
+    {
+      const int rowi = lane >> 4, l = lane & 15;
+      for (int p0 = (tid >> 6) * 4; p0 < Tq * Tk; p0 += 16) {
+        const int p = p0 + rowi;
+        const bool ok = p < Tq * Tk;
+        const int pp = ok ? p : 0;
+        const int i = pp / Tk, j = pp - i * Tk;
+        f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 4 * l; c < hd; c += 64) a4 += *(const f32x4*)(sq + i * hd + c) * *(const f32x4*)(sk + j * hd + c);
+        float sacc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+        auto dpp_add = [&](auto ctrl) {
+          sacc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sacc), decltype(ctrl)::value, 0xf, 0xf, true));
+        };
+        dpp_add(std::integral_constant<int, 0xB1>{});     // quad_perm [1,0,3,2]
+        dpp_add(std::integral_constant<int, 0x4E>{});     // quad_perm [2,3,0,1]
+        dpp_add(std::integral_constant<int, 0x141>{});    // row_half_mirror
+        dpp_add(std::integral_constant<int, 0x140>{});    // row_mirror
+        if (ok && l == 0) sc[i * 33 + j] = sacc * scale + smk[i * 33 + j] + skp[j];
+      }
+    }
+    __syncthreads();
+    if (tid < Tq) {
+      float mx = -INFINITY;
+      for (int j = 0; j < Tk; ++j) mx = fmaxf(mx, sc[tid * 33 + j]);
+      float sum = 0.f;
+      for (int j = 0; j < Tk; ++j) { const float e = expf(sc[tid * 33 + j] - mx); sc[tid * 33 + j] = e; sum += e; }
+      const float inv = 1.f / sum;
+      for (int j = 0; j < Tk; ++j) sc[tid * 33 + j] *= inv;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < Tq * hv; idx += WK_THREADS) {
+      const int i = idx / hv, c = (idx - i * hv) * 4;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < Tk; ++j) a += sc[i * 33 + j] * *(const f32x4*)(sv + j * hd + c);
+      stc(rO, (unsigned)(((i * B + b) * d + hh * hd + c) * 4), a);
+    }
+  }
+}
+
 template <int MT>
 __global__ void __launch_bounds__(WK_THREADS) xf_walk_kernel(const WalkOp* __restrict__ ops_g, int n_ops, WalkSync* sy, unsigned* host_abort, unsigned long long* stamps,
                                                               unsigned expect_wg, unsigned long long timeout) {
@@ -398,82 +480,212 @@ __global__ void __launch_bounds__(WK_THREADS) xf_walk_kernel(const WalkOp* __res
         stc(rY, (unsigned)(((t * B + b) * d + c) * 4), a);
       }
     } else if (kind == WK_ATTN) {
-      // q (Tq*B rows, stride q_ld) and k, v (Tk*B rows, stride kv_ld): projections already reduced (+ bias) by the stage before
-      const int Tq = op.Tq, Tk = op.Tk, B = op.B, heads = op.heads, hd = op.hd;
-      const int d = heads * hd, hv = hd / 4;
-      float* sq = (float*)smem;
-      float* sk = sq + Tq * hd;
-      float* sv = sk + Tk * hd;
-      float* sc = sv + Tk * hd;                              // [32][33]
-      float* smk = sc + 32 * 33;                             // [32][33] the (Tq, Tk) mask
-      float* skp = smk + 32 * 33;                            // [32] this batch row's key-padding bias
-      const float scale = rsqrtf((float)hd);
-      const __amdgpu_buffer_rsrc_t rQ = rsrc_of(op.qs, (unsigned)op.q_span * 4u), rK = rsrc_of(op.ks, (unsigned)op.kv_span * 4u),
-                                   rV = rsrc_of(op.vs, (unsigned)(op.kv_span - (int)(op.vs - op.ks)) * 4u), rO = rsrc_of(op.Y, (unsigned)(Tq * B * d) * 4u);
-      for (int job = (int)blockIdx.x; job < B * heads; job += (int)nwg) {
-        const int b = job / heads, hh = job - b * heads;
-        __syncthreads();                                     // the previous job's LDS reads are done
-        for (int idx = tid; idx < Tq * Tk; idx += WK_THREADS) smk[(idx / Tk) * 33 + idx % Tk] = op.mask ? ldr1(op.mask, Tq * Tk, idx) : 0.f;
-        if (tid < Tk) skp[tid] = op.kpad ? ldr1(op.kpad, B * Tk, b * Tk + tid) : 0.f;
-        for (int idx0 = 0; idx0 < (Tq + 2 * Tk) * hv; idx0 += 8 * WK_THREADS) {
-          f32x4 a[8];
+      wk_attention_stage(op, smem, nwg);
+    }
+    WSTAMP(3);
+  }
+}
+
+// ---- the small-row kernel (at most 8 rows: single-clip sampling, `python -m prediction.predict`) --------------------------------------------
+// At 6 rows the split-K walk above is a chain of 168 dependent stages of ~6 us, and what a stage costs is its device-wide barrier and one
+// coherent round trip, not its bytes.  Here a GEMM stage is NOT split over K: workgroup w owns ceil(N / #workgroups) <= 8
+// output columns and reads whole rows of W for them (64 KB at 2048 x 2048: the same bytes per workgroup as a 128 x 128 tile), so its result is
+// complete — bias, ReLU, the residual add and the embedding's scale + positional row ride in the GEMM's epilogue and the `reduce` stages are
+// gone; and it holds ALL (<= 8) rows of X in LDS, so the LayerNorm in front of a GEMM is computed by the consumer on its own copy of the rows
+// (every workgroup redundantly: 8 x 2048 values) and the `reduce + LayerNorm` stages are gone too: 5 instead of 9 stages per encoder layer,
+// 8 instead of 16 per decoder layer.
+// Matrix tile.  v_mfma_f32_16x16x4_f32 with 8 valid weight rows and <= 8 valid X rows would run 19 % full; instead the two halves of a wave's K
+// range share one tile: A row (c, h) = weight column c over k-half h, B column (m, h') = X row m over k-half h'; the diagonal blocks h = h' are
+// the two halves' partial sums of out[m][c], the off-diagonal blocks are discarded.  Half the MFMAs per wave, all 64 lanes load weights.
+// Four waves split K; eight partial sums per output meet in LDS in a fixed order.
+constexpr int SM_STEPS = kWalkSmallMaxK / 128;          // 16-wide k steps of a wave's half range (K / 128)
+constexpr int SM_PAD = 64;                              // bytes between X rows in LDS (rows would otherwise share all banks)
+constexpr int SM_GB = kWalkSmallRows * (kWalkSmallMaxK * 4 + SM_PAD);     // LDS offset of the LayerNorm parameters (4 vectors of K floats)
+
+__global__ void __launch_bounds__(WK_THREADS) xf_walk_small_kernel(const WalkOp* __restrict__ ops_g, int n_ops, WalkSync* sy, unsigned* host_abort,
+                                                                    unsigned expect_wg, unsigned long long timeout) {
+  typedef const __attribute__((address_space(4))) WalkOp* cops_t;
+  const cops_t ops = (cops_t)ops_g;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int dead;
+  __shared__ __attribute__((aligned(16))) float red[4][2][8][8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int c8 = l15 & 7, h = l15 >> 3;                 // operand row / column (c or m, k-half)
+  const unsigned nwg = gridDim.x;
+  unsigned bar_k = 0;
+  if (tid == 0) dead = 0;
+  __syncthreads();
+
+  // ---- the weight stream: this workgroup's column block of the next GEMM stage, requested one stage ahead
+  f32x4 wn[SM_STEPS], wc[SM_STEPS];
+  auto load_w = [&](int s) {
+    const int N = ops[s].N, K = ops[s].K;
+    const int ct = (N + (int)nwg - 1) / (int)nwg;
+    const int n = (int)blockIdx.x * ct + c8;
+    const bool okn = c8 < ct && n < N;
+    const __amdgpu_buffer_rsrc_t rW = rsrc_of(ops[s].W, (unsigned)(N * K) * 4u);
+    const int kh = wave * (K >> 2) + h * (K >> 3) + 4 * lq;
+    const int steps = K >> 7;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {                      // up to 8 rounds' worth of loads in flight at once
-            const int idx = idx0 + i * WK_THREADS + tid;
-            const int r = idx / hv, c = (idx - r * hv) * 4;
-            unsigned off = INVALID;
-            if (r < Tq) off = (unsigned)(((r * B + b) * op.q_ld + hh * hd + c) * 4);
-            else if (r < Tq + 2 * Tk) off = (unsigned)((((r < Tq + Tk ? r - Tq : r - Tq - Tk) * B + b) * op.kv_ld + hh * hd + c) * 4);
-            a[i] = r < Tq ? ldc(rQ, off) : (r < Tq + Tk ? ldc(rK, off) : ldc(rV, off));
-          }
+    for (int st = 0; st < SM_STEPS; ++st) {
+      const unsigned off = (okn && st < steps) ? (unsigned)((n * K + kh + 16 * st) * 4) : INVALID;
+      wn[st] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, off, 0, 0));
+    }
+  };
+  int js = ops[0].kind == WK_GEMMF ? 0 : ops[0].next_gemm;
+  if (js < n_ops) load_w(js);
+
+  for (int s = 0; s < n_ops; ++s) {
+    const auto& op = ops[s];
+    if (op.bar) {
+      wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      ++bar_k;
+      if (tid == 0 && !wk_barrier(sy, bar_k, expect_wg, timeout)) {
+        dead = 1;
+        __hip_atomic_store(host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      __syncthreads();
+      if (dead) {                                        // gave up: the final stage's output becomes NaN (see xf_walk_kernel)
+        const auto& last = ops[n_ops - 1];
+        const __amdgpu_buffer_rsrc_t rL = rsrc_of(last.Y, (unsigned)((last.M - 1) * last.ldy + last.N) * 4u);
+        const unsigned qn = 0x7FC00000u;
+        for (int v = (int)blockIdx.x * WK_THREADS + tid; v < last.M * last.N; v += (int)nwg * WK_THREADS)
+          __builtin_amdgcn_raw_buffer_store_b32(qn, rL, (unsigned)(((v / last.N) * last.ldy + v % last.N) * 4), 0, SC1);
+        return;
+      }
+    }
+    if (op.kind == WK_ATTN) {
+      wk_attention_stage(op, smem, nwg);
+      continue;
+    }
+    // ---- WK_GEMMF
+    const int M = op.M, N = op.N, K = op.K;
+    const int rowb = K * 4 + SM_PAD;                      // bytes per X row in LDS
+    const int steps = K >> 7;
+    // wc <- wn through opaque moves (as in xf_walk_kernel: keeps the request of the NEXT block in flight across this stage)
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int idx = idx0 + i * WK_THREADS + tid;
-            if (idx < (Tq + 2 * Tk) * hv) *(f32x4*)(sq + idx * 4) = a[i];          // sq, sk, sv are contiguous: row r at r * hd
-          }
-        }
-        __syncthreads();
-        // scores: a 16-lane row per (i, j) pair, lane l takes channels 4 l + 64 k; the row sum by four DPP steps (a 64-lane butterfly of
-        // ds_bpermute shuffles per pair cost ~0.4 us each: stamps)
-        {
-          const int rowi = lane >> 4, l = lane & 15;
-          for (int p0 = (tid >> 6) * 4; p0 < Tq * Tk; p0 += 16) {
-            const int p = p0 + rowi;
-            const bool ok = p < Tq * Tk;
-            const int pp = ok ? p : 0;
-            const int i = pp / Tk, j = pp - i * Tk;
-            f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
-            for (int c = 4 * l; c < hd; c += 64) a4 += *(const f32x4*)(sq + i * hd + c) * *(const f32x4*)(sk + j * hd + c);
-            float sacc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-            auto dpp_add = [&](auto ctrl) {
-              sacc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sacc), decltype(ctrl)::value, 0xf, 0xf, true));
-            };
-            dpp_add(std::integral_constant<int, 0xB1>{});     // quad_perm [1,0,3,2]
-            dpp_add(std::integral_constant<int, 0x4E>{});     // quad_perm [2,3,0,1]
-            dpp_add(std::integral_constant<int, 0x141>{});    // row_half_mirror
-            dpp_add(std::integral_constant<int, 0x140>{});    // row_mirror
-            if (ok && l == 0) sc[i * 33 + j] = sacc * scale + smk[i * 33 + j] + skp[j];
-          }
-        }
-        __syncthreads();
-        if (tid < Tq) {
-          float mx = -INFINITY;
-          for (int j = 0; j < Tk; ++j) mx = fmaxf(mx, sc[tid * 33 + j]);
-          float sum = 0.f;
-          for (int j = 0; j < Tk; ++j) { const float e = expf(sc[tid * 33 + j] - mx); sc[tid * 33 + j] = e; sum += e; }
-          const float inv = 1.f / sum;
-          for (int j = 0; j < Tk; ++j) sc[tid * 33 + j] *= inv;
-        }
-        __syncthreads();
-        for (int idx = tid; idx < Tq * hv; idx += WK_THREADS) {
-          const int i = idx / hv, c = (idx - i * hv) * 4;
-          f32x4 a = {0.f, 0.f, 0.f, 0.f};
-          for (int j = 0; j < Tk; ++j) a += sc[i * 33 + j] * *(const f32x4*)(sv + j * hd + c);
-          stc(rO, (unsigned)(((i * B + b) * d + hh * hd + c) * 4), a);
+    for (int st = 0; st < SM_STEPS; ++st)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("v_mov_b32 %0, %1" : "=v"(wc[st][j]) : "v"(wn[st][j]) : "memory");
+    js = op.next_gemm;
+    if (!op.reuse_x) {
+      __builtin_amdgcn_s_barrier();                      // every wave is done with the previous X tile / attention slices in LDS
+      const __amdgpu_buffer_rsrc_t rX = rsrc_of(op.X, (unsigned)((M - 1) * op.ld + K) * 4u);
+      const int segs = K >> 8;                           // 1-KiB pieces per row
+      const int total = M * segs;
+      for (int p = wave; p < total; p += 4) {
+        const int r = p / segs, seg = p - r * segs;
+        const int src = op.perm ? (r % op.B) * op.T + r / op.B : r;      // the launch's inputs are batch-first, the rows in flight (t, b)
+        const unsigned voff = (unsigned)((src * op.ld + seg * 256 + lane * 4) * 4);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_ptr_t)(smem + r * rowb + seg * 1024), 16, voff, 0, 0, SC1);
+      }
+      // the LayerNorm parameters ride along (plain cached loads: they were written before the launch): gamma1 | beta1 | gamma2 | beta2 behind the
+      // rows, so the normalising pass reads them from LDS instead of waiting on a global round trip per pass
+      if (op.g1) {
+        const int nvec = op.g2 ? 4 : 2;
+        for (int p = wave; p < nvec * segs; p += 4) {
+          const int v = p / segs, seg = p - v * segs;
+          const float* src = v == 0 ? op.g1 : (v == 1 ? op.b1 : (v == 2 ? op.g2 : op.b2));
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_of(src, (unsigned)K * 4u), (lds_ptr_t)(smem + SM_GB + v * K * 4 + seg * 1024), 16,
+                                                   (unsigned)((seg * 256 + lane * 4) * 4), 0, 0, 0);
         }
       }
     }
-    WSTAMP(3);
+    asm volatile("" ::: "memory");
+    if (js < n_ops) load_w(js); else load_w(s);           // 16 loads either way: the counted wait below counts on them
+    asm volatile("" ::: "memory");
+    if (!op.reuse_x) {
+      wait_vm<SM_STEPS>();                               // the X pieces (older than the 16 weight loads just requested) have landed
+      __builtin_amdgcn_s_barrier();
+      if (op.g1) {
+        // LayerNorm(s) of the rows, in place: 32 threads per row, two-pass statistics; then this workgroup's share of the normalised rows
+        // goes to Yln (the residual of a later stage reads it)
+        const int r = tid >> 5, j = tid & 31;
+        const bool rok = r < M;
+        float* xr = (float*)(smem + r * rowb);
+        auto ln_pass = [&](int which) {
+          const float* g = (const float*)(smem + SM_GB + (2 * which) * K * 4);
+          const float* b = (const float*)(smem + SM_GB + (2 * which + 1) * K * 4);
+          f32x4 v[SM_STEPS];
+          float sum = 0.f;
+#pragma unroll
+          for (int i = 0; i < SM_STEPS; ++i) {
+            v[i] = (rok && i < steps) ? *(const f32x4*)(xr + j * 4 + i * 128) : f32x4{0.f, 0.f, 0.f, 0.f};
+            sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+          }
+          for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+          const float mean = sum / (float)K;
+          float q = 0.f;
+#pragma unroll
+          for (int i = 0; i < SM_STEPS; ++i)
+            if (i < steps) { const f32x4 t = v[i] - mean; q += (t[0] * t[0] + t[1] * t[1]) + (t[2] * t[2] + t[3] * t[3]); }
+          for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o);
+          const float rstd = rsqrtf(q / (float)K + op.eps);
+#pragma unroll
+          for (int i = 0; i < SM_STEPS; ++i)
+            if (rok && i < steps) {
+              const int k = j * 4 + i * 128;
+              *(f32x4*)(xr + k) = (v[i] - mean) * rstd * *(const f32x4*)(g + k) + *(const f32x4*)(b + k);
+            }
+        };
+        ln_pass(0);
+        if (op.g2) ln_pass(1);                           // (a thread re-reads only what it wrote itself)
+        __syncthreads();
+        if (op.Yln) {
+          const int cl = (K + (int)nwg - 1) / (int)nwg, k0 = (int)blockIdx.x * cl;
+          const __amdgpu_buffer_rsrc_t rL = rsrc_of(op.Yln, (unsigned)(M * K) * 4u);
+          for (int t = tid; t < M * cl; t += WK_THREADS) {
+            const int rr = t / cl, k = k0 + t - rr * cl;
+            if (k < K) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, *(const float*)(smem + rr * rowb + k * 4)), rL, (unsigned)((rr * K + k) * 4), 0, SC1);
+          }
+        }
+      }
+    }
+    // ---- the epilogue's operands (bias, positional row, residual) are requested BEFORE the product: three dependent global round trips
+    // (~1 us each) otherwise sit on the stage's critical path
+    const int ct = (N + (int)nwg - 1) / (int)nwg;
+    const int e_m = tid >> 3, e_n = (int)blockIdx.x * ct + (tid & 7);
+    const bool e_ok = tid < 64 && e_m < M && (tid & 7) < ct && e_n < N;
+    float e_bias = 0.f, e_pe = 0.f, e_res = 0.f;
+    if (e_ok) {
+      if (op.bias) e_bias = ldr1(op.bias, N, e_n);
+      if (op.pe) {
+        const int b = e_m % op.B;
+        const int pr = op.pe_row ? __builtin_bit_cast(int, ldr1(op.pe_row, op.B, b)) : b;
+        e_pe = ldr1(op.pe, 63 * op.ld_res + N, pr * op.ld_res + e_n);
+      }
+      if (op.res) e_res = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_of(op.res, (unsigned)((M - 1) * op.ld_res + N) * 4u), (unsigned)((e_m * op.ld_res + e_n) * 4), 0, SC1));
+    }
+    // ---- the product: this wave's quarter of K, two halves in one tile
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    {
+      const char* xb = smem + c8 * rowb + (wave * (K >> 2) + h * (K >> 3) + 4 * lq) * 4;
+#pragma unroll
+      for (int st = 0; st < SM_STEPS; ++st)
+        if (st < steps) {
+          const f32x4 x = *(const f32x4*)(xb + st * 64);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[st][j], x[j], acc, 0, 0, 0);
+        }
+    }
+    // D[i = 4 lq + r][j = l15]: valid where the halves agree, (lq >> 1) == h: out[m = l15 & 7][c = 4 (lq & 1) + r], half h
+    __syncthreads();                                     // the previous stage's readers of `red` are done
+    if ((lq >> 1) == h) *(f32x4*)&red[wave][h][c8][4 * (lq & 1)] = acc;
+    __syncthreads();
+    if (e_ok) {
+      const int m = e_m, cc = tid & 7;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += red[w][0][m][cc] + red[w][1][m][cc];
+      v += e_bias;
+      if (op.pe) v = v * op.scale + e_pe;                 // embedding epilogue: rows are (t, b); positional row of batch row b
+      if (op.relu) v = fmaxf(v, 0.f);
+      v += e_res;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_of(op.Y, (unsigned)((M - 1) * op.ldy + N) * 4u), (unsigned)((m * op.ldy + e_n) * 4), 0, SC1);
+    }
   }
 }
 
@@ -567,7 +779,7 @@ const char* kGaveUp = "xf_walk: a layer-walking launch gave up at a device-wide 
 
 // Every stage against what the kernel assumes about it.  The kernel reads its operands through exact-size descriptors (a wrong index
 // returns zeros instead of faulting), but a table that breaks these rules would still compute garbage or overrun LDS: refuse it on the host.
-void validate_table(const WalkOp* ops, int n_ops, int rows, int64_t lds) {
+void validate_table(const WalkOp* ops, int n_ops, int rows, int64_t lds, bool small, int n_wg) {
   const int mt = walk_mt(rows);
   auto span_ok = [](int64_t elems) { return elems > 0 && elems * 4 < (int64_t)1 << 31; };
   for (int i = 0; i < n_ops; ++i) {
@@ -598,8 +810,19 @@ void validate_table(const WalkOp* ops, int n_ops, int rows, int64_t lds) {
         SVG_CHECK(op.M == op.B * op.T && op.N % 4 == 0 && op.d_txt % 4 == 0 && op.slab && op.Y && op.pe && op.bias && op.ksplit >= 1 && (op.d_txt == 0 || op.text),
                   "xf_walk: stage %d: embedding %d x %d (+%d)", i, op.M, op.N, op.d_txt);
         break;
+      case WK_GEMMF:
+        SVG_CHECK(small && op.M >= 1 && op.M <= kWalkSmallRows && op.K % 256 == 0 && op.K >= 256 && op.K <= kWalkSmallMaxK && op.N >= 1 &&
+                      (op.N + n_wg - 1) / n_wg <= 8 && op.ld >= op.K && op.ldy >= op.N && op.X && op.W && op.Y && (!op.res || op.ld_res >= op.N),
+                  "xf_walk: stage %d: small-row GEMM %d x %d x %d does not fit the kernel (at most %d rows, K a multiple of 256 up to %d, at most 8 columns per workgroup)",
+                  i, op.M, op.N, op.K, kWalkSmallRows, kWalkSmallMaxK);
+        SVG_CHECK((!op.g1 || op.b1) && (!op.g2 || (op.g1 && op.b2)) && (!op.Yln || op.g1) && (!op.reuse_x || (i > 0 && ops[i - 1].kind == WK_GEMMF && ops[i - 1].X == op.X && ops[i - 1].K == op.K && !op.bar)) &&
+                      (!op.perm || (op.B >= 1 && op.T >= 1 && op.B * op.T == op.M)) && (!op.pe || op.B >= 1),
+                  "xf_walk: stage %d: small-row GEMM flags are inconsistent", i);
+        SVG_CHECK(span_ok((int64_t)op.N * op.K) && (int64_t)kWalkSmallRows * (kWalkSmallMaxK * 4 + 64) + 4 * kWalkSmallMaxK * 4 <= lds, "xf_walk: stage %d: operands of the small-row GEMM exceed a descriptor / LDS", i);
+        break;
       default: SVG_CHECK(false, "xf_walk: stage %d: unknown kind %d", i, op.kind);
     }
+    SVG_CHECK(small ? (op.kind == WK_GEMMF || op.kind == WK_ATTN) : op.kind != WK_GEMMF, "xf_walk: stage %d: kind %d does not belong to this launch form", i, op.kind);
   }
   SVG_CHECK(!ops[0].bar, "xf_walk: the first stage reads the launch's inputs and takes no barrier");
 }
@@ -628,7 +851,10 @@ void xf_walk_init_device() {
   // the largest LDS a launch may ask for, capped at one workgroup per compute unit (the kernel's tiling: a 2048 x 2048 matrix = 256 tiles), a
   // multiple of 8 (the barrier's per-XCD groups).  With $SVG_XF_WALK_COOP=1 the launch itself goes through
   // hipLaunchCooperativeKernel, which repeats that check per launch (and costs 23-31 us per forward: off by default).
-  const int per_cu = std::min({resident_per_cu<1>(), resident_per_cu<2>(), resident_per_cu<3>(), resident_per_cu<4>(), resident_per_cu<6>(),
+  int small_per_cu = 0;
+  HIP_OK(hipFuncSetAttribute((const void*)xf_walk_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+  HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&small_per_cu, (const void*)xf_walk_small_kernel, WK_THREADS, (size_t)kMaxLds));
+  const int per_cu = std::min({small_per_cu, resident_per_cu<1>(), resident_per_cu<2>(), resident_per_cu<3>(), resident_per_cu<4>(), resident_per_cu<6>(),
                                resident_per_cu<8>(), resident_per_cu<11>()});
   D.n_wg = per_cu >= 1 ? (prop.multiProcessorCount / 8) * 8 : 0;
   int coop_attr = 0;
@@ -684,15 +910,33 @@ void xf_walk_check(svg_ctx* ctx) {
   }
 }
 
+int xf_walk_grid() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+  std::lock_guard<std::mutex> lk(g_mu);
+  return g_dev[dev].init ? g_dev[dev].n_wg : 0;
+}
+
+static void walk_launch_impl(const WalkOp* ops, int n_ops, int rows, int64_t lds_bytes, hipStream_t s, bool small);
+
 void xf_walk_launch(svg_ctx* ctx, const WalkOp* ops, int n_ops, int rows, int64_t lds_bytes, hipStream_t s) {
   (void)ctx;
+  walk_launch_impl(ops, n_ops, rows, lds_bytes, s, false);
+}
+
+void xf_walk_small_launch(svg_ctx* ctx, const WalkOp* ops, int n_ops, int64_t lds_bytes, hipStream_t s) {
+  (void)ctx;
+  walk_launch_impl(ops, n_ops, kWalkSmallRows, lds_bytes, s, true);
+}
+
+static void walk_launch_impl(const WalkOp* ops, int n_ops, int rows, int64_t lds_bytes, hipStream_t s, bool small) {
   SVG_CHECK(n_ops >= 1 && n_ops <= kWalkMaxOps, "xf_walk: %d stages (at most %d)", n_ops, kWalkMaxOps);
   SVG_CHECK(xf_walk_available(rows, lds_bytes), "xf_walk: %d rows / %lld bytes of LDS unsupported", rows, (long long)lds_bytes);
   // LDS above half the compute unit's: one workgroup per compute unit
   const int64_t lds = std::max<int64_t>(lds_bytes, kMinLds);
-  validate_table(ops, n_ops, rows, lds);
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
+  validate_table(ops, n_ops, rows, lds, small, std::max(1, xf_walk_grid()));
   std::lock_guard<std::mutex> lk(g_mu);
   WalkDev& D = g_dev[dev];
   SVG_CHECK(D.init, "xf_walk: xf_walk_init_device() has not run on device %d", dev);
@@ -704,7 +948,7 @@ void xf_walk_launch(svg_ctx* ctx, const WalkOp* ops, int n_ops, int rows, int64_
   memcpy(D.hops[slot], ops, sizeof(WalkOp) * n_ops);
   for (int i = n_ops - 1, nxt = n_ops; i >= 0; --i) {     // the weight stream's chain: the next GEMM stage after each stage
     D.hops[slot][i].next_gemm = nxt;
-    if (D.hops[slot][i].kind == WK_GEMM) nxt = i;
+    if (D.hops[slot][i].kind == (small ? WK_GEMMF : WK_GEMM)) nxt = i;
   }
   // one walk at a time on the device: a second one could take compute units the first still needs for its unplaced workgroups
   if (D.last >= 0 && D.last != slot) HIP_OK(hipStreamWaitEvent(s, D.done[D.last], 0));
@@ -716,7 +960,16 @@ void xf_walk_launch(svg_ctx* ctx, const WalkOp* ops, int n_ops, int rows, int64_
   unsigned* ha = D.habort + slot;
   // test hook: a barrier that waits for 8 workgroups more than the grid has never completes — exercises the give-up path end to end
   const unsigned expect = (unsigned)D.n_wg + (D.test_giveup ? 8u : 0u);
-  switch (mt) {
+  if (small) {
+    unsigned long long timeout = D.timeout;
+    const WalkOp* cops = dops;
+    if (D.coop) {
+      void* args[] = {(void*)&cops, (void*)&n_ops, (void*)&sy, (void*)&ha, (void*)&expect, (void*)&timeout};
+      HIP_OK(hipLaunchCooperativeKernel((const void*)xf_walk_small_kernel, dim3(D.n_wg), dim3(WK_THREADS), args, (unsigned)lds, s));
+    } else {
+      hipLaunchKernelGGL(xf_walk_small_kernel, dim3(D.n_wg), dim3(WK_THREADS), (size_t)lds, s, cops, n_ops, sy, ha, expect, timeout);
+    }
+  } else switch (mt) {
     case 1: launch<1>(D, lds, s, dops, n_ops, sy, ha, expect); break;
     case 2: launch<2>(D, lds, s, dops, n_ops, sy, ha, expect); break;
     case 3: launch<3>(D, lds, s, dops, n_ops, sy, ha, expect); break;

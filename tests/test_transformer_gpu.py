@@ -150,13 +150,15 @@ def _walk_model(d=256, heads=4, enc=2, dec=2, seed=11):
     return build("model_10_26", dict(dim_model=d, num_heads=heads, num_encoder_layers=enc, num_decoder_layers=dec))
 
 
-def _with_walk(on, fn):
+def _with_walk(on, fn, small=True):
+    """on: the layer-walking launch (False: the per-GEMM kernels); small: forwards of at most 8 rows take the small-row form of the walk
+    (whole-K GEMM stages, csrc/xf_walk.hip: xf_walk_small_kernel) — small=False keeps them on the split-K walk"""
     from sd_video_gen_amd import _lib
     # ROWS: every accumulator height the kernel is built for (the default stops at 96 rows); SPLIT: larger batches in chunks
-    keys = {"SVG_XF_WALK": "1", "SVG_XF_WALK_SPLIT": "1", "SVG_XF_WALK_ROWS": "176"}
+    keys = {"SVG_XF_WALK": "1", "SVG_XF_WALK_SPLIT": "1", "SVG_XF_WALK_ROWS": "176", "SVG_XF_WALK_SMALL": "1" if small else "0"}
     old = {k: os.environ.get(k) for k in keys}
     for k, v in keys.items():
-        os.environ[k] = v if on else "0"
+        os.environ[k] = v if (on or k == "SVG_XF_WALK_SMALL") else "0"
     _lib.env_refresh()
     try:
         return fn()
@@ -338,3 +340,62 @@ def test_walk_give_up_is_reported_once_and_the_device_falls_back(ctx):
                 os.environ[k] = old[k]
         _lib.env_refresh()
     assert torch.equal(_with_walk(True, run), good)        # re-armed by the refresh: the walk again, same bits
+
+
+@pytest.mark.parametrize("shape", ["kitti", "config_test", "ucf"])
+def test_walk_small_rows_single_clip(ctx, shape):
+    """The small-row form of the walk (at most 8 rows = one clip): whole-K GEMM stages with the LayerNorm of their input and
+    bias / ReLU / residual / embedding epilogue folded in — 5 + 8 instead of 9 + 16 stages per encoder / decoder layer.  Full-size models of
+    three configs (d = 2048 4 + 8 layers D_lat 256; d = 256 6 + 6 layers D_lat 1024; d = 2048 D_lat 1024), one clip of 6 tokens, and 2 clips of
+    4 tokens (8 rows, reference PE quirk: row = batch row), Ts != Tt with key-padding masks: against the split-K walk, the per-GEMM kernels
+    and the CPU oracle; bit-identical from run to run."""
+    from sd_video_gen_amd import config as svg_config
+    from sd_video_gen_amd.transformer import Transformer
+    cfgname, kw, heads = {"kitti": ("1_16_kitti_L1_64", dict(dim_model=2048, num_heads=8, num_encoder_layers=4, num_decoder_layers=8), 8),
+                          "config_test": ("config_test", dict(dim_model=256, num_heads=8, num_encoder_layers=6, num_decoder_layers=6), 8),
+                          "ucf": ("11_27_ucf_final", dict(dim_model=2048, num_heads=8, num_encoder_layers=2, num_decoder_layers=2), 8)}[shape]
+    svg_config.set_args(["--dataset", "ball", "--config", cfgname])
+    torch.manual_seed(31)
+    m = Transformer(**kw).eval()
+    D = m.d_lat
+    sd = {k: v.clone().cpu() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(7)
+    # (1) one clip, 6 tokens, causal mask: the single-clip sampling call
+    X = torch.randn(1, 6, D, generator=g)
+    mask = m.get_tgt_mask(6).cuda()
+    pe0 = torch.zeros(1, dtype=torch.int32)
+    run = lambda: m(X.cuda(), X.cuda(), mask, pe_row=pe0).cpu()
+    out = _with_walk(True, run)
+    assert torch.equal(out, _with_walk(True, run))
+    assert rel_l2(out, _with_walk(True, run, small=False)) < 5e-6
+    assert rel_l2(out, _with_walk(False, run)) < 5e-6
+    assert rel_l2(out, TO.forward(sd, X, X, heads, TO.get_tgt_mask(6))) < TOL
+    # (2) two clips of 4 tokens (8 rows), the reference's PE-row-by-batch-row quirk (no pe_row)
+    X2 = torch.randn(2, 4, D, generator=g)
+    m4 = m.get_tgt_mask(4).cuda()
+    run2 = lambda: m(X2.cuda(), X2.cuda(), m4).cpu()
+    out2 = _with_walk(True, run2)
+    assert rel_l2(out2, _with_walk(False, run2)) < 5e-6
+    assert rel_l2(out2, TO.forward(sd, X2, X2, heads, TO.get_tgt_mask(4))) < TOL
+    # (3) Ts != Tt, key-padding masks on both sides
+    S, T = torch.randn(1, 5, D, generator=g), torch.randn(1, 7, D, generator=g)
+    ps = torch.tensor([[False, False, True, False, True]]); pt = torch.tensor([[False, False, False, True, False, False, True]])
+    m7 = m.get_tgt_mask(7).cuda()
+    run3 = lambda: m(S.cuda(), T.cuda(), m7, ps, pt).cpu()
+    out3 = _with_walk(True, run3)
+    assert rel_l2(out3, _with_walk(False, run3)) < 5e-6
+    assert rel_l2(out3, TO.forward(sd, S, T, heads, TO.get_tgt_mask(7), src_pad_mask=ps, tgt_pad_mask=pt)) < TOL
+    # timing of the single-clip call, printed (profiles/README.md)
+    def timed(small, walk=True):
+        def f():
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(3):
+                m(X.cuda(), X.cuda(), mask, pe_row=pe0)
+            e0.record()
+            for _ in range(20):
+                m(X.cuda(), X.cuda(), mask, pe_row=pe0)
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / 20
+        return _with_walk(walk, f, small=small)
+    print("[walk] %s, 6 rows: small-row walk %.3f ms | split-K walk %.3f ms | per-GEMM kernels %.3f ms" % (shape, timed(True), timed(False), timed(True, walk=False)))

@@ -20,8 +20,9 @@ mask = m.get_tgt_mask(6).cuda()
 pe0 = torch.zeros(B, dtype=torch.int32)
 
 
-def run(walk):
+def run(walk, small=False):
     os.environ["SVG_XF_WALK"] = "1" if walk else "0"
+    os.environ["SVG_XF_WALK_SMALL"] = "1" if small else "0"          # the small-row form (at most 8 rows), forced on / off
     _lib.env_refresh()
     out = m(X, X, mask, pe_row=pe0)
     torch.cuda.synchronize()
@@ -39,4 +40,8 @@ old, t_old = run(False)
 print("walk ...", flush=True)
 new, t_new = run(True)
 err = ((new - old).norm() / old.norm()).item()
-print("d=%d heads=%d enc=%d dec=%d B=%d d_lat=%d: rel-L2 walk vs per-GEMM %.3e | per-GEMM %.3f ms, walk %.3f ms" % (d, heads, enc, dec, B, d_lat, err, t_old, t_new), flush=True)
+line = "d=%d heads=%d enc=%d dec=%d B=%d d_lat=%d: rel-L2 walk vs per-GEMM %.3e | per-GEMM %.3f ms, walk %.3f ms" % (d, heads, enc, dec, B, d_lat, err, t_old, t_new)
+if B * 6 <= 8 and d % 256 == 0 and d_lat % 256 == 0:
+    sm, t_sm = run(True, small=True)
+    line += ", small-row walk %.3f ms (rel-L2 vs per-GEMM %.3e)" % (t_sm, ((sm - old).norm() / old.norm()).item())
+print(line, flush=True)
