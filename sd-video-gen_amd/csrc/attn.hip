@@ -524,6 +524,10 @@ __global__ void __launch_bounds__(256) attn_dma40_kernel(const AttnArgs a) {
     for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
       for (int j = 0; j < 16; ++j) { S0[qb][j] = 0.f; S1[qb][j] = 0.f; }
+#ifndef ATTN_PRIO
+#define ATTN_PRIO 0
+#endif
+    if (ATTN_PRIO & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const h16x8 a0 = *(const h16x8*)(sK + r * KROW + (ks * 2 + h) * 16);
@@ -534,6 +538,7 @@ __global__ void __launch_bounds__(256) attn_dma40_kernel(const AttnArgs a) {
         S1[qb] = MFMA_32x32x16(a1, qf[qb][ks], S1[qb]);
       }
     }
+    if (ATTN_PRIO & 1) __builtin_amdgcn_s_setprio(0);
     // V^T fragments of this tile: one 16-byte read each, issued now so that their latency runs under the softmax
     uint4 vfr[4 * DVT];
 #pragma unroll
@@ -555,6 +560,7 @@ __global__ void __launch_bounds__(256) attn_dma40_kernel(const AttnArgs a) {
           if (base + 32 + kv >= a.Skv) S1[qb][j] = -INFINITY;
         }
     }
+    if (ATTN_PRIO & 4) __builtin_amdgcn_s_setprio(1);
     float mx[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -588,6 +594,7 @@ __global__ void __launch_bounds__(256) attn_dma40_kernel(const AttnArgs a) {
         S1[qb][j] = __builtin_amdgcn_exp2f(S1[qb][j]);
       }
     }
+    if (ATTN_PRIO & 4) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -597,6 +604,7 @@ __global__ void __launch_bounds__(256) attn_dma40_kernel(const AttnArgs a) {
         for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
           for (int j = 0; j < 8; ++j) pf[qb][j] = (h16)(st == 0 ? S0[qb][8 * s2 + j] : S1[qb][8 * s2 + j]);
+        if (ATTN_PRIO & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int dt = 0; dt < DVT; ++dt) {
           const uint4 v = vfr[(2 * st + s2) * DVT + dt];
@@ -604,6 +612,7 @@ __global__ void __launch_bounds__(256) attn_dma40_kernel(const AttnArgs a) {
           for (int qb = 0; qb < QB; ++qb)
             O[qb][dt] = MFMA_32x32x16(*(const h16x8*)&v, pf[qb], O[qb][dt]);
         }
+        if (ATTN_PRIO & 2) __builtin_amdgcn_s_setprio(0);
       }
   }
 
