@@ -247,6 +247,7 @@ int main() {
   transformer(384);
   transformer(0, 128, 128, 256);
   transformer(384, 128, 128, 256);
+  transformer(0, 256, 256, 256);                   // d = K = 256: one clip (6 rows) takes the small-row walk (xf_forward_walk_small: whole-K stage table)
   vae(0); vae(1);
   unet(0, 0); unet(1, 0); unet(0, 1);
   text_towers();
