@@ -524,7 +524,10 @@ __global__ void __launch_bounds__(WK_THREADS) xf_walk_small_kernel(const WalkOp*
     const int N = ops[s].N, K = ops[s].K;
     const int ct = (N + (int)nwg - 1) / (int)nwg;
     const int n = (int)blockIdx.x * ct + c8;
-    const bool okn = c8 < ct && n < N;
+#ifndef SM_ABL            // timing ablations of the small-row kernel (results are garbage): 1 no weight loads, 2 no X staging
+#define SM_ABL 0
+#endif
+    const bool okn = SM_ABL != 1 && c8 < ct && n < N;
     const __amdgpu_buffer_rsrc_t rW = rsrc_of(ops[s].W, (unsigned)(N * K) * 4u);
     const int kh = wave * (K >> 2) + h * (K >> 3) + 4 * lq;
     const int steps = K >> 7;
@@ -579,7 +582,7 @@ __global__ void __launch_bounds__(WK_THREADS) xf_walk_small_kernel(const WalkOp*
       for (int p = wave; p < total; p += 4) {
         const int r = p / segs, seg = p - r * segs;
         const int src = op.perm ? (r % op.B) * op.T + r / op.B : r;      // the launch's inputs are batch-first, the rows in flight (t, b)
-        const unsigned voff = (unsigned)((src * op.ld + seg * 256 + lane * 4) * 4);
+        const unsigned voff = SM_ABL == 2 ? INVALID : (unsigned)((src * op.ld + seg * 256 + lane * 4) * 4);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_ptr_t)(smem + r * rowb + seg * 1024), 16, voff, 0, 0, SC1);
       }
       // the LayerNorm parameters ride along (plain cached loads: they were written before the launch): gamma1 | beta1 | gamma2 | beta2 behind the
