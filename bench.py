@@ -317,7 +317,7 @@ def roofline_pass(args, sd_utils, step, denoise, C, model=None):
     return out
 
 
-def fp8_same_box(args, cfg, local_rank, build_model, clips, seeds, kw_s, cls_emb, fps_fp16):
+def fp8_same_box(args, cfg, local_rank, build_model, clips, seeds, kw_s, cls_emb, fps_fp16, streams):
     """extras.fp8_same_box: the SAME workload, clips and process, with the UNet's resnet / upsampler 3x3 convs on MX-fp8
     operands (SDUtils(fp8=True): e4m3 x e4m3 + E8M0 block scales, fp16 storage elsewhere) — two warm-up and two timed steps after the
     headline has been computed.  The headline stays fp16 (the reference's autocast arithmetic); fp8 is narrower than the reference and is
@@ -327,10 +327,10 @@ def fp8_same_box(args, cfg, local_rank, build_model, clips, seeds, kw_s, cls_emb
     from sd_video_gen_amd.predict import sample_clips, sample_clips_streams
     from sd_video_gen_amd.sd_utils import SDUtils
     workers = []
-    for _ in range(args.streams):
+    for i in range(args.streams):                       # on the headline's own streams (see GPU_MAX_HW_QUEUES in main)
         c8 = _lib.Context(local_rank)
         torch.manual_seed(0)
-        workers.append((build_model(c8), SDUtils(weights="synthetic", seed=0, verbose=False, ctx=c8, fp8=True, dtype="fp16"), torch.cuda.Stream()))
+        workers.append((build_model(c8), SDUtils(weights="synthetic", seed=0, verbose=False, ctx=c8, fp8=True, dtype="fp16"), streams[i]))
 
     def step8():
         return sample_clips_streams(workers, clips, args.pred_frames, seeds, cls_list=cls_emb, **kw_s)
@@ -468,6 +468,11 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    # HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, assigned at a stream's first use): two stream
+    # groups that land on ONE queue lose their overlap (measured: the same fp16 pair 19.0 frames/s on one pair of streams, 17.8 on another;
+    # with 8 queues both 19.0 — profiles/r05_fp8_inproc_probe.txt).  The headline's two streams are the first two of the process and never
+    # aliased; the later passes of this process (fp8_same_box) would.  Must be set before the HIP runtime initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -617,7 +622,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         line.update(roofline_pass(args, sd_utils, step, denoise, C, model))
     if rank == 0 and denoise and args.dtype == "fp16" and not args.no_fp8_extra:
-        line.setdefault("extras", {})["fp8_same_box"] = fp8_same_box(args, cfg, local_rank, build_model, clips, seeds, kw_s, cls_emb, fps)
+        line.setdefault("extras", {})["fp8_same_box"] = fp8_same_box(args, cfg, local_rank, build_model, clips, seeds, kw_s, cls_emb, fps, [w[2] for w in workers])
     if rank == 0 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.config, args.start_step, denoise, guidance, args.text)
     if rank == 0:
