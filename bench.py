@@ -600,7 +600,8 @@ def main():
     # what actually ran, read back from the library (the requested string is not evidence)
     ran_dtype = sd_utils.ctx.model_dtype(_lib.SVG_UNET) if denoise else "f32"
     if denoise and fp8:
-        ran_dtype = "fp8 (MX e4m3: the resnets' 3x3 convs) + " + ran_dtype
+        ran_dtype = ("fp8 (MX e4m3: the 16 x 16 level's resnet 3x3 convs — the placement a guided DDIM loop keeps under 1e-1, $SVG_FP8_SITES_GUIDED) + "
+                     if guidance != 0.0 else "fp8 (MX e4m3: the resnets' 3x3 convs) + ") + ran_dtype
     line = {"metric": metric, "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

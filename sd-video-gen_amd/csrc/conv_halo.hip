@@ -116,15 +116,23 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
   const int r0 = tid >> 3;                                // 0..63
   const int cB = (tid & 7) ^ (r0 & 7);
   unsigned b_voff[5];
+  // PERM (BN = 160, NT = 5: round 5): LDS row rb of the weight slab holds the weight row its MFMA operand row stands for in the 16-byte epilogue
+  // (igemm_epi.h: epi_perm_col — the quads of a tile pair are 8 consecutive output channels per lane, without lane exchanges or registers)
+  constexpr bool PERM = (NT & 1) != 0;
+  auto w_row = [&](int rb) {
+    if (!PERM) return n0 + rb;
+    const int run = rb / (BN / 2);
+    return n0 + run * (BN / 2) + epi_perm_col<NT>(rb - run * (BN / 2));
+  };
 #pragma unroll
   for (int i = 0; i < BIT; ++i) {
-    const int n = n0 + r0 + 64 * i;
+    const int n = w_row(r0 + 64 * i);
     b_voff[i] = (n < g.n_valid) ? (unsigned)(n * g.ldb + cB * 8) * 2u : INVALID;
   }
   constexpr bool B_TAIL = (BN % 64) != 0;                 // BN = 160: a last half group of 32 rows
   unsigned b_voff_tail = INVALID;
   if (B_TAIL) {
-    const int n = n0 + BIT * 64 + r0;
+    const int n = w_row(BIT * 64 + (r0 & 31));
     if (r0 < 32 && n < g.n_valid) b_voff_tail = (unsigned)(n * g.ldb + cB * 8) * 2u;
   }
 
@@ -484,13 +492,14 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const int n = nc + j * 16;
+        // (PERM: the quads of a tile pair are columns 32 (j >> 1) + 8 lq + 4 (j & 1) .. + 3 of the wave's run, the unpaired tile natural)
+        const int n = (PERM && j < (NT & ~1)) ? n0 + wn * (BN / 2) + 32 * (j >> 1) + 8 * lq + 4 * (j & 1) : nc + j * 16;
         if (n < g.N) *(f32x4*)(g.slabs + ((int64_t)ks * g.M + mr + i * OW) * g.N + n) = acc[i][j];
       }
   } else {
-    // 16-bit output, no GEGLU: the wide epilogue — at BN = 128 only: at BN = 160 (NT = 5, the kernel sits at 254 VGPRs) it spills 38
-    // registers and measured 0.193 against 0.190 ms (28 x 64 x 64 x 320 -> 320, profiles/r04_kbench_conv_fp8_vs_fp16.txt)
-    epi_tile<MT, NT, false, (NT % 2 == 0)>(g, 0, mr, OW, nc, acc, smem, 4, wm, wn, tile_m, n0);
+    // 16-bit output, no GEGLU: the wide epilogue — at BN = 128 through lane exchanges; at BN = 160 (NT = 5, the kernel sits at 254 VGPRs, the
+    // exchange form spills 38 registers) through the permuted weight rows above (round 5)
+    epi_tile<MT, NT, false, (NT % 2 == 0) ? 1 : 2>(g, 0, mr, OW, nc, acc, smem, 4, wm, wn, tile_m, n0);
   }
 }
 

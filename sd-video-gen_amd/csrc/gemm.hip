@@ -38,7 +38,9 @@ __device__ __forceinline__ void epi_store_geglu(const GemmArgs& g, int z, int m,
 }
 
 // WIDE: the wide tile epilogue (igemm_epi.h) — dense GEMMs with a 16-bit output and no GEGLU (the launcher decides)
-template <int BN, int AMODE, bool WIDE = false>
+// WIDE = 2: the same 16-byte epilogue through a permutation of the W rows at load time instead of lane exchanges (igemm_epi.h: epi_perm_col) —
+// no extra registers: the form of the 160-column dense tiles (launched without split-K only: the slab path keeps natural columns)
+template <int BN, int AMODE, int WIDE = 0>
 __global__ void __launch_bounds__(256, 2) igemm_kernel(const GemmArgs g) {
   constexpr int NT = BN / 32;       // 16-wide n tiles per wave
   constexpr int MT = 4;             // 16-high m tiles per wave
@@ -132,6 +134,10 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const GemmArgs g) {
 #pragma unroll
   for (int i = 0; i < BIT; ++i) {
     int n = n0 + r0 + 32 * i;
+    if (WIDE == 2) {                                     // LDS row rb = r0 + 32 i of the B tile holds the weight row its MFMA operand row stands for
+      const int rb = r0 + 32 * i, run = rb / (BN / 2);
+      n = n0 + run * (BN / 2) + epi_perm_col<NT>(rb - run * (BN / 2));
+    }
     b_voff[i] = (n < g.n_valid) ? (unsigned)(n * g.ldb + c * 8) * 2u : INVALID;
   }
 
@@ -349,12 +355,18 @@ __global__ void pack_geglu_kernel(const float* __restrict__ w, const float* __re
 // (the VAE's conv_in at 512 x 512: 1.9 GB of output per 28-clip launch — a store-bound launch)
 template <int BN, int AMODE>
 constexpr bool kWideInst = (AMODE == A_DENSE && (BN == 64 || BN == 128)) || (AMODE == A_CONV_SMALLC && BN == 128);
+template <int BN, int AMODE>
+constexpr bool kPermInst = AMODE == A_DENSE && BN == 160;      // WIDE = 2 (W rows permuted at load): dense 160-column tiles
 
 template <int BN, int AMODE>
 void launch_inst(const GemmArgs& g, dim3 grid, hipStream_t s) {
   constexpr int smem = 2 * (BM * 128 + BN * 128);
-  if constexpr (kWideInst<BN, AMODE>) {      // (BN = 160: 48 spilled registers in the wide form — not used there)
-    if (g.act != ACT_GEGLU && !g.out_f32) { hipLaunchKernelGGL((igemm_kernel<BN, AMODE, true>), grid, dim3(256), smem, s, g); return; }
+  if constexpr (kWideInst<BN, AMODE>) {      // (BN = 160: 48 spilled registers in the exchange form — the permuted-row form below)
+    if (g.act != ACT_GEGLU && !g.out_f32) { hipLaunchKernelGGL((igemm_kernel<BN, AMODE, 1>), grid, dim3(256), smem, s, g); return; }
+  }
+  if constexpr (kPermInst<BN, AMODE>) {
+    static const int perm_on = getenv("SVG_IGEMM_PERM") ? atoi(getenv("SVG_IGEMM_PERM")) : 1;
+    if (perm_on && g.act != ACT_GEGLU && !g.out_f32 && g.splitk == 1) { hipLaunchKernelGGL((igemm_kernel<BN, AMODE, 2>), grid, dim3(256), smem, s, g); return; }
   }
   hipLaunchKernelGGL((igemm_kernel<BN, AMODE>), grid, dim3(256), smem, s, g);
 }
@@ -378,7 +390,9 @@ template <int BN, int AMODE>
 void attr_inst() {
   HIP_OK(hipFuncSetAttribute((const void*)igemm_kernel<BN, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM * 128 + BN * 128)));
   if constexpr (kWideInst<BN, AMODE>)
-    HIP_OK(hipFuncSetAttribute((const void*)igemm_kernel<BN, AMODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM * 128 + BN * 128)));
+    HIP_OK(hipFuncSetAttribute((const void*)igemm_kernel<BN, AMODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM * 128 + BN * 128)));
+  if constexpr (kPermInst<BN, AMODE>)
+    HIP_OK(hipFuncSetAttribute((const void*)igemm_kernel<BN, AMODE, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM * 128 + BN * 128)));
 }
 template <int BN>
 void attr_bn() {

@@ -193,7 +193,14 @@ __device__ __forceinline__ void bar() {
 // the K loop) and the first BN_ threads add them in a fixed order.  WM_ = waves along M, wm / wn = this wave's position,
 // BNH_ = columns per wave, tile_m = row-tile index, n0 = first column of the tile.
 // LN_ (dense GEMMs only): additionally emit the LayerNorm row partials of the stored values (GemmArgs::ln_part).
-template <int MT_, int NT_, bool LN_ = false, bool WIDE_ = false>
+// WIDE_ = 2 of epi_tile: weight row (inside a wave's run of NT 16-column tiles) that belongs in MFMA operand row x = 16 j + r of that run
+template <int NT_>
+__device__ __forceinline__ int epi_perm_col(int x) {
+  const int j = x >> 4, r = x & 15;
+  return j < (NT_ & ~1) ? 32 * (j >> 1) + 8 * (r >> 2) + 4 * (j & 1) + (r & 3) : x;
+}
+
+template <int MT_, int NT_, bool LN_ = false, int WIDE_ = 0>
 __device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int mstep, int nc, f32x4 (&acc)[MT_][NT_],
                                          char* lds = nullptr, int WM_ = 0, int wm = 0, int wn = 0, int tile_m = 0, int n0 = 0) {
   const bool geglu = g.act == ACT_GEGLU;
@@ -209,11 +216,20 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int m
   // here).  cj(j) = first of the 4 columns acc[i][j] holds in this lane, before or after the exchange.
   // WIDE_ is a compile-time choice of the kernel instantiation (the launcher picks it when the output is 16-bit and the activation is
   // not GEGLU): with the two forms selected at run time inside one kernel the allocator spills 250+ registers at NT_ = 5
-  constexpr bool wide = WIDE_ && NT_ >= 2;
+  // WIDE_ = 2 (round 5): the SAME lane layout without the exchange — the kernel dealt the rows of W to the MFMA operand rows of a tile pair so
+  // that a lane's quads of tiles (j, j + 1) ARE 8 consecutive columns (epi_perm_col below: operand row r of tile j <-> column 32 (j >> 1) +
+  // 8 (r >> 2) + 4 (j & 1) + (r & 3); an unpaired last tile stays natural).  No permlane instructions, no extra registers: the form for the
+  // 160-column tiles, whose exchange form spills.
+  constexpr bool wide = WIDE_ != 0 && NT_ >= 2;
   // column of acc[i][j][0] in this lane: paired tiles cb + 16 (j & ~1) + (j & 1) * cstep, an unpaired last tile nc + 16 j (two registers,
   // not a table: these kernels sit at the 256-register limit)
   int cb = nc, cstep = 16;
-  if constexpr (wide) {
+  if constexpr (wide && WIDE_ == 2) {
+    const int lq_ = (threadIdx.x & 63) >> 4;
+    cb = nc + 4 * lq_;                                    // nc = base + 4 lq: the lane's 8 columns start at base + 8 lq
+    cstep = 4;
+  }
+  if constexpr (wide && WIDE_ == 1) {
     const int lq_ = (threadIdx.x & 63) >> 4;
     cb = (lq_ & 1) ? nc - 4 * lq_ + 16 + 4 * (lq_ - 1) : nc;
     cstep = 4;
