@@ -279,8 +279,11 @@ __global__ void __launch_bounds__(512, 2) ff_pair_kernel(const FfArgs a, unsigne
         const unsigned voff = (unsigned)((128 * c + row) * FC + ch * 8) * 2u;
         dma16(srd1, voff, s * 128, dst + blk * 1024);
       } else {
-        const int rr = 64 * (s - 5) + (row & 63);          // row inside the column half
-        const int r = (row >> 6) * 160 + rr;
+        const int rr = 64 * (s - 5) + (row & 63);          // MFMA operand row inside the column half: tile rr >> 4, row rr & 15
+        // the output column that operand row stands for: the quads of a tile pair are 8 consecutive columns per lane (16-byte epilogue, as
+        // gemm_ws.hip / igemm_epi.h: epi_perm_col) — ten tiles per half, all paired
+        const int cperm = 32 * (rr >> 5) + 8 * ((rr & 15) >> 2) + 4 * ((rr >> 4) & 1) + (rr & 3);
+        const int r = (row >> 6) * 160 + cperm;
         const unsigned voff = rr < 160 ? (unsigned)(r * FH + ch * 8) * 2u : INVALID;
         dma16(srd2, voff, c * 128, dst + blk * 1024);
       }
@@ -501,20 +504,27 @@ __global__ void __launch_bounds__(512, 2) ff_pair_kernel(const FfArgs a, unsigne
   }
   FSTAMP(t_all1);
 
-  // ---- epilogue: + b2 + residual, h16 store (4 consecutive columns per lane)
+  // ---- epilogue: + b2 + residual, h16 store — 8 consecutive columns per lane and tile pair (the W2 rows were dealt accordingly): one
+  // 16-byte residual load and one 16-byte store instead of two 8-byte ones (the epilogue was 10 % of the kernel's cycles)
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
     if (!m_ok[rt]) continue;
     const int m = mrow[rt];
 #pragma unroll
-    for (int t = 0; t < 10; ++t) {
-      const int n = half_u * 160 + t * 16 + lq * 4;
-      f32x4 v = acc2[rt][t] + *(const f32x4*)(a.b2 + n);
+    for (int p = 0; p < 5; ++p) {
+      const int n = half_u * 160 + 32 * p + 8 * lq;
+      f32x4 v0 = acc2[rt][2 * p] + *(const f32x4*)(a.b2 + n);
+      f32x4 v1 = acc2[rt][2 * p + 1] + *(const f32x4*)(a.b2 + n + 4);
       if (a.residual) {
-        const h16x4 r = *(const h16x4*)(a.residual + (int64_t)m * a.ldr + n);
-        v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+        const h16x8 r = *(const h16x8*)(a.residual + (int64_t)m * a.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v0[e] += (float)r[e]; v1[e] += (float)r[4 + e]; }
       }
-      *(h16x4*)(a.out + (int64_t)m * a.ldo + n) = to_h16x4(v);
+      h16x8 w;
+      const h16x4 w0 = to_h16x4(v0), w1 = to_h16x4(v1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { w[e] = w0[e]; w[4 + e] = w1[e]; }
+      *(h16x8*)(a.out + (int64_t)m * a.ldo + n) = w;
     }
   }
 #ifdef FF_STAMP
@@ -556,7 +566,7 @@ void pack_ff2_perm(const float* w, h16* out, int N, int K, hipStream_t s) {
 
 void ff_fused(svg_ctx* ctx, const h16* X, int ldx, const h16* W1, const float* b1, const float* s1, const float* rs, const float* rm,
               const h16* W2p, const float* b2, const h16* residual, int ldr, h16* out, int ldo, int M, hipStream_t s) {
-  SVG_CHECK(ldx % 8 == 0 && ldr % 4 == 0 && ldo % 4 == 0 && (int64_t)M * ldx < (1LL << 31), "ff_fused: strides / size unsupported");
+  SVG_CHECK(ldx % 8 == 0 && ldr % 8 == 0 && ldo % 8 == 0 && (int64_t)M * ldx < (1LL << 31), "ff_fused: strides / size unsupported");
   if (!SVG_LAUNCHING(ctx)) return;
   char tag[64];
   snprintf(tag, sizeof(tag), "ff_fused_M%d_C%d", M, FC);
