@@ -95,8 +95,11 @@ __global__ void __launch_bounds__(512, 2) xattn_fused_kernel(const XaArgs a) {
         else dma16(srdk, voff, h * X_HEAD_ELEMS * 2, dst + blk * 1024);
       } else {
         const int j = q - X_P1 - X_P2, ks = j / 3, rb = j - 3 * ks;
-        const int r = rb * 128 + row;
-        dma16(srdo, r < XC ? (unsigned)((r * XQ + ch * 8) * 2) : INVALID, ks * 128, dst + blk * 1024);
+        const int x = rb * 128 + row;                        // MFMA operand row: tile x >> 4, row x & 15
+        // plain form: the output column that operand row stands for — the quads of a tile pair are 8 consecutive columns per lane (16-byte
+        // epilogue, as gemm_ws.hip); CHAIN keeps the natural order (its residual hb[] comes from phase 0's accumulators in that order)
+        const int r = CHAIN ? x : 32 * (x >> 5) + 8 * ((x & 15) >> 2) + 4 * ((x >> 4) & 1) + (x & 3);
+        dma16(srdo, x < XC ? (unsigned)((r * XQ + ch * 8) * 2) : INVALID, ks * 128, dst + blk * 1024);
       }
     }
   };
@@ -320,13 +323,26 @@ __global__ void __launch_bounds__(512, 2) xattn_fused_kernel(const XaArgs a) {
     }
 
   if (m_ok) {
+    if constexpr (CHAIN) {
 #pragma unroll
-    for (int t = 0; t < XC / 16; ++t) {
-      const int n = t * 16 + lq * 4;
-      f32x4 v = acco[t] + *(const f32x4*)(sBo + n);
-      const h16x4 r = CHAIN ? hb[t] : *(const h16x4*)(a.X + (int64_t)m * a.ldx + n);
-      v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
-      *(h16x4*)(a.out + (int64_t)m * a.ldo + n) = to_h16x4(v);
+      for (int t = 0; t < XC / 16; ++t) {
+        const int n = t * 16 + lq * 4;
+        f32x4 v = acco[t] + *(const f32x4*)(sBo + n);
+        const h16x4 r = hb[t];
+        v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+        *(h16x4*)(a.out + (int64_t)m * a.ldo + n) = to_h16x4(v);
+      }
+    } else {
+      // 8 consecutive columns per lane and tile pair: one 16-byte residual load and one 16-byte store (W_out's rows were dealt accordingly)
+#pragma unroll
+      for (int p = 0; p < XC / 32; ++p) {
+        const int n = 32 * p + 8 * lq;
+        f32x4 v0 = acco[2 * p] + *(const f32x4*)(sBo + n), v1 = acco[2 * p + 1] + *(const f32x4*)(sBo + n + 4);
+        const h16x8 r = *(const h16x8*)(a.X + (int64_t)m * a.ldx + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v0[e] += (float)r[e]; v1[e] += (float)r[4 + e]; }
+        *(h16x8*)(a.out + (int64_t)m * a.ldo + n) = cat8(to_h16x4(v0), to_h16x4(v1));
+      }
     }
   }
 }
@@ -422,7 +438,7 @@ void xattn_pack_kv(const h16* K, int ldk, int64_t k_bs, const h16* Vt, int ldv, 
 void xattn_fused(svg_ctx* ctx, const h16* X, int ldx, const h16* R, int ldr, const h16* Wp, const float* bp, const float* rs, const float* rm,
                  const h16* Wq, const float* sq, const float* bq, const h16* Kp, const h16* Vp, const h16* Wo, const float* bo, h16* out, int ldo,
                  int M, int rows_per_sample, int L, hipStream_t s) {
-  SVG_CHECK(ldx % 8 == 0 && ldo % 4 == 0 && (int64_t)M * ldx < (1LL << 31) && (!Wp || (R && ldr % 4 == 0)), "xattn_fused: strides / size unsupported");
+  SVG_CHECK(ldx % 8 == 0 && ldo % 8 == 0 && (int64_t)M * ldx < (1LL << 31) && (!Wp || (R && ldr % 4 == 0)), "xattn_fused: strides / size unsupported");
   if (!SVG_LAUNCHING(ctx)) return;
   char tag[64];
   snprintf(tag, sizeof(tag), "xattn_%s_M%d_C%d_L%d", Wp ? "chain" : "fused", M, XC, L);
