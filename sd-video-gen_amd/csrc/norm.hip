@@ -301,24 +301,28 @@ __global__ void __launch_bounds__(256) gn_fold_weights_kernel(const float* __res
 // latency: 22-27 us for 2.6-10 MB).  Values are fetched as 8-byte (4-channel) pieces, so a group may straddle the two
 // sources of a virtual concat.  Deterministic: fixed per-thread order, shuffle + LDS tree.
 typedef h16 h16x4n __attribute__((ext_vector_type(4)));
-template <int MAXCH>
+typedef h16 h16x8n __attribute__((ext_vector_type(8)));
+// VW = channels per piece: 4 (8-byte pieces: any cpg % 4 == 0) or 8 (16-byte pieces, cpg % 8 == 0 — round 5: half the vector-memory
+// instructions and half the predicated trips: 256 x 40 channels = 5 pieces per thread instead of 10)
+template <int MAXCH, int VW>
 __global__ void __launch_bounds__(256) gn_small_kernel(const h16* __restrict__ x, int C1, const h16* __restrict__ x2, int C2,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        h16* __restrict__ out, int HW, int groups, float eps, int silu) {
+  typedef h16 vec_t __attribute__((ext_vector_type(VW)));
   __shared__ float red[8];
-  const int C = C1 + C2, cpg = C / groups, nch = cpg >> 2, total = HW * nch;
+  const int C = C1 + C2, cpg = C / groups, nch = cpg / VW, total = HW * nch;
   const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  h16x4n v[MAXCH];
+  vec_t v[MAXCH];
   float s = 0.f, q = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXCH; ++i) {
     const int id = tid + 256 * i;
     if (id < total) {
-      const int p = id / nch, c = g * cpg + ((id - p * nch) << 2);
+      const int p = id / nch, c = g * cpg + (id - p * nch) * VW;
       const h16* src = (c < C1) ? x + ((int64_t)b * HW + p) * C1 + c : x2 + ((int64_t)b * HW + p) * C2 + (c - C1);
-      v[i] = *(const h16x4n*)src;
+      v[i] = *(const vec_t*)src;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { const float f = (float)v[i][j]; s += f; q += f * f; }
+      for (int j = 0; j < VW; ++j) { const float f = (float)v[i][j]; s += f; q += f * f; }
     }
   }
   s = wave_sum(s); q = wave_sum(q);
@@ -333,18 +337,21 @@ __global__ void __launch_bounds__(256) gn_small_kernel(const h16* __restrict__ x
   for (int i = 0; i < MAXCH; ++i) {
     const int id = tid + 256 * i;
     if (id < total) {
-      const int p = id / nch, c = g * cpg + ((id - p * nch) << 2);
-      const float4 ga = *(const float4*)(gamma + c), be = *(const float4*)(beta + c);
-      const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
-      h16x4n o;
+      const int p = id / nch, c = g * cpg + (id - p * nch) * VW;
+      vec_t o;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float a = rstd * gg[j];
-        float f = fmaf((float)v[i][j], a, bb[j] - mean * a);
-        if (silu) f = f * __builtin_amdgcn_rcpf(1.f + __expf(-f));
-        o[j] = (h16)f;
+      for (int j4 = 0; j4 < VW; j4 += 4) {
+        const float4 ga = *(const float4*)(gamma + c + j4), be = *(const float4*)(beta + c + j4);
+        const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a = rstd * gg[j];
+          float f = fmaf((float)v[i][j4 + j], a, bb[j] - mean * a);
+          if (silu) f = f * __builtin_amdgcn_rcpf(1.f + __expf(-f));
+          o[j4 + j] = (h16)f;
+        }
       }
-      *(h16x4n*)(out + ((int64_t)b * HW + p) * C + c) = o;
+      *(vec_t*)(out + ((int64_t)b * HW + p) * C + c) = o;
     }
   }
 }
@@ -527,10 +534,16 @@ void groupnorm(svg_ctx* ctx, const h16* x, int C1, const h16* x2, int C2, const 
       char tag[96];
       snprintf(tag, sizeof(tag), "small_B%d_HW%d_C%d", B, HW, C);
       ProfScope ps(ctx, PK_GNORM, s, 0, 2.0 * B * HW * C * 2, tag);
-      if ((int64_t)HW * (cpg / 4) <= 256 * 5)
-        hipLaunchKernelGGL(gn_small_kernel<5>, dim3(groups, B), dim3(256), 0, s, x, C1, x2, C2, gamma, beta, out, HW, groups, eps, silu);
+      static const int vw8 = getenv("SVG_GN_SMALL_VW8") ? atoi(getenv("SVG_GN_SMALL_VW8")) : 1;
+      if (vw8 && cpg % 8 == 0 && C1 % 8 == 0) {             // 16-byte pieces
+        if ((int64_t)HW * (cpg / 8) <= 256 * 5)
+          hipLaunchKernelGGL((gn_small_kernel<5, 8>), dim3(groups, B), dim3(256), 0, s, x, C1, x2, C2, gamma, beta, out, HW, groups, eps, silu);
+        else
+          hipLaunchKernelGGL((gn_small_kernel<10, 8>), dim3(groups, B), dim3(256), 0, s, x, C1, x2, C2, gamma, beta, out, HW, groups, eps, silu);
+      } else if ((int64_t)HW * (cpg / 4) <= 256 * 5)
+        hipLaunchKernelGGL((gn_small_kernel<5, 4>), dim3(groups, B), dim3(256), 0, s, x, C1, x2, C2, gamma, beta, out, HW, groups, eps, silu);
       else
-        hipLaunchKernelGGL(gn_small_kernel<20>, dim3(groups, B), dim3(256), 0, s, x, C1, x2, C2, gamma, beta, out, HW, groups, eps, silu);
+        hipLaunchKernelGGL((gn_small_kernel<20, 4>), dim3(groups, B), dim3(256), 0, s, x, C1, x2, C2, gamma, beta, out, HW, groups, eps, silu);
       check_launch("gn_small");
       return;
     }
