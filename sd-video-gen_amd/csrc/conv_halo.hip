@@ -408,13 +408,6 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
       for (int j = 0; j < NT; ++j) wf[j] = *(const h16x8*)(smem + waddr[kk] + stage * B_BYTES + j * 2048);
     };
 
-    // HALO_PRIO (compile-time experiment): 0 = s_setprio 1 around every MFMA segment (shipped), 1 = no priority changes, 2 = a static
-    // s_setprio 1 for the second wave group (MI355X_MICROARCH.md, two waves per SIMD, item 4), 3 = static for the first group
-#ifndef HALO_PRIO
-#define HALO_PRIO 0
-#endif
-    if (HALO_PRIO == 2 && grp == 1) __builtin_amdgcn_s_setprio(1);
-    if (HALO_PRIO == 3 && grp == 0) __builtin_amdgcn_s_setprio(1);
     for (int cc = cc_begin; cc < cc_end; ++cc) {
       const int pbuf = (cc - cc_begin) & 1;
       const int hn = (cc + 1 < cc_end) ? 1 : 0;
@@ -437,7 +430,7 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         bar();
         __builtin_amdgcn_sched_barrier(0);
-        if (HALO_PRIO == 0) __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -446,7 +439,7 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j) acc[i][j] = MFMA_16x16x32(w1[j], x1[i], acc[i][j]);
-        if (HALO_PRIO == 0) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         bar();
       }
