@@ -317,13 +317,33 @@ int svg_op_xf_gemm(svg_ctx* ctx, const float* X, const float* W, const float* bi
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* When enabled (on = 1), every launch of each kernel family is bracketed by hipEvents on its stream;
- * svg_prof_report synchronises and writes "name calls total_ms flops bytes\n" lines into buf.
+ * svg_prof_report waits for the context's own brackets (no device-wide sync) and writes "name calls total_ms flops bytes\n" lines into buf.
  * on = 2 additionally keeps one entry per call-site signature, reported as "@family|shape ..." lines. */
 int svg_prof_enable(svg_ctx* ctx, int on);
 int svg_prof_reset(svg_ctx* ctx);
 int svg_prof_report(svg_ctx* ctx, char* buf, int buflen);
 /* workspace bytes currently reserved by the context */
 int64_t svg_workspace_bytes(svg_ctx* ctx);
+
+/* ---- workspace ownership ("workspace arena sized at svg_create / first call; no allocation in steady state") ----
+ * The reference has no counterpart: torch's caching allocator serves its intermediates (utils/sd_utils.py:247-261 allocates per
+ * step).  Here every model call plans its intermediates into one arena per context.  A caller sizes it once:
+ *   svg_reserve_workspace   at least `bytes` of workspace from now on;
+ *   svg_plan_begin .. svg_plan_end   every model call in between runs its planning pass ONLY (nothing is launched, outputs are
+ *                           not written) and records its need; svg_plan_end reserves the largest and returns it in *bytes
+ *                           (the cross-attention K / V cache of svg_ddim_loop is sized too).
+ * A call that still needs more grows the arena without freeing or synchronising (the outgrown block is released by the next
+ * reserve / plan end / svg_destroy): safe while another thread of the process captures a stream.
+ * svg_workspace_growths: (re)allocations since svg_create — constant once the workload has been planned.
+ * Threads: one context per thread; svg_destroy, svg_model_configure, svg_finalize and svg_reserve_workspace synchronise the device
+ * and therefore wait for any other thread's capture window inside the library (the DDIM loop's, the training step's) to close. */
+int svg_reserve_workspace(svg_ctx* ctx, int64_t bytes);
+int svg_plan_begin(svg_ctx* ctx);
+int svg_plan_end(svg_ctx* ctx, int64_t* bytes);
+int64_t svg_workspace_growths(svg_ctx* ctx);
+/* capture windows open inside the library right now, over all contexts of the process (tests: drive a call into another
+ * thread's window, $SVG_TEST_CAPTURE_HOLD_MS keeps svg_ddim_loop's open) */
+int svg_debug_captures_active(void);
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,11 @@ SIGNATURES = {
     "svg_prof_reset": [_vp],
     "svg_prof_report": [_vp, C.c_char_p, _i],
     "svg_workspace_bytes": [_vp],
+    "svg_workspace_growths": [_vp],
+    "svg_reserve_workspace": [_vp, _i64],
+    "svg_plan_begin": [_vp],
+    "svg_plan_end": [_vp, C.POINTER(_i64)],
+    "svg_debug_captures_active": [],
 }
 # fp16-storage twins of the 16-bit operator hooks (svg_op_<name>_f16: same arguments)
 for _n in ("gemm", "conv3x3", "conv3x3_gn", "conv3x3_mx", "gemm_lnstats", "gemm_cat", "ff_fused", "xattn_fused", "quant_mx", "gemm_fp8", "groupnorm", "layernorm",
@@ -86,7 +91,7 @@ for _n in ("gemm", "conv3x3", "conv3x3_gn", "conv3x3_mx", "gemm_lnstats", "gemm_
     SIGNATURES["svg_op_%s_f16" % _n] = SIGNATURES["svg_op_" + _n]
 SIGNATURES["svg_model_dtype"] = [_vp, _i]
 _RESTYPES = {"svg_destroy": None, "svg_env_refresh": None, "svg_model_dtype": C.c_char_p, "svg_last_error": C.c_char_p, "svg_version": C.c_char_p,
-             "svg_workspace_bytes": _i64}
+             "svg_workspace_bytes": _i64, "svg_workspace_growths": _i64}
 
 
 def host_cpu_quota():
@@ -484,6 +489,39 @@ class Context:
     def workspace_bytes(self):
         return int(self.lib.svg_workspace_bytes(self.h))
 
+    def workspace_growths(self):
+        """(re)allocations of the workspace since the context was created: constant once the workload has been planned"""
+        return int(self.lib.svg_workspace_growths(self.h))
+
+    def reserve_workspace(self, nbytes):
+        self.check(self.lib.svg_reserve_workspace(self.h, int(nbytes)), "svg_reserve_workspace")
+
+    def planning(self):
+        """``with ctx.planning() as plan:`` — the model calls inside run their planning pass only (nothing is launched, the returned
+        tensors are NOT written); on exit the workspace is sized once for the largest of them (``plan.bytes``)."""
+        return _Planning(self)
+
+
+class _Planning:
+    def __init__(self, ctx):
+        self.ctx, self.bytes = ctx, None
+
+    def __enter__(self):
+        self.ctx.check(self.ctx.lib.svg_plan_begin(self.ctx.h), "svg_plan_begin")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        n = _i64(0)
+        rc = self.ctx.lib.svg_plan_end(self.ctx.h, C.byref(n))
+        self.bytes = n.value
+        if et is None:
+            self.ctx.check(rc, "svg_plan_end")
+        return False
+
+
+def captures_active():
+    """capture windows open inside the library right now (svg_debug_captures_active)"""
+    return int(load().svg_debug_captures_active())
 
 
 _default_ctx = {}

@@ -32,11 +32,15 @@ int svg_model_configure(svg_ctx* ctx, int model, const char* kv) {
   try {
     SVG_CHECK(ctx, "null context");
     // a new configuration starts a fresh model: drop the previous weights and packed buffers
-    if (WeightStore* old = store_of(ctx, model, true)) old->clear();
-    HIP_OK(hipDeviceSynchronize());
-    for (void* p : ctx->owned[model]) hipFree(p);
-    ctx->owned[model].clear();
-    if (model == SVG_TRANSFORMER) { xf_train_free(ctx->xf); ctx->xf->pe = nullptr; ctx->xf->iota = nullptr; }
+    {
+      DeviceWideScope lk;             // frees live device memory: not while another thread's stream is capturing
+      HIP_OK(hipDeviceSynchronize());
+      if (WeightStore* old = store_of(ctx, model, true)) old->clear();
+      for (void* p : ctx->owned[model]) hipFree(p);
+      ctx->owned[model].clear();
+      if (model == SVG_TRANSFORMER) xf_train_free(ctx->xf);
+    }
+    if (model == SVG_TRANSFORMER) { ctx->xf->pe = nullptr; ctx->xf->iota = nullptr; }
     if (model == SVG_VAE || model == SVG_UNET) {
       // storage type of the SD networks: f16=1 -> IEEE half (the reference's autocast arithmetic), default bf16
       auto m = parse_kv(kv);
@@ -60,7 +64,10 @@ int svg_load_weight(svg_ctx* ctx, int model, const char* name, const float* data
     WeightStore* ws = store_of(ctx, model, true);
     HIP_OK(hipSetDevice(ctx->device));
     ws->put(ctx, name, data, shape, ndim);
-    if (model == SVG_TRANSFORMER) { xf_train_free(ctx->xf); ctx->xf->ready = false; }   // new weights: a fresh optimizer state
+    if (model == SVG_TRANSFORMER) {   // new weights: a fresh optimizer state
+      if (ctx->xf->train) { DeviceWideScope lk; xf_train_free(ctx->xf); }
+      ctx->xf->ready = false;
+    }
     else if (model == SVG_VAE) ctx->vae->ready = false;
     else if (model == SVG_CLIP_TEXT) ctx->clip->ready = false;
     else if (model == SVG_MINILM) ctx->minilm->ready = false;
@@ -85,7 +92,10 @@ int svg_finalize(svg_ctx* ctx, int model, int64_t* n_params) {
       else ctx->unet->finalize(ctx, n_params);
     } catch (...) { ctx->cur_model = svg_ctx::kCtxSlot; throw; }
     ctx->cur_model = svg_ctx::kCtxSlot;
-    HIP_OK(hipDeviceSynchronize());
+    {
+      DeviceWideScope lk;
+      HIP_OK(hipDeviceSynchronize());
+    }
     return 0;
   } catch (const std::exception& e) { return svg_fail(ctx, e); }
 }

@@ -9,6 +9,9 @@
 #include <cstdio>
 #include <cstring>
 #include <cmath>
+#include <atomic>
+#include <mutex>
+#include <shared_mutex>
 
 // Storage type of the Stable-Diffusion side (activations and packed weights; accumulation is always f32).  Every SD source is
 // compiled twice into libsvg_hip.so: once with h16 = bf16 (namespace sd_bf16, the default) and once with -DSVG_F16, h16 = IEEE
@@ -137,8 +140,36 @@ struct svg_ctx {
   std::vector<void*> owned[7];   // device allocations per model id (kCtxSlot = context) freed at reconfigure / destroy
   int cur_model = kCtxSlot;
   uint64_t* seed_scratch = nullptr;   // device word for svg_op_dropout_mask
+  // Workspace growth never frees and never synchronises: the outgrown block may still be read by this context's queued kernels and
+  // another thread of the process may be inside a stream capture (where a device-wide sync is an error).  Outgrown blocks are parked
+  // here and released by release_retired() at the points that hold the device-wide lock (reserve / plan end / destroy).
+  std::vector<DevBuf> arena_retired;
+  int64_t arena_growths = 0;          // (re)allocations of the workspace since svg_create: constant in steady state
+  // svg_plan_begin .. svg_plan_end: every planned call runs its dry pass only (nothing is launched) and the largest workspace
+  // need is kept; svg_plan_end sizes the arena for it once
+  bool plan_only = false;
+  int64_t plan_high = 0;
   void* dalloc(int64_t bytes);
   void ensure_arena(int64_t bytes);
+  void release_retired();             // caller holds DeviceWideScope
+};
+
+// One process-wide lock between stream captures and device-wide operations.  HIP rejects hipDeviceSynchronize (and anything that
+// implies it: hipFree of live memory, re-finalize) while ANY stream of the process is capturing, whichever thread asks.  Capture
+// windows (the DDIM loop's second step, the training step) hold it shared; every device-wide synchronisation / free holds it
+// exclusive and therefore waits the few milliseconds a capture window takes to record.
+std::shared_mutex& svg_capture_mutex();
+extern std::atomic<int> g_captures_active;          // capture windows open right now (svg_debug_captures_active)
+struct CaptureScope {
+  std::shared_lock<std::shared_mutex> lk;
+  CaptureScope() : lk(svg_capture_mutex()) { g_captures_active.fetch_add(1); }
+  ~CaptureScope() { g_captures_active.fetch_sub(1); }
+  CaptureScope(const CaptureScope&) = delete;
+};
+struct DeviceWideScope {
+  std::unique_lock<std::shared_mutex> lk;
+  DeviceWideScope() : lk(svg_capture_mutex()) {}
+  DeviceWideScope(const DeviceWideScope&) = delete;
 };
 
 // Kernel families for the profiler (index into prof_entries)

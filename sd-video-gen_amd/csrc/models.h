@@ -1,6 +1,7 @@
 // Model graphs executed by the library: latent Transformer, SD VAE, SD UNet, DDIM loop.
 #pragma once
 #include "kernels.h"
+#include <algorithm>
 #include <initializer_list>
 #include <memory>
 
@@ -17,7 +18,7 @@ struct WeightStore {
 
 std::unordered_map<std::string, std::vector<int64_t>> parse_kv(const char* kv);
 
-// Plans a call twice: a dry pass measures the arena high-water mark, then the real pass launches.
+// Plans a call twice: a dry pass measures the arena high-water mark, then the real pass launches (in plan mode: the dry pass only).
 template <typename F>
 inline void run_planned(svg_ctx* ctx, F&& body) {
   ctx->arena.reset();
@@ -25,6 +26,11 @@ inline void run_planned(svg_ctx* ctx, F&& body) {
   ctx->arena.high = 0;
   try { body(); } catch (...) { ctx->arena.dry = false; throw; }
   ctx->arena.dry = false;
+  if (ctx->plan_only) {   // svg_plan_begin .. svg_plan_end: only the need is recorded
+    ctx->plan_high = std::max(ctx->plan_high, ctx->arena.high);
+    ctx->arena.reset();
+    return;
+  }
   ctx->ensure_arena(ctx->arena.high);
   ctx->arena.reset();
   body();

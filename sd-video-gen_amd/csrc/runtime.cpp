@@ -26,18 +26,38 @@ void* svg_ctx::dalloc(int64_t bytes) {
   return p;
 }
 
+std::shared_mutex& svg_capture_mutex() {
+  static std::shared_mutex mu;
+  return mu;
+}
+std::atomic<int> g_captures_active{0};
+
+// Grows the workspace WITHOUT freeing and WITHOUT synchronising: the outgrown block stays alive (kernels this context queued may
+// still read it; another thread may be capturing, where hipDeviceSynchronize / hipFree are errors) and is parked in arena_retired.
+// Callers that size the workspace up front (svg_plan_begin/_end, svg_reserve_workspace) never get here in steady state.
 void svg_ctx::ensure_arena(int64_t bytes) {
   bytes = align_up(bytes + (1 << 20), 1 << 20);
   if (arena_buf.bytes >= bytes) return;
-  if (arena_buf.p) {
+  int64_t parked = 0;
+  for (const DevBuf& b : arena_retired) parked += b.bytes;
+  if (parked > ((int64_t)8 << 30)) {            // bound what growth-by-growth use can strand: wait for the captures to end, release
+    DeviceWideScope lk;
     HIP_OK(hipDeviceSynchronize());
-    HIP_OK(hipFree(arena_buf.p));
-    arena_buf.p = nullptr;
+    release_retired();
   }
-  HIP_OK(hipMalloc(&arena_buf.p, (size_t)bytes));
+  void* p = nullptr;
+  HIP_OK(hipMalloc(&p, (size_t)bytes));
+  if (arena_buf.p) arena_retired.push_back(arena_buf);
+  arena_buf.p = p;
   arena_buf.bytes = bytes;
-  arena.base = (char*)arena_buf.p;
+  arena.base = (char*)p;
   arena.cap = bytes;
+  ++arena_growths;
+}
+
+void svg_ctx::release_retired() {
+  for (DevBuf& b : arena_retired) hipFree(b.p);
+  arena_retired.clear();
 }
 
 ProfScope::ProfScope(svg_ctx* c_, int kind_, hipStream_t s_, double flops, double bytes, const char* tag) : c(c_), kind(kind_), s(s_) {
@@ -205,9 +225,11 @@ int svg_create(int device_id, svg_ctx** out) {
 
 void svg_destroy(svg_ctx* ctx) {
   if (!ctx) return;
+  DeviceWideScope lk;                 // waits for capture windows of other threads: a device-wide sync inside one is an error
   hipDeviceSynchronize();
   destroy_models(ctx);
   for (auto& v : ctx->owned) for (void* p : v) hipFree(p);
+  ctx->release_retired();
   if (ctx->arena_buf.p) hipFree(ctx->arena_buf.p);
   for (auto e : ctx->ev_pool) hipEventDestroy(e);
   delete ctx;
@@ -216,6 +238,37 @@ void svg_destroy(svg_ctx* ctx) {
 const char* svg_last_error(svg_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
 int64_t svg_workspace_bytes(svg_ctx* ctx) { return ctx ? ctx->arena_buf.bytes : 0; }
+int64_t svg_workspace_growths(svg_ctx* ctx) { return ctx ? ctx->arena_growths : 0; }
+int svg_debug_captures_active(void) { return g_captures_active.load(); }
+
+int svg_reserve_workspace(svg_ctx* ctx, int64_t bytes) {
+  API_BEGIN
+  SVG_CHECK(ctx && bytes >= 0, "svg_reserve_workspace: bad arguments");
+  HIP_OK(hipSetDevice(ctx->device));
+  ctx->ensure_arena(bytes);
+  if (!ctx->arena_retired.empty()) {
+    DeviceWideScope lk;
+    HIP_OK(hipDeviceSynchronize());   // kernels queued on the outgrown blocks
+    ctx->release_retired();
+  }
+  API_END(ctx)
+}
+int svg_plan_begin(svg_ctx* ctx) {
+  API_BEGIN
+  SVG_CHECK(ctx, "svg_plan_begin: null context");
+  ctx->plan_only = true;
+  ctx->plan_high = 0;
+  API_END(ctx)
+}
+int svg_plan_end(svg_ctx* ctx, int64_t* bytes) {
+  API_BEGIN
+  SVG_CHECK(ctx && ctx->plan_only, "svg_plan_end without svg_plan_begin");
+  ctx->plan_only = false;
+  if (bytes) *bytes = ctx->plan_high;
+  const int rc = svg_reserve_workspace(ctx, ctx->plan_high);
+  if (rc != 0) return rc;
+  API_END(ctx)
+}
 
 int svg_prof_enable(svg_ctx* ctx, int on) {
   if (!ctx) return -1;
@@ -223,9 +276,13 @@ int svg_prof_enable(svg_ctx* ctx, int on) {
   ctx->prof_detail = on == 2;
   return 0;
 }
+// the brackets of this context only: no device-wide synchronisation (another thread may be capturing)
+static void prof_wait(svg_ctx* ctx) {
+  for (size_t i = 0; i < ctx->ev_used; ++i) HIP_OK(hipEventSynchronize(ctx->ev_pool[i]));
+}
 int svg_prof_reset(svg_ctx* ctx) {
   API_BEGIN
-  HIP_OK(hipDeviceSynchronize());
+  prof_wait(ctx);
   for (auto& e : ctx->prof_entries) { e.calls = 0; e.flops = 0; e.bytes = 0; e.ev.clear(); }
   ctx->prof_shapes.clear();
   ctx->ev_used = 0;
@@ -233,7 +290,7 @@ int svg_prof_reset(svg_ctx* ctx) {
 }
 int svg_prof_report(svg_ctx* ctx, char* buf, int buflen) {
   API_BEGIN
-  HIP_OK(hipDeviceSynchronize());
+  prof_wait(ctx);
   std::ostringstream os;
   for (auto& e : ctx->prof_entries) {
     if (!e.calls) continue;

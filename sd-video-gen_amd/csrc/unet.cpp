@@ -2,7 +2,9 @@
 // (utils/sd_utils.py:222-267) on NHWC bf16 activations.
 #include "models.h"
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
+#include <thread>
 
 namespace SDNS {
 
@@ -504,11 +506,17 @@ struct UnetRun {
       const int idx = xf_idx++;
       const int64_t kn = (int64_t)N * L * C, vn = (int64_t)N * C * Lp;
       h16 *k, *vt;
-      if (cache && SVG_LAUNCHING(ctx)) {
-        if ((int)cache->k.size() <= idx) { cache->k.resize(idx + 1, nullptr); cache->vt.resize(idx + 1, nullptr); cache->k_cap.resize(idx + 1, 0); cache->vt_cap.resize(idx + 1, 0); }
-        if (cache->k_cap[idx] < kn) { cache->k[idx] = (h16*)ctx->dalloc(kn * sizeof(h16)); cache->k_cap[idx] = kn; cache->valid = false; }
-        if (cache->vt_cap[idx] < vn) { cache->vt[idx] = (h16*)ctx->dalloc(vn * sizeof(h16)); cache->vt_cap[idx] = vn; cache->valid = false; }
-        k = cache->k[idx]; vt = cache->vt[idx];
+      h16* const unset = (h16*)(uintptr_t)0x1000;     // dry pass before the cache exists: never dereferenced (nothing is launched)
+      // the cache lives outside the arena (it survives the call); plan mode sizes it too, so the first real step allocates nothing
+      const bool grow_cache = cache && (SVG_LAUNCHING(ctx) || ctx->plan_only);
+      if (cache) {
+        if (grow_cache) {
+          if ((int)cache->k.size() <= idx) { cache->k.resize(idx + 1, nullptr); cache->vt.resize(idx + 1, nullptr); cache->k_cap.resize(idx + 1, 0); cache->vt_cap.resize(idx + 1, 0); }
+          if (cache->k_cap[idx] < kn) { cache->k[idx] = (h16*)ctx->dalloc(kn * sizeof(h16)); cache->k_cap[idx] = kn; cache->valid = false; }
+          if (cache->vt_cap[idx] < vn) { cache->vt[idx] = (h16*)ctx->dalloc(vn * sizeof(h16)); cache->vt_cap[idx] = vn; cache->valid = false; }
+        }
+        const bool have = idx < (int)cache->k.size() && cache->k[idx];
+        k = have ? cache->k[idx] : unset; vt = have ? cache->vt[idx] : unset;
       } else {
         k = ctx->arena.get<h16>(kn);
         vt = ctx->arena.get<h16>(vn);
@@ -516,13 +524,16 @@ struct UnetRun {
       h16 *kp = nullptr, *vp = nullptr;
       if (xa_one) {
         const int64_t pn = xattn_kv_pack_elems(N);
-        if (cache && SVG_LAUNCHING(ctx)) {
-          if ((int)cache->kp.size() <= idx) { cache->kp.resize(idx + 1, nullptr); cache->vp.resize(idx + 1, nullptr); cache->kvp_cap.resize(idx + 1, 0); }
-          if (cache->kvp_cap[idx] < pn) {
-            cache->kp[idx] = (h16*)ctx->dalloc(pn * sizeof(h16)); cache->vp[idx] = (h16*)ctx->dalloc(pn * sizeof(h16));
-            cache->kvp_cap[idx] = pn; cache->valid = false;
+        if (cache) {
+          if (grow_cache) {
+            if ((int)cache->kp.size() <= idx) { cache->kp.resize(idx + 1, nullptr); cache->vp.resize(idx + 1, nullptr); cache->kvp_cap.resize(idx + 1, 0); }
+            if (cache->kvp_cap[idx] < pn) {
+              cache->kp[idx] = (h16*)ctx->dalloc(pn * sizeof(h16)); cache->vp[idx] = (h16*)ctx->dalloc(pn * sizeof(h16));
+              cache->kvp_cap[idx] = pn; cache->valid = false;
+            }
           }
-          kp = cache->kp[idx]; vp = cache->vp[idx];
+          const bool have = idx < (int)cache->kp.size() && cache->kp[idx];
+          kp = have ? cache->kp[idx] : unset; vp = have ? cache->vp[idx] : unset;
         } else {
           kp = ctx->arena.get<h16>(pn);
           vp = ctx->arena.get<h16>(pn);
@@ -758,15 +769,22 @@ void UnetModel::ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const flo
     one_step(start_step, true);                        // direct launches: fills the K / V^T cache, bumps the counter
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    try {
-      one_step(start_step + 1, true);
-    } catch (...) {
-      hipStreamEndCapture(s, &graph);
-      if (graph) hipGraphDestroy(graph);
-      throw;
+    {
+      // Shared with other captures, exclusive against every device-wide synchronisation of the library (common.h): HIP rejects
+      // hipDeviceSynchronize from ANY thread while this window is open (BENCH_r05: the other stream group's workspace growth).
+      CaptureScope cap;
+      HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      try {
+        one_step(start_step + 1, true);
+        // test hook: keep the window open so that a test can drive another context's calls into it (tests/test_streams_gpu.py)
+        if (const int64_t hold = svg_env_i64("SVG_TEST_CAPTURE_HOLD_MS", 0)) std::this_thread::sleep_for(std::chrono::milliseconds(hold));
+      } catch (...) {
+        hipStreamEndCapture(s, &graph);
+        if (graph) hipGraphDestroy(graph);
+        throw;
+      }
+      HIP_OK(hipStreamEndCapture(s, &graph));
     }
-    HIP_OK(hipStreamEndCapture(s, &graph));
     hipError_t ge = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     if (ge != hipSuccess) { hipGraphDestroy(graph); HIP_OK(ge); }
     for (int i = start_step + 1; i < num_steps; ++i) {

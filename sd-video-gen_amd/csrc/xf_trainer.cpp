@@ -408,16 +408,19 @@ void loss_pass(svg_ctx* ctx, XfModel* m, const svg_train_cfg& cfg, const float* 
     if (!pl->exec || pl->arena_base != ctx->arena.base) {       // first use, or the workspace moved since the capture
       if (pl->exec) { HIP_OK(hipGraphExecDestroy(pl->exec)); pl->exec = nullptr; }
       hipGraph_t g = nullptr;
-      HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-      try {
-        ctx->arena.reset();
-        body(pl->src, pl->tgt, pl->exp, pl->text, pl->mask);
-      } catch (...) {
-        hipStreamEndCapture(s, &g);
-        if (g) hipGraphDestroy(g);
-        throw;
+      {
+        CaptureScope cap;             // shared with other captures, exclusive against device-wide syncs (common.h)
+        HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        try {
+          ctx->arena.reset();
+          body(pl->src, pl->tgt, pl->exp, pl->text, pl->mask);
+        } catch (...) {
+          hipStreamEndCapture(s, &g);
+          if (g) hipGraphDestroy(g);
+          throw;
+        }
+        HIP_OK(hipStreamEndCapture(s, &g));
       }
-      HIP_OK(hipStreamEndCapture(s, &g));
       const hipError_t e = hipGraphInstantiate(&pl->exec, g, nullptr, nullptr, 0);
       hipGraphDestroy(g);
       HIP_OK(e);
@@ -437,6 +440,7 @@ void loss_pass(svg_ctx* ctx, XfModel* m, const svg_train_cfg& cfg, const float* 
 
 }  // namespace
 
+// caller holds DeviceWideScope when m->train exists (svg_destroy, svg_model_configure, svg_load_weight)
 void xf_train_free(XfModel* m) {
   if (!m->train) return;
   hipDeviceSynchronize();

@@ -32,7 +32,7 @@ def clip_noise(seeds, shape, device):
 
 def sample_clips(model, sd_utils, clips_u8, pred_frames, denoise=False, start_step=40, seeds=None,
                  text_embeddings=None, num_inference_steps=50, guidance_scale=0.0, return_frames=False, res=512,
-                 cls_list=None, cpu_noise=False, latent_denoise=False):
+                 cls_list=None, cpu_noise=False, latent_denoise=False, _planning=False):
     """The per-clip loop of prediction/predict.py:117-197 for C independent clips in lock step, device resident.
 
     clips_u8: (C,T,F,F,3) uint8 conditioning frames on the device (T = 5 in prediction/predict.py; the FVD loop of
@@ -47,11 +47,18 @@ def sample_clips(model, sd_utils, clips_u8, pred_frames, denoise=False, start_st
     512-pixel latent grid and denoised, instead of being decoded, resized as an image and re-encoded first.
     ``cpu_noise``: the per-clip generators live on the host (bit-reproducible on a machine without the GPU: the committed
     oracle fixtures of tests/golden/sd_*.pt were drawn that way); default is the device generator, like the reference.
+    Workspace: the first call of a given shape signature on a context first runs itself in the library's planning mode (every model
+    call records its workspace need, nothing is launched) and sizes the context's arena ONCE for the largest; the real calls then
+    allocate nothing (SURVEY 8(b) Ownership; `ctx.workspace_growths()` stays constant).
     Returns all_latents (C, 4+N, D_lat) f32 [and the decoded frames (C,4+N,F,F,3) uint8].
     """
     ctx = sd_utils.vae.ctx                      # (checked: the context's slots still hold this SDUtils' networks)
     if denoise:
         assert sd_utils.unet is not None and sd_utils.unet.ctx is ctx, "sample_clips(denoise=True) needs SDUtils built with --denoise"
+    if not _planning:
+        plan_workspace(model, sd_utils, clips_u8, pred_frames, denoise=denoise, start_step=start_step, text_embeddings=text_embeddings,
+                       num_inference_steps=num_inference_steps, guidance_scale=guidance_scale, return_frames=return_frames, res=res,
+                       cls_list=cls_list, latent_denoise=latent_denoise)
     dev = clips_u8.device
     C, T, F = clips_u8.shape[0], clips_u8.shape[1], clips_u8.shape[2]
     assert 2 <= T <= 31, "conditioning frames: 5 in predict.py:57, 16 in predict_text.py:133 (the library serves sequences up to 32 tokens)"
@@ -101,14 +108,40 @@ def sample_clips(model, sd_utils, clips_u8, pred_frames, denoise=False, start_st
         return all_latents, frames
 
 
+def plan_workspace(model, sd_utils, clips_u8, pred_frames, **kw):
+    """Size the context's workspace once for `sample_clips(model, sd_utils, clips_u8, pred_frames, **kw)`: the same call sequence in
+    the library's planning mode (svg_plan_begin .. svg_plan_end: nothing is launched), once per shape signature and context.
+    Returns True when it planned, False when that signature was already planned."""
+    ctx = sd_utils.vae.ctx
+    emb, cl = kw.get("text_embeddings"), kw.get("cls_list")
+    key = ("sample_clips", id(model), tuple(clips_u8.shape), int(pred_frames), bool(kw.get("denoise")), int(kw.get("start_step", 40)),
+           int(kw.get("num_inference_steps", 50)), float(kw.get("guidance_scale", 0.0)) != 0.0, bool(kw.get("return_frames")), int(kw.get("res", 512)),
+           bool(kw.get("latent_denoise")), None if emb is None else tuple(emb.shape), cl is not None)
+    kw = {k: v for k, v in kw.items() if k not in ("seeds", "cpu_noise")}
+    seen = ctx.__dict__.setdefault("_planned", set())
+    if key in seen:
+        return False
+    import contextlib
+    from . import _lib
+    mctx = getattr(model, "_bound_ctx", None) or _lib.default_context()      # the latent Transformer may live on another context
+    with contextlib.ExitStack() as st:
+        for c in ([ctx] if mctx is ctx else [ctx, mctx]):
+            st.enter_context(c.planning())
+        sample_clips(model, sd_utils, clips_u8, pred_frames, _planning=True, **kw)
+    seen.add(key)
+    return True
+
+
 def sample_clips_streams(workers, clips_u8, pred_frames, seeds, **kw):
     """Run `sample_clips` on several (model, sd_utils, stream) workers at once: the clips are split into contiguous
     groups, each group is driven by its own host thread on its own HIP stream and library context (full weight
     replica each), so kernels of different groups can share the GPU (ALU/HBM-bound normalisation and softmax work of
-    one group under the MFMA-bound convs of another).  Results equal one call on all clips up to the bf16 rounding that a
-    different rows-per-launch count brings (tile width / split-K selection: measured <= 1e-2 rel-L2 on the full-size UNet,
-    tests/test_fullsize_gpu.py); the f32 latent-Transformer part is bitwise equal.  ``text_embeddings`` of per-clip form
-    (2*C rows: [uncond(C); cond(C)]) are sliced per group."""
+    one group under the MFMA-bound convs of another).  Results equal one call on all clips up to the 16-bit rounding that a
+    different rows-per-launch count brings (tile width / split-K selection); the f32 latent-Transformer part is bitwise equal
+    (tests/test_streams_gpu.py: reduced width with denoising, and full size with start_step 48).  ``text_embeddings`` of per-clip
+    form (2*C rows: [uncond(C); cond(C)]) are sliced per group.
+    Every group's workspace is planned on the CALLING thread before the worker threads start (plan_workspace): a DDIM loop captures
+    its step as a hipGraph, and no thread may allocate-and-free or synchronise the device while another one is capturing."""
     import threading
     n = clips_u8.shape[0]
     G = len(workers)
@@ -117,20 +150,28 @@ def sample_clips_streams(workers, clips_u8, pred_frames, seeds, **kw):
     errs = []
     cur = torch.cuda.current_stream()
 
+    def group_kw(g):
+        a, b = bounds[g], bounds[g + 1]
+        kwg = dict(kw)
+        emb = kwg.get("text_embeddings")
+        if emb is not None and emb.shape[0] == 2 * n and n > 1:      # per-clip embeddings: this group's rows of each half
+            kwg["text_embeddings"] = torch.cat([emb[a:b], emb[n + a:n + b]])
+        cl = kwg.get("cls_list")
+        if cl is not None:
+            kwg["cls_list"] = cl[a:b]
+        return kwg
+
+    for g in range(G):
+        if bounds[g + 1] > bounds[g]:
+            plan_workspace(workers[g][0], workers[g][1], clips_u8[bounds[g]:bounds[g + 1]], pred_frames, **group_kw(g))
+
     def run(g):
         try:
             model, sdu, stream = workers[g]
             a, b = bounds[g], bounds[g + 1]
-            kwg = dict(kw)
-            emb = kwg.get("text_embeddings")
-            if emb is not None and emb.shape[0] == 2 * n and n > 1:      # per-clip embeddings: this group's rows of each half
-                kwg["text_embeddings"] = torch.cat([emb[a:b], emb[n + a:n + b]])
-            cl = kwg.get("cls_list")
-            if cl is not None:
-                kwg["cls_list"] = cl[a:b]
             stream.wait_stream(cur)
             with torch.cuda.stream(stream):
-                out[g] = sample_clips(model, sdu, clips_u8[a:b], pred_frames, seeds=seeds[a:b], **kwg)
+                out[g] = sample_clips(model, sdu, clips_u8[a:b], pred_frames, seeds=seeds[a:b], **group_kw(g))
         except Exception as e:      # surfaced on the caller's thread
             errs.append(e)
     threads = [threading.Thread(target=run, args=(g,)) for g in range(G) if bounds[g + 1] > bounds[g]]

@@ -254,8 +254,10 @@ def test_error_codes_map_to_exceptions(ctx):
 def test_bench_spawns_its_ranks():
     """`python bench.py --gpus 2` with no launcher: the script starts torch.distributed.run itself (before any GPU call in
     the parent) and rank 0 prints ONE JSON line with n_gpus 2.  Both ranks share the box's single GPU here (gloo + device
-    override: the rehearsal knobs), tiny step (1 clip per rank, last DDIM step only)."""
-    env = dict(os.environ, SVG_DIST_BACKEND="gloo", SVG_DEVICE_OVERRIDE="0")
+    override: the rehearsal knobs), tiny step (1 clip per rank, last DDIM step only).  An optional pass that FAILS on rank 0 after
+    the headline (the $SVG_BENCH_FAIL_EXTRA hook stands in for extras.fp8_same_box raising, as in BENCH_r05) still leaves the
+    line and exit code 0, with the failure recorded under its own key."""
+    env = dict(os.environ, SVG_DIST_BACKEND="gloo", SVG_DEVICE_OVERRIDE="0", SVG_BENCH_FAIL_EXTRA="1")
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--clips", "1",
@@ -266,6 +268,7 @@ def test_bench_spawns_its_ranks():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_clips"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert "SVG_BENCH_FAIL_EXTRA" in d["extras"]["fp8_same_box"]["error"]
 
 
 def test_rccl_gathers_device_tensors_in_a_one_rank_group():

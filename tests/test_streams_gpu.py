@@ -1,0 +1,265 @@
+"""GPU: the function the headline times — `sample_clips_streams` (two library contexts, two host threads, two HIP streams, a
+hipGraph capture in each DDIM loop) — and the library's rules for concurrent contexts.
+
+The reference samples on one stream (prediction/predict.py:117-197, utils/sd_utils.py:247-261); running two clip groups at once is
+this implementation's own addition, so it carries its own tests:
+  * a call on one context may need a larger workspace while another thread's DDIM loop is inside its stream-capture window
+    (BENCH_r05 died exactly there: a device-wide sync inside the growth);
+  * the workspace is planned once per workload (svg_plan_begin / svg_plan_end) and nothing is allocated afterwards;
+  * the threaded form returns what one call on all clips returns, and what the CPU loop oracle returns.
+"""
+import os
+import sys
+import threading
+import time
+
+import pytest
+import torch
+
+from conftest import margin, rel_l2, sd_tol
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import loop_oracle, sd_oracle as SO  # noqa: E402
+from sd_video_gen_amd import _lib  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+VCFG = dict(block_out=(64, 128, 128, 128), layers=1, groups=32, latent=4)
+UCFG = dict(block_out=(64, 128), layers=1, heads=4, ctx_dim=768, groups=32, in_ch=4, out_ch=4, attn=(1, 0))
+
+
+def _worker(vsd, usd, arch, seed=3, d_model=64, layers=(1, 2)):
+    """a fresh context with its own replica of the networks + a latent Transformer bound to it + a stream of its own"""
+    from sd_video_gen_amd.sd_utils import SDUtils
+    from sd_video_gen_amd.transformer import Transformer
+    c = _lib.Context(0)
+    sdu = SDUtils(weights={"vae": vsd, "unet": usd, "text_encoder": "synthetic"}, arch=arch, verbose=False, ctx=c)
+    torch.manual_seed(seed)
+    m = Transformer(dim_model=d_model, num_heads=4, num_encoder_layers=layers[0], num_decoder_layers=layers[1]).eval().use_context(c)
+    return m, sdu, torch.cuda.Stream()
+
+
+def _small_nets(seed=3):
+    return SO.seeded_weights(SO.vae_shapes(VCFG), seed), SO.seeded_weights(SO.unet_shapes(UCFG), seed + 1)
+
+
+def _clip_noise_cpu(seed, res, F, pred_frames, start_step):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    L = F // 8
+    n = {"cond": torch.randn((5, 4, L, L), generator=g, device="cuda").cpu(), "e512": [], "add": [], "eF": []}
+    for _ in range(pred_frames):
+        n["e512"].append(torch.randn((4, res // 8, res // 8), generator=g, device="cuda").cpu())
+        if start_step > 0:
+            n["add"].append(torch.randn((4, res // 8, res // 8), generator=g, device="cuda").cpu())
+        n["eF"].append(torch.randn((4, L, L), generator=g, device="cuda").cpu())
+    return n
+
+
+def _set_cfg(denoise=True, name="model_10_26"):
+    from sd_video_gen_amd import config as svg_config
+    svg_config.set_args(["--dataset", "synthetic-ball", "--config", name] + (["--denoise", "1"] if denoise else []))
+
+
+def test_workspace_growth_inside_another_threads_capture_window(monkeypatch):
+    """Thread A's DDIM loop is held inside hipStreamBeginCapture .. EndCapture ($SVG_TEST_CAPTURE_HOLD_MS) while thread B, on a FRESH
+    context, makes calls that each need a larger workspace than the one before, reads its profile brackets and resets them.  The
+    round-5 library failed here ("operation not permitted when stream is capturing": ensure_arena synchronised the device)."""
+    _set_cfg()
+    vsd, usd = _small_nets()
+    arch = {"vae": VCFG, "unet": UCFG}
+    mA, sduA, sA = _worker(vsd, usd, arch)
+    mB, sduB, sB = _worker(vsd, usd, arch)
+    cA, cB = sduA.ctx, sduB.ctx
+    emb = sduA.encode_text([""])
+    z0 = torch.randn(2, 4, 16, 16, device="cuda")
+    nz = torch.randn(2, 4, 16, 16, device="cuda")
+    torch.cuda.synchronize()
+    # reference results, nothing concurrent
+    with torch.cuda.stream(sA):
+        want_A = cA.ddim_loop(z0, emb.repeat_interleave(2, 0), num_steps=50, start_step=44, guidance=0.0, noise=nz)
+    imgs = [torch.randint(0, 256, (n, 64, 64, 3), dtype=torch.uint8, device="cuda") for n in (1, 2, 3, 5, 8)]
+    eps = [torch.randn(n, 4, 8, 8, device="cuda") for n in (1, 2, 3, 5, 8)]
+    cQ = _worker(vsd, usd, arch)[1].ctx
+    want_B = [cQ.vae_encode(i, eps=e) for i, e in zip(imgs, eps)]
+    torch.cuda.synchronize()
+
+    monkeypatch.setenv("SVG_TEST_CAPTURE_HOLD_MS", "1500")
+    _lib.env_refresh()
+    got, errs, seen = {}, [], {"inside": 0, "growths": 0}
+
+    def run_A():
+        try:
+            with torch.cuda.stream(sA):
+                got["A"] = cA.ddim_loop(z0, emb.repeat_interleave(2, 0), num_steps=50, start_step=44, guidance=0.0, noise=nz)
+            sA.synchronize()
+        except Exception as e:   # noqa: BLE001
+            errs.append(("A", e))
+
+    def run_B():
+        try:
+            t0 = time.time()
+            while _lib.captures_active() == 0 and time.time() - t0 < 20:
+                time.sleep(0.001)
+            assert _lib.captures_active() > 0, "thread A never opened its capture window"
+            out = []
+            with torch.cuda.stream(sB):
+                cB.prof_enable(True)
+                for i, e in zip(imgs, eps):
+                    g0 = cB.workspace_growths()
+                    out.append(cB.vae_encode(i, eps=e))
+                    seen["growths"] += cB.workspace_growths() - g0
+                    seen["inside"] += int(_lib.captures_active() > 0)
+                rep = cB.prof_report()           # waits for B's own brackets only
+                cB.prof_reset()
+                cB.prof_enable(False)
+                assert rep["conv3x3"]["calls"] > 0
+            sB.synchronize()
+            got["B"] = out
+        except Exception as e:   # noqa: BLE001
+            errs.append(("B", e))
+
+    ta, tb = threading.Thread(target=run_A), threading.Thread(target=run_B)
+    ta.start(); tb.start(); ta.join(); tb.join()
+    monkeypatch.delenv("SVG_TEST_CAPTURE_HOLD_MS")
+    _lib.env_refresh()
+    assert not errs, errs
+    # the calls really fell into the window, and really had to grow (second and later growths replace a live block)
+    assert seen["inside"] >= 3 and seen["growths"] >= 3, seen
+    assert torch.equal(got["A"], want_A)
+    for a, b in zip(got["B"], want_B):
+        assert torch.equal(a, b)
+    # a device-wide operation requested during a capture waits for the window instead of failing
+    monkeypatch.setenv("SVG_TEST_CAPTURE_HOLD_MS", "600")
+    _lib.env_refresh()
+    errs.clear()
+    ta = threading.Thread(target=run_A)
+    ta.start()
+    t0 = time.time()
+    while _lib.captures_active() == 0 and time.time() - t0 < 20:
+        time.sleep(0.001)
+    cB.reserve_workspace(cB.workspace_bytes() + (64 << 20))        # grows, then releases the outgrown blocks under the device-wide lock
+    assert _lib.captures_active() == 0                              # ... which it only gets once A's window has closed
+    cQ.close()                                                      # svg_destroy: device-wide as well
+    ta.join()
+    assert not errs, errs
+    assert torch.equal(got["A"], want_A)
+
+
+def test_workspace_is_planned_once_and_steady_state_allocates_nothing():
+    """SURVEY 8(b) Ownership: the first sample_clips call of a workload plans every model call's workspace (nothing launched) and sizes
+    the arena once; the real calls — and every later step — leave svg_workspace_growths and svg_workspace_bytes unchanged."""
+    from sd_video_gen_amd.predict import sample_clips, bouncing_ball_clips, plan_workspace
+    _set_cfg()
+    vsd, usd = _small_nets()
+    m, sdu, _ = _worker(vsd, usd, {"vae": VCFG, "unet": UCFG})
+    c = sdu.ctx
+    emb = sdu.encode_text([""])
+    clips = bouncing_ball_clips(3, 64, 5, seed=2).cuda()
+    kw = dict(denoise=True, start_step=46, text_embeddings=emb, res=128)
+    g0 = c.workspace_growths()
+    assert plan_workspace(m, sdu, clips, 2, **kw) is True
+    g1, b1 = c.workspace_growths(), c.workspace_bytes()
+    assert g1 == g0 + 1 and b1 > 0                                  # ONE allocation for the whole loop
+    assert plan_workspace(m, sdu, clips, 2, **kw) is False          # same signature: nothing to do
+    a = sample_clips(m, sdu, clips, 2, seeds=[1, 2, 3], **kw)
+    b = sample_clips(m, sdu, clips, 2, seeds=[1, 2, 3], **kw)
+    torch.cuda.synchronize()
+    assert c.workspace_growths() == g1 and c.workspace_bytes() == b1
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    # explicit form of the same: reserve, then a smaller call does not touch the arena
+    c.reserve_workspace(b1 + (32 << 20))
+    g2 = c.workspace_growths()
+    assert g2 == g1 + 1 and c.workspace_bytes() >= b1 + (32 << 20)
+    sample_clips(m, sdu, clips[:1], 1, seeds=[1], **kw)
+    assert c.workspace_growths() == g2
+    # planning leaves no trace in results: a context that never planned (calls grow as they come) agrees bit for bit
+    m2, sdu2, _ = _worker(vsd, usd, {"vae": VCFG, "unet": UCFG})
+    a2 = sample_clips(m2, sdu2, clips, 2, seeds=[1, 2, 3], _planning=True, **kw)    # _planning=True: skip the planning pass
+    assert sdu2.ctx.workspace_growths() >= 1
+    assert torch.equal(a, a2)
+
+
+def test_latent_transformer_is_bitwise_equal_across_stream_groups():
+    """the f32 part of the claim in sample_clips_streams' docstring: a clip's Transformer forward does not depend on which context,
+    thread or stream ran it, nor on how many clips shared the launch"""
+    from sd_video_gen_amd.predict import predict
+    _set_cfg(False)
+    vsd, usd = _small_nets()
+    ws = [_worker(vsd, usd, {"vae": VCFG, "unet": UCFG}) for _ in range(2)]
+    X = torch.randn(4, 6, 256, device="cuda")
+    pe = torch.zeros(4, dtype=torch.int32, device="cuda")
+    one = predict(ws[0][0], X, pe_row=pe)
+    out = [None, None]
+
+    def run(g):
+        with torch.cuda.stream(ws[g][2]):
+            out[g] = predict(ws[g][0], X[2 * g:2 * g + 2], pe_row=pe[:2])
+        ws[g][2].synchronize()
+    ts = [threading.Thread(target=run, args=(g,)) for g in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert torch.equal(torch.cat(out), one)
+
+
+def test_sample_clips_streams_matches_single_call_and_oracle():
+    """reduced width, denoise round trip at 128 x 128 with 3 DDIM steps (the second is captured, the third replays the graph):
+    2 groups x 2 clips through sample_clips_streams == one sample_clips call on the 4 clips == the CPU loop oracle."""
+    from sd_video_gen_amd.predict import sample_clips, sample_clips_streams, bouncing_ball_clips
+    _set_cfg()
+    vsd, usd = _small_nets()
+    arch = {"vae": VCFG, "unet": UCFG}
+    workers = [_worker(vsd, usd, arch) for _ in range(2)]
+    clips = bouncing_ball_clips(4, 64, 5, seed=9)
+    seeds = [21, 22, 23, 24]
+    emb = workers[0][1].encode_text([""])
+    S = 47
+    kw = dict(denoise=True, start_step=S, text_embeddings=emb, res=128)
+    grow0 = [w[1].ctx.workspace_growths() for w in workers]
+    lat_s = sample_clips_streams(workers, clips.cuda(), 2, seeds, **kw)
+    torch.cuda.synchronize()
+    grow1 = [w[1].ctx.workspace_growths() for w in workers]
+    assert [b - a for a, b in zip(grow0, grow1)] == [1, 1]          # each group's arena sized once, on the calling thread
+    again = sample_clips_streams(workers, clips.cuda(), 2, seeds, **kw)
+    torch.cuda.synchronize()
+    assert [w[1].ctx.workspace_growths() for w in workers] == grow1  # steady state: nothing allocated
+    assert torch.equal(again, lat_s)
+    lat_1 = sample_clips(workers[0][0], workers[0][1], clips.cuda(), 2, seeds=seeds, **kw)
+    assert lat_s.shape == lat_1.shape == (4, 6, 256)
+    margin("sample_clips_streams (2 groups x 2 clips) vs one sample_clips call, reduced width", rel_l2(lat_s.cpu(), lat_1.cpu()), sd_tol(1e-2, 3e-2))
+    xsd = {k: v.cpu() for k, v in workers[0][0].state_dict().items()}
+    for c in range(4):
+        noise = _clip_noise_cpu(seeds[c], 128, 64, 2, S)
+        ref = loop_oracle.sample_clip(xsd, 4, vsd, clips[c], 2, noise, denoise=True, start_step=S, unet_sd=usd, text_emb=emb.cpu(),
+                                      vae_cfg=VCFG, unet_cfg=UCFG, res=128)
+        margin("sample_clips_streams vs loop oracle, reduced width, clip %d" % c, rel_l2(lat_s[c:c + 1].cpu(), ref), sd_tol(5.4e-3, 2e-2))
+
+
+def test_sample_clips_streams_full_size_start_step_48():
+    """full-size SD v1.4 UNet + VAE (two replicas, as bench.py builds them), 512 x 512 round trip, start step 48 (2 of the 50 DDIM
+    steps keep the CPU oracle short): 2 groups x 1 clip vs one call on both clips vs the loop oracle."""
+    from sd_video_gen_amd.predict import sample_clips, sample_clips_streams, bouncing_ball_clips
+    n = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    try:
+        _set_cfg(True, "1_16_kitti_L1_64")
+        usd = SO.seeded_weights(SO.unet_shapes(), 31)
+        vsd = SO.seeded_weights(SO.vae_shapes(), 32)
+        workers = [_worker(vsd, usd, None, seed=7, d_model=256, layers=(2, 2)) for _ in range(2)]
+        clips = bouncing_ball_clips(2, 64, 5, seed=4)
+        seeds = [5, 6]
+        emb = workers[0][1].encode_text([""])
+        S = 48
+        kw = dict(denoise=True, start_step=S, text_embeddings=emb)
+        lat_s = sample_clips_streams(workers, clips.cuda(), 1, seeds, **kw)
+        lat_1 = sample_clips(workers[1][0], workers[1][1], clips.cuda(), 1, seeds=seeds, **kw)
+        torch.cuda.synchronize()
+        assert lat_s.shape == (2, 5, 256) and torch.isfinite(lat_s).all()
+        margin("sample_clips_streams (2 x 1 clip) vs one call, full size, start step 48", rel_l2(lat_s.cpu(), lat_1.cpu()), sd_tol(1e-2, 3e-2))
+        xsd = {k: v.cpu() for k, v in workers[0][0].state_dict().items()}
+        noise = _clip_noise_cpu(seeds[0], 512, 64, 1, S)
+        ref = loop_oracle.sample_clip(xsd, 4, vsd, clips[0], 1, noise, denoise=True, start_step=S, unet_sd=usd, text_emb=emb.cpu())
+        margin("sample_clips_streams vs loop oracle, full size, conditioning latents", rel_l2(lat_s[:1, :4].cpu(), ref[:, :4]), sd_tol(1.3e-3, 1.1e-2))
+        margin("sample_clips_streams vs loop oracle, full size, denoised frame", rel_l2(lat_s[:1, 4:].cpu(), ref[:, 4:]), sd_tol(1.8e-2, 7e-2))
+    finally:
+        torch.set_num_threads(n)
