@@ -322,6 +322,12 @@ int svg_op_xf_gemm(svg_ctx* ctx, const float* X, const float* W, const float* bi
 int svg_prof_enable(svg_ctx* ctx, int on);
 int svg_prof_reset(svg_ctx* ctx);
 int svg_prof_report(svg_ctx* ctx, char* buf, int buflen);
+/* Has a layer-walking forward of the latent Transformer (models/transformer.py:47-68 in one launch, xf_walk.hip) on this device given up at a
+ * device-wide barrier since the last Transformer call / status query?  0 = no; SVG_ERR_RUNTIME = yes: that forward's output is NaN-filled,
+ * the walk is now off for the device (later forwards run the per-GEMM kernels) and the forward must be re-issued.  Call it where the
+ * forward's result is consumed (after synchronising its stream).  The event is also raised by the next svg_transformer_* call; the VAE /
+ * UNet / DDIM entry points log it and keep running. */
+int svg_transformer_status(svg_ctx* ctx);
 /* workspace bytes currently reserved by the context */
 int64_t svg_workspace_bytes(svg_ctx* ctx);
 

@@ -79,6 +79,7 @@ SIGNATURES = {
     "svg_prof_reset": [_vp],
     "svg_prof_report": [_vp, C.c_char_p, _i],
     "svg_workspace_bytes": [_vp],
+    "svg_transformer_status": [_vp],
     "svg_workspace_growths": [_vp],
     "svg_reserve_workspace": [_vp, _i64],
     "svg_plan_begin": [_vp],
@@ -294,6 +295,13 @@ class Context:
         self.check(self.lib.svg_transformer_forward(self.h, _ptr(src), _ptr(tgt_c), B, Ts, Tt, _ptr(mask), _ptr(pe_row),
                                                     _ptr(out), _stream()), "svg_transformer_forward")
         return out
+
+    def transformer_status(self, sync=True):
+        """raises RuntimeError when a layer-walking Transformer forward on this device gave up since the last check (its output is
+        NaN-filled: re-issue it).  sync: wait for the current stream first, so that the forward whose result is about to be read is covered."""
+        if sync:
+            torch.cuda.current_stream().synchronize()
+        self.check(self.lib.svg_transformer_status(self.h), "svg_transformer_status")
 
     # ---- training step of the latent Transformer ---------------------------------------------------
     def transformer_loss(self, cfg, src, tgt, expected, mask=None, text=None, backward=True, read_losses=True):

@@ -105,7 +105,7 @@ int svg_vae_encode(svg_ctx* ctx, const uint8_t* img, int N, int srcH, int srcW, 
                    float* moments_out, void* stream) {
   try {
     SVG_CHECK(ctx && ctx->vae, "vae: model not configured");
-    xf_walk_check(ctx);                              // an earlier layer-walking forward that gave up surfaces at the next model call
+    xf_walk_check(ctx, false);                       // an earlier layer-walking forward that gave up: walk off + logged; raised to the Transformer's caller
     ctx->vae->encode(ctx, img, N, srcH, srcW, H, W, eps, z_out, moments_out, (hipStream_t)stream);
     return 0;
   } catch (const std::exception& e) { return svg_fail(ctx, e); }
@@ -114,7 +114,7 @@ int svg_vae_decode(svg_ctx* ctx, const float* z, int N, int h, int w, uint8_t* i
                    void* stream) {
   try {
     SVG_CHECK(ctx && ctx->vae, "vae: model not configured");
-    xf_walk_check(ctx);                              // an earlier layer-walking forward that gave up surfaces at the next model call
+    xf_walk_check(ctx, false);                       // an earlier layer-walking forward that gave up: walk off + logged; raised to the Transformer's caller
     ctx->vae->decode(ctx, z, N, h, w, img_out, outH, outW, float_out, (hipStream_t)stream);
     return 0;
   } catch (const std::exception& e) { return svg_fail(ctx, e); }
@@ -123,7 +123,7 @@ int svg_unet_forward(svg_ctx* ctx, const float* x, int N, int h, int w, const fl
                      float* eps_out, void* stream) {
   try {
     SVG_CHECK(ctx && ctx->unet, "unet: model not configured");
-    xf_walk_check(ctx);                              // an earlier layer-walking forward that gave up surfaces at the next model call
+    xf_walk_check(ctx, false);                       // an earlier layer-walking forward that gave up: walk off + logged; raised to the Transformer's caller
     ctx->unet->forward(ctx, x, N, h, w, timesteps, ctx_emb, ctx_len, eps_out, (hipStream_t)stream);
     return 0;
   } catch (const std::exception& e) { return svg_fail(ctx, e); }
@@ -132,7 +132,7 @@ int svg_ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const float* text
                   float guidance, const float* noise, float* hist, void* stream) {
   try {
     SVG_CHECK(ctx && ctx->unet, "unet: model not configured");
-    xf_walk_check(ctx);                              // an earlier layer-walking forward that gave up surfaces at the next model call
+    xf_walk_check(ctx, false);                       // an earlier layer-walking forward that gave up: walk off + logged; raised to the Transformer's caller
     ctx->unet->ddim_loop(ctx, z, N, h, w, text_emb, ctx_len, num_steps, start_step, guidance, noise, hist, (hipStream_t)stream);
     return 0;
   } catch (const std::exception& e) { return svg_fail(ctx, e); }
@@ -143,6 +143,16 @@ int svg_ddim_step(svg_ctx* ctx, const float* x, const float* eps, float* prev, i
     float sa, s1a, sap, s1ap;
     ctx->unet->ddim_coefs(t, t_prev, &sa, &s1a, &sap, &s1ap);
     ddim_step(x, eps, nullptr, 0.f, prev, n, sa, s1a, sap, s1ap, (hipStream_t)stream);
+    return 0;
+  } catch (const std::exception& e) { return svg_fail(ctx, e); }
+}
+/* Has a layer-walking Transformer forward on this device given up since the last Transformer call / status query?  Call it where
+ * the forward's result is consumed (after the stream has been synchronised): 0 = no, SVG_ERR_RUNTIME = yes (svg_last_error says what;
+ * that forward's output is NaN-filled and must be re-issued: the walk is now off, the per-GEMM kernels serve). */
+int svg_transformer_status(svg_ctx* ctx) {
+  try {
+    SVG_CHECK(ctx, "null context");
+    xf_walk_check(ctx, true);
     return 0;
   } catch (const std::exception& e) { return svg_fail(ctx, e); }
 }

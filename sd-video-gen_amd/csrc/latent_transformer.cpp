@@ -341,7 +341,18 @@ static bool xf_walk_small_usable(const XfModel* m, int B, int Ts, int Tt, hipStr
   if (m->text_dim != 0 || B * std::max(Ts, Tt) > kWalkSmallRows || hd % 4) return false;
   for (int K : {d, m->ffn, m->d_lat})
     if (K % 256 != 0 || K < 256 || K > kWalkSmallMaxK) return false;
-  if (4 + 7 * m->enc_layers + 14 * m->dec_layers + 4 > kWalkMaxOps) return false;       // column blocks of wide matrices count as stages
+  {
+    // exact stage count of xf_forward_walk_small's table: a GEMM stage is cut into column blocks of 8 x (workgroups of the grid) columns
+    const int blk = 8 * std::max(1, xf_walk_grid());
+    auto nb = [&](int N) { return (N + blk - 1) / blk; };
+    const int ffn = m->ffn;
+    const bool same = Ts == Tt;                      // (src == tgt is the caller's business: count the longer table)
+    int64_t n = (int64_t)nb(d) * (same ? 1 : 2);
+    n += (int64_t)m->enc_layers * (nb(3 * d) + 1 + nb(d) + nb(ffn) + nb(d));
+    n += (int64_t)m->dec_layers * (nb(3 * d) + nb(2 * d) + 1 + nb(d) + nb(d) + 1 + nb(d) + nb(ffn) + nb(d));
+    n += nb(m->d_lat) + nb(d);                       // output projection (+ the second embedding when src != tgt at equal lengths)
+    if (n > kWalkMaxOps) return false;
+  }
   const int T = std::max(Ts, Tt);
   const int64_t lds = std::max<int64_t>((int64_t)kWalkSmallRows * (kWalkSmallMaxK * 4 + 64) + 4 * kWalkSmallMaxK * 4, ((int64_t)3 * T * hd + 2 * 32 * 33 + 32) * 4);
   return xf_walk_grid() >= 8 && xf_walk_available(kWalkSmallRows, lds);

@@ -216,7 +216,6 @@ struct UnetModel : UnetIface {
   std::vector<int> attn{1, 1, 1, 0};
   int layers = 2, heads = 8, ctx_dim = 768, groups = 32, in_ch = 4, out_ch = 4;
   int fp8 = 0;                       // configure key fp8=1: the resnets' / upsamplers' 3x3 convs run on MX block-scaled fp8 operands
-  int64_t fp8_sites_run = -1;        // placement mask in force for the running call (unet.cpp: $SVG_FP8_SITES_GUIDED under guidance)
   const char* dtype() const override { return SD_F16 ? "fp16" : "bf16"; }
   int temb_dim = 0;
   PackedLinear time1, time2, temb_all;     // temb_all: every resnet's time_emb_proj stacked [sum Cout][temb_dim]
@@ -230,7 +229,7 @@ struct UnetModel : UnetIface {
   void finalize(svg_ctx* ctx, int64_t* n_params) override;
   // one UNet call (planned by the caller); cache: cross-attention K / V^T reuse across the steps of a DDIM loop
   void run(svg_ctx* ctx, const float* x, int N, int h, int w, const float* timesteps, const float* ctx_emb, int ctx_len,
-           float* eps_out, hipStream_t s, KvCache* cache = nullptr);
+           float* eps_out, hipStream_t s, KvCache* cache = nullptr, int64_t fp8_sites = -1);   // fp8_sites: MX-fp8 placement mask of this call (-1: all)
   void forward(svg_ctx* ctx, const float* x, int N, int h, int w, const float* timesteps, const float* ctx_emb, int ctx_len,
                float* eps_out, hipStream_t s) override;
   void ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const float* text_emb, int ctx_len, int num_steps,

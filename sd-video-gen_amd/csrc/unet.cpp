@@ -295,6 +295,7 @@ struct UnetRun {
   const float* temb;               // (N, temb_total) f32: every resnet's time_emb_proj(silu(temb))
   int temb_ld;
   KvCache* cache = nullptr;        // cross-attention K / V^T reuse across DDIM steps (constant context)
+  int64_t sites = -1;              // placement mask of the MX-fp8 convs for THIS call (a parameter of the call, not model state)
   int xf_idx = 0;
 
   // an activation tensor with, when its producer could leave them, the GroupNorm column sums of its row tiles
@@ -336,7 +337,7 @@ struct UnetRun {
                          const float* bbn, int bbn_ld, const h16* resid, GnEmit* e, int conv_bit) {
       const int Cn = Ca + Ca2;
       ctx->arena.push();
-      const bool site_on = ((m->fp8_sites_run >> r.site) & 1) && ((m->fp8_sites_run >> conv_bit) & 1);      // this call's placement mask
+      const bool site_on = ((sites >> r.site) & 1) && ((sites >> conv_bit) & 1);      // this call's placement mask
       if (site_on && conv3x3_fp8_ok(cw, N, H, W)) {
         const int64_t Cp = align_up(Cn, 128);
         uint8_t* q = ctx->arena.get<uint8_t>(P * Cp);
@@ -583,11 +584,14 @@ struct UnetRun {
 
 void UnetModel::forward(svg_ctx* ctx, const float* x, int N, int h, int w, const float* timesteps, const float* ctx_emb,
                         int ctx_len, float* eps_out, hipStream_t s) {
-  run_planned(ctx, [&]() { run(ctx, x, N, h, w, timesteps, ctx_emb, ctx_len, eps_out, s); });
+  // A direct call cannot know whether its batch is a classifier-free-guidance pair: with fp8=1 it runs EVERY eligible conv in e4m3 unless
+  // $SVG_FP8_SITES_FORWARD narrows the placement (e.g. 3140 = 0xC44, the 16 x 16 level a guided svg_ddim_loop keeps).
+  const int64_t sites = svg_env_i64("SVG_FP8_SITES_FORWARD", -1);
+  run_planned(ctx, [&]() { run(ctx, x, N, h, w, timesteps, ctx_emb, ctx_len, eps_out, s, nullptr, sites); });
 }
 
 void UnetModel::run(svg_ctx* ctx, const float* x, int N, int h, int w, const float* timesteps, const float* ctx_emb,
-                    int ctx_len, float* eps_out, hipStream_t s, KvCache* cache) {
+                    int ctx_len, float* eps_out, hipStream_t s, KvCache* cache, int64_t fp8_sites) {
   SVG_CHECK(ready, "unet: svg_finalize has not been called");
   const int nb = (int)block_out.size();
   const int down = 1 << (nb - 1);
@@ -596,6 +600,7 @@ void UnetModel::run(svg_ctx* ctx, const float* x, int N, int h, int w, const flo
   const int c0 = block_out[0];
   UnetRun r{ctx, this, s, N};
   r.cache = cache;
+  r.sites = fp8_sites;
   r.L = ctx_len; r.Lp = (int)align_up(ctx_len, 8);
   // context -> bf16
   h16* cb = ctx->arena.get<h16>((int64_t)N * ctx_len * ctx_dim);
@@ -655,7 +660,7 @@ void UnetModel::run(svg_ctx* ctx, const float* x, int N, int h, int w, const flo
     if (i < nb - 1) {
       h16* y = ctx->arena.get<h16>((int64_t)N * (2 * H) * (2 * W) * up_s[i].Opad);
       GnEmit e = r.emit_for((int64_t)4 * H * W, up_s[i].Opad);
-      if (((fp8_sites_run >> 9) & 1) && conv3x3_fp8_ok(up_s[i], N, H, W, true)) {      // fp8=1: quantise the (small) source image, conv on the MX fp8 path
+      if (((fp8_sites >> 9) & 1) && conv3x3_fp8_ok(up_s[i], N, H, W, true)) {      // fp8=1: quantise the (small) source image, conv on the MX fp8 path
         ctx->arena.push();
         const int64_t Ps = (int64_t)N * H * W, Cp = align_up(up_s[i].Cin, 128);
         uint8_t* q = ctx->arena.get<uint8_t>(Ps * Cp);
@@ -686,9 +691,8 @@ void UnetModel::ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const flo
   const int64_t n = (int64_t)N * in_ch * h * w;
   const bool cfg = guidance != 0.f;
   const int NB = cfg ? 2 * N : N;
-  // the e4m3 placement of this loop (see kFp8SitesGuided); restored when the loop returns or throws
-  struct SitesGuard { int64_t& v; int64_t old; ~SitesGuard() { v = old; } } sites_guard{fp8_sites_run, fp8_sites_run};
-  if (cfg) fp8_sites_run = svg_env_i64("SVG_FP8_SITES_GUIDED", kFp8SitesGuided);
+  // the e4m3 placement of this loop (see kFp8SitesGuided): handed to every UNet call of the loop as an argument
+  const int64_t sites = cfg ? svg_env_i64("SVG_FP8_SITES_GUIDED", kFp8SitesGuided) : -1;
   const int64_t emb_n = (int64_t)N * ctx_len * ctx_dim;
   auto timestep_at = [&](int i) { return (num_steps - 1 - i) * ratio; };   // (arange(n)*ratio)[::-1]
 
@@ -743,7 +747,7 @@ void UnetModel::ddim_loop(svg_ctx* ctx, float* z, int N, int h, int w, const flo
       // guidance == 0: noise_pred = uncond + 0*(text - uncond) == uncond — only the uncond half is needed
       std::unique_ptr<ProfScope> step_scope;
       if (SVG_LAUNCHING(ctx)) step_scope.reset(new ProfScope(ctx, PK_UNET_STEP, s, 0, 0));
-      run(ctx, cfg ? zin : z, NB, h, w, tvec, text_emb, ctx_len, eps, s, &kv);
+      run(ctx, cfg ? zin : z, NB, h, w, tvec, text_emb, ctx_len, eps, s, &kv, sites);
       if (SVG_LAUNCHING(ctx)) {
         if (tabled) {
           ddim_step_tab(z, eps, cfg ? eps + n : nullptr, guidance, z, n, tab, idx, s);

@@ -64,5 +64,7 @@ void xf_walk_init_device();
 bool xf_walk_enabled(hipStream_t s);
 void xf_walk_env_refresh();                           // svg_env_refresh(): re-reads $SVG_XF_WALK* for every initialised device (re-arms the walk after a give-up)
 // When an earlier walk on this device gave up at a barrier (a workgroup never became resident): clears the flag, turns the walk off for
-// the device (later forwards take the per-GEMM kernels) and raises ONCE.  Called at the head of every model entry point of the C ABI.
-void xf_walk_check(svg_ctx* ctx);
+// the device (later forwards take the per-GEMM kernels), logs it, and — throw_it — raises ONCE.  The Transformer's entry points and
+// svg_transformer_status raise; the other model entry points (which must still run) call it with throw_it = false and leave the event
+// pending for the Transformer's caller.  Returns whether an event is still pending.
+bool xf_walk_check(svg_ctx* ctx, bool throw_it = true);

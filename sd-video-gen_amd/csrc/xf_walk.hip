@@ -552,11 +552,16 @@ __global__ void __launch_bounds__(WK_THREADS) xf_walk_small_kernel(const WalkOp*
       }
       __syncthreads();
       if (dead) {                                        // gave up: the final stage's output becomes NaN (see xf_walk_kernel)
+        // the final stage may be cut into column blocks (reuse_x marks the continuation blocks): poison ALL of its columns, not the last block's
         const auto& last = ops[n_ops - 1];
-        const __amdgpu_buffer_rsrc_t rL = rsrc_of(last.Y, (unsigned)((last.M - 1) * last.ldy + last.N) * 4u);
+        int f = n_ops - 1;
+        while (f > 0 && ops[f].reuse_x) --f;
+        float* const Y0 = ops[f].Y;
+        const int ntot = (int)(last.Y - Y0) + last.N;
+        const __amdgpu_buffer_rsrc_t rL = rsrc_of(Y0, (unsigned)((last.M - 1) * last.ldy + ntot) * 4u);
         const unsigned qn = 0x7FC00000u;
-        for (int v = (int)blockIdx.x * WK_THREADS + tid; v < last.M * last.N; v += (int)nwg * WK_THREADS)
-          __builtin_amdgcn_raw_buffer_store_b32(qn, rL, (unsigned)(((v / last.N) * last.ldy + v % last.N) * 4), 0, SC1);
+        for (int v = (int)blockIdx.x * WK_THREADS + tid; v < last.M * ntot; v += (int)nwg * WK_THREADS)
+          __builtin_amdgcn_raw_buffer_store_b32(qn, rL, (unsigned)(((v / ntot) * last.ldy + v % ntot) * 4), 0, SC1);
         return;
       }
     }
@@ -697,6 +702,7 @@ constexpr int kRing = 16;                              // table / barrier-word s
 constexpr int kMts[] = {1, 2, 3, 4, 6, 8, 11};        // the instantiated accumulator heights
 struct WalkDev {
   bool init = false;
+  bool pending = false;              // a give-up has been seen (walk turned off, logged) but not yet raised to a Transformer caller
   bool disabled = false;             // set when a launch gave up at a barrier, or when ranks share the device: the per-GEMM kernels serve
   bool coop_ok = false;              // the device reports hipDeviceAttributeCooperativeLaunch
   bool coop = false;                 // launches go through hipLaunchCooperativeKernel (the runtime refuses a grid that cannot be co-resident)
@@ -896,21 +902,30 @@ bool xf_walk_enabled(hipStream_t s) {
   return true;
 }
 
-void xf_walk_check(svg_ctx* ctx) {
+// throw_it = true (the latent Transformer's entry points, svg_transformer_status): raise the give-up as that call's error.
+// throw_it = false (VAE / UNet / DDIM entry points, which did nothing wrong and must still run): turn the walk off, say so on stderr, and keep
+// the event for the next Transformer call or status query to raise.
+bool xf_walk_check(svg_ctx* ctx, bool throw_it) {
   (void)ctx;
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 16) return;
+  if (dev < 0 || dev >= 16) return false;
   std::lock_guard<std::mutex> lk(g_mu);
   WalkDev& D = g_dev[dev];
-  if (!D.init) return;
+  if (!D.init) return false;
   bool gave_up = false;
   for (int i = 0; i < kRing; ++i)
     if (__atomic_load_n(&D.habort[i], __ATOMIC_RELAXED) != 0) { gave_up = true; __atomic_store_n(&D.habort[i], 0u, __ATOMIC_RELAXED); }
   if (gave_up) {
     D.disabled = true;                                 // one contention event must not make every later forward raise: fall back for good
+    D.pending = true;
+    fprintf(stderr, "[svg_hip] %s\n", kGaveUp);
+  }
+  if (D.pending && throw_it) {
+    D.pending = false;
     throw SvgHipError(std::string(kGaveUp));          // a device-side failure (SVG_ERR_RUNTIME), not a bad argument
   }
+  return D.pending;
 }
 
 int xf_walk_grid() {

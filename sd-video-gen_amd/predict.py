@@ -101,11 +101,17 @@ def sample_clips(model, sd_utils, clips_u8, pred_frames, denoise=False, start_st
             preds.append(pred)
             all_latents = torch.cat([inputs[:, :-1], torch.stack(preds, dim=1)], dim=1)     # :193
             X = all_latents[:, -5:]                                                         # :196
-        if not return_frames:
-            return all_latents
-        n_out = all_latents.shape[1]
-        frames = ctx.vae_decode(all_latents.reshape(C * n_out, 4, L, L)).reshape(C, n_out, F, F, 3)   # :208-211
-        return all_latents, frames
+        frames = None
+        if return_frames:
+            n_out = all_latents.shape[1]
+            frames = ctx.vae_decode(all_latents.reshape(C * n_out, 4, L, L)).reshape(C, n_out, F, F, 3)   # :208-211
+        if not _planning and C * (T + 1) <= 176:
+            # small batches may have taken the layer-walking Transformer launch, which can give up under contention and NaN-fill its
+            # output: surface that HERE, where the clip is handed back, not at some later call (svg_transformer_status)
+            mctx = getattr(model, "_ctx", None)
+            if mctx is not None:
+                mctx.transformer_status(sync=True)
+        return (all_latents, frames) if return_frames else all_latents
 
 
 def plan_workspace(model, sd_utils, clips_u8, pred_frames, **kw):

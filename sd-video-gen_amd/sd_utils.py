@@ -232,7 +232,7 @@ class LMSDiscreteScheduler:
 
 
 class SDUtils():
-    def __init__(self, weights=None, text_embeddings=None, seed=0, verbose=True, arch=None, ctx=None, fp8=None, dtype=None):
+    def __init__(self, weights=None, text_embeddings=None, seed=0, verbose=True, arch=None, ctx=None, fp8=None, dtype=None, vae_dtype=None):
         self.config, self.args = parse_config_args()             # sd_utils.py:22
         self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
         if self.device.type != "cuda":
@@ -255,6 +255,13 @@ class SDUtils():
         self.dtype = (dtype or os.environ.get("SVG_SD_DTYPE", "fp16")).lower().replace("float16", "fp16").replace("half", "fp16")
         if self.dtype not in ("bf16", "fp16"):
             raise ValueError("SDUtils dtype must be 'bf16' or 'fp16', got %r" % (self.dtype,))
+        # The VAE keeps fp16 storage whatever the UNet runs in: its decoder ends in a uint8 image (sd_utils.py:156-169), and bf16's 8
+        # significant bits flip 52 % of the pixels (max 5 LSB) against 7.5 % (max 1 LSB) in fp16 — the reference's own autocast floor
+        # is 4.6 % (profiles/r05_vae_decoder_storage.txt).  `dtype` therefore names the UNet's storage (where BASELINE configs[1]'s
+        # "bf16" buys its speed: 96 % of the FLOPs); vae_dtype / $SVG_VAE_DTYPE = 'bf16' restores the all-bf16 arithmetic for A/B.
+        self.vae_dtype = (vae_dtype or os.environ.get("SVG_VAE_DTYPE", "fp16")).lower().replace("float16", "fp16").replace("half", "fp16")
+        if self.vae_dtype not in ("bf16", "fp16"):
+            raise ValueError("SDUtils vae_dtype must be 'bf16' or 'fp16', got %r" % (self.vae_dtype,))
         # `arch` overrides the SD v1.4 widths (reduced-size parity tests): {'vae': {...}, 'unet': {...}}
         # (a local diffusers directory's config.json plays the same role, as it does for from_pretrained)
         local = os.environ.get("SVG_SD_WEIGHTS")
@@ -305,7 +312,7 @@ class SDUtils():
         va = self.vae_arch
         sd, self.vae_source = self._weights_for("vae", weights, lambda: sd_layout.vae_shapes(va), self._seed + 1)
         ctx.configure(_lib.SVG_VAE, block_out=list(va["block_out"]), layers=va["layers"], groups=va["groups"], latent=4,
-                      f16=int(self.dtype == "fp16"))
+                      f16=int(self.vae_dtype == "fp16"))
         ctx.load_state_dict(_lib.SVG_VAE, sd)
         vae = _VAE(ctx, ctx.finalize(_lib.SVG_VAE))
         del sd

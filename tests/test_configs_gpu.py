@@ -192,7 +192,8 @@ def _config2_free_running(g, cnets, dtype, tol_loop, tol_frame, ar):
     lat, sdu = _rollout("1_16_kitti_L1_64", g, cnets, dtype)
     ar.check_fp8(sdu.unet.ctx, 1)
     store = "fp16" if dtype == "fp8" else dtype
-    assert sdu.ctx.model_dtype(_lib.SVG_UNET) == store and sdu.ctx.model_dtype(_lib.SVG_VAE) == store and sdu.fp8 == (dtype == "fp8")
+    # (the VAE keeps fp16 storage under a bf16 UNet: its decoder ends in a uint8 image — SDUtils)
+    assert sdu.ctx.model_dtype(_lib.SVG_UNET) == store and sdu.ctx.model_dtype(_lib.SVG_VAE) == "fp16" and sdu.fp8 == (dtype == "fp8")
     e_frame = rel_l2(lat[:, 4:], g["all_latents"][:, 4:])
     emb = GG.text_emb().cuda()
     ks = g["hist_steps"]

@@ -307,18 +307,29 @@ def test_walk_deep_narrow_model_more_workgroups_than_tiles(ctx):
             assert rel_l2(out[:, b:b + 1], TO.forward(sd, X[b:b + 1], X[b:b + 1], 8, TO.get_tgt_mask(6))) < TOL
 
 
-def test_walk_give_up_is_reported_once_and_the_device_falls_back(ctx):
-    """ADVICE r04 #1: a layer-walking launch that gives up at a device-wide barrier (test hook: the barrier waits for 8 workgroups more
-    than the grid has; 20 ms wall-clock give-up time) NaN-fills its output, is reported by the NEXT model call of the C ABI — once — and
-    turns the walk off for the device: the calls after that run the per-GEMM kernels and are correct.  svg_env_refresh re-arms it."""
+@pytest.mark.parametrize("B", [2, 1])
+def test_walk_give_up_is_reported_once_and_the_device_falls_back(ctx, B):
+    """ADVICE r04 #1 / r05: a layer-walking launch that gives up at a device-wide barrier (test hook: the barrier waits for 8 workgroups more
+    than the grid has; 20 ms wall-clock give-up time) NaN-fills its WHOLE output and turns the walk off for the device; the event is raised
+    — once — where the result is consumed (svg_transformer_status after a stream sync) or by the next Transformer call, while a VAE call in
+    between only logs it and runs.  The calls after that run the per-GEMM kernels and are correct.  svg_env_refresh re-arms the walk.
+    B = 2: 12 rows, the split-K walk; B = 1: 6 rows, the small-row walk (xf_walk_small_kernel)."""
     from sd_video_gen_amd import _lib
     m = _walk_model(seed=14)
     sd = {k: v.clone().cpu() for k, v in m.state_dict().items()}
-    X = torch.randn(2, 6, 256, generator=torch.Generator().manual_seed(3))
-    pe0 = torch.zeros(2, dtype=torch.int32)
+    X = torch.randn(B, 6, 256, generator=torch.Generator().manual_seed(3))
+    pe0 = torch.zeros(B, dtype=torch.int32)
     mask = m.get_tgt_mask(6).cuda()
     run = lambda: m(X.cuda(), X.cuda(), mask, pe_row=pe0).cpu()
     good = _with_walk(True, run)
+    mctx = m._ctx
+    # a small VAE on the fixture context: a non-Transformer entry point on the same device
+    from oracle import sd_oracle as SO
+    vcfg = dict(block_out=(64, 128), layers=1, groups=32, latent=4)
+    ctx.configure(_lib.SVG_VAE, block_out=list(vcfg["block_out"]), layers=1, groups=32, latent=4, f16=1)
+    ctx.load_state_dict(_lib.SVG_VAE, SO.seeded_weights(SO.vae_shapes(vcfg), 5))
+    ctx.finalize(_lib.SVG_VAE)
+    img = torch.randint(0, 256, (1, 16, 16, 3), dtype=torch.uint8, device="cuda")
     keys = {"SVG_XF_WALK": "1", "SVG_XF_WALK_TEST_GIVEUP": "1", "SVG_XF_WALK_TIMEOUT_MS": "20"}
     old = {k: os.environ.get(k) for k in keys}
     os.environ.update(keys)
@@ -326,12 +337,21 @@ def test_walk_give_up_is_reported_once_and_the_device_falls_back(ctx):
     try:
         bad = run()                                        # the launch itself succeeds; its result is poisoned
         assert torch.isnan(bad).all()
+        z = ctx.vae_encode(img)                            # did nothing wrong: runs (the event is logged and stays pending)
+        assert torch.isfinite(z).all()
         with pytest.raises(RuntimeError, match="gave up"):
-            run()
+            mctx.transformer_status()                      # where the forward's result is consumed
+        mctx.transformer_status()                          # raised once
         os.environ["SVG_XF_WALK_TEST_GIVEUP"] = "0"        # (not refreshed: the library must already have fallen back by itself)
         after = run()                                      # no raise any more, per-GEMM kernels
         assert torch.isfinite(after).all() and rel_l2(after, good) < 5e-6
         assert rel_l2(after[:, :1], TO.forward(sd, X[:1], X[:1], 4, TO.get_tgt_mask(6))) < TOL
+        # without a status query the NEXT Transformer call raises (round 4's contract)
+        os.environ["SVG_XF_WALK_TEST_GIVEUP"] = "1"
+        _lib.env_refresh()
+        assert torch.isnan(run()).all()
+        with pytest.raises(RuntimeError, match="gave up"):
+            run()
     finally:
         for k in keys:
             if old[k] is None:
