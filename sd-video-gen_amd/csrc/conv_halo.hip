@@ -26,6 +26,10 @@ constexpr int ABL = HALO_ABL;
 constexpr int PW = 18;                 // patch width / height in pixels
 constexpr int PPIX = PW * PW;          // 324
 constexpr int NPD = 6;                 // patch DMA instructions per wave: 8 waves * 64 lanes * 6 = 3072 >= 324 * 8 chunks
+// MFMA (0-based, of the 2 nm in a merged segment) behind which DMA slot o of the merged loop sits (the placement gemm_pp.hip measured best)
+__host__ __device__ constexpr int halo_slot_at(int o, int nm) {
+  return o == 0 ? nm / 2 - 1 : o == 1 ? nm + 1 : o == 2 ? nm + nm / 2 - 1 : o == 3 ? (3 * nm) / 4 : 2 * nm - 5;
+}
 
 // PP = ping-pong schedule: the 8 waves run as two groups of four (one wave of each group per SIMD) staggered by one
 // barrier, so that while one group multiplies (20 MFMAs between two barriers, s_setprio 1) the other issues its fragment
@@ -374,6 +378,13 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
       if (i < NPD - 1) dma16(srdA, voff, cc * 128, dst + i * 8192);
       else if (wave_u == 0 && lane < 32) dma16(srdA, voff, cc * 128, dst + (NPD - 1) * 8192);
     };
+    auto dma_w_one = [&](int cc, int tap, int stage, int i) {   // instruction i (compile-time after unrolling) of the slab's NW
+      const unsigned dst = lds0 + OFF_B + stage * B_BYTES + wave_u * 1024;
+      const int soff = (tap * g.Cin + cc * 64) * 2;
+      if (i < BIT) dma16(srdB, b_voff[i], soff, dst + i * 8192);
+      else dma16(srdB, b_voff_tail, soff, (wave_u < 4) ? (dst + BIT * 8192) : (lds0 + OFF_DUMMY + wave_u * 1024));
+    };
+    const int km_cfg = __builtin_amdgcn_readfirstlane(g.pp_dma_m);
     // DMAs this wave issues for a slab / for patch piece i
     const int nw_own = HALO_NOPAD ? BIT + (tail_w ? 1 : 0) : NW;
     auto np_own = [&](int i) { return (!HALO_NOPAD || i < NPD - 1 || wave_u == 0) ? 1 : 0; };
@@ -424,21 +435,48 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
         h16x8 x0[MT], x1[MT], w0[NT], w1[NT];
         rd_x(tap, 0, x0); rd_w(tap % NWS, 0, w0);
         rd_x(tap, 1, x1); rd_w(tap % NWS, 1, w1);
-        if (more_w) dma_w_own(wcc, wtap, (tap + 2) % NWS);
-        if (pp) dma_p_own(cc + 1, pbuf ^ 1, tap);
-        wait_vm((more_w ? nw_own : 0) + (pp ? np_own(tap) : 0));
+        // km of the step's DMA instructions (the slab's last ones, then the patch piece) ride among the MFMAs instead (round 6, as in
+        // gemm_pp.hip): the load segment — 18 fragment reads + 3-4 DMA issues of ~110 cycles each — is longer than the 40-MFMA segment
+        // it hides under and every barrier interval lasts max(load, matrix).  Issued later than before (behind this step's barrier) and
+        // ahead of the next load segment's issues, whose counted wait therefore covers them: the RAW / WAR argument above is unchanged.
+        const int kw = more_w ? (km_cfg < NW ? km_cfg : NW) : 0;          // weight instructions moved
+        const bool p_in_m = pp && km_cfg > NW;                             // the patch piece moved
+        if (HALO_NOPAD) {
+          if (more_w) dma_w_own(wcc, wtap, (tap + 2) % NWS);
+          if (pp) dma_p_own(cc + 1, pbuf ^ 1, tap);
+          wait_vm((more_w ? nw_own : 0) + (pp ? np_own(tap) : 0));
+        } else {
+          if (more_w) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i)
+              if (i < NW - kw) dma_w_one(wcc, wtap, (tap + 2) % NWS, i);
+          }
+          if (pp && !p_in_m) dma_p_own(cc + 1, pbuf ^ 1, tap);
+          wait_vm((more_w ? NW - kw : 0) + ((pp && !p_in_m) ? 1 : 0));
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         bar();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = MFMA_16x16x32(w0[j], x0[i], acc[i][j]);
+          for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+            for (int j = 0; j < NT; ++j) {
+              acc[i][j] = hh == 0 ? MFMA_16x16x32(w0[j], x0[i], acc[i][j]) : MFMA_16x16x32(w1[j], x1[i], acc[i][j]);
+              const int idx = (hh * MT + i) * NT + j;
+              if (!HALO_NOPAD) {
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = MFMA_16x16x32(w1[j], x1[i], acc[i][j]);
+                for (int o = 0; o <= NW; ++o)
+                  if (idx == halo_slot_at(o, MT * NT)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (o < NW) { if (kw > o) dma_w_one(wcc, wtap, (tap + 2) % NWS, NW - 1 - o); }
+                    else if (p_in_m) dma_p_own(cc + 1, pbuf ^ 1, tap);
+                    __builtin_amdgcn_sched_barrier(0);
+                  }
+              }
+            }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         bar();
@@ -554,8 +592,12 @@ void launch_conv_halo(const GemmArgs& g, dim3 grid, hipStream_t s) {
   const bool w160 = conv_halo_bn(g) == 160;
   // merged ping-pong (one 32 / 40-MFMA phase per tap); SVG_HALO_MERGE (cached, svg_env_refresh): 0 off, 1 BN = 128 only, 2 / unset both widths
   const int mm = (int)svg_env_i64("SVG_HALO_MERGE", 2);
-  if (pp && mm >= 2 && w160) { launch_halo<160, 2>(g, grid, s); return; }
-  if (pp && mm >= 1 && !w160) { launch_halo<128, 2>(g, grid, s); return; }
+  if (pp && mm >= 1 && (mm >= 2 || !w160)) {
+    GemmArgs gm = g;
+    gm.pp_dma_m = std::max(0, std::min(4, (int)svg_env_i64("SVG_HALO_DMA_M", 4)));   // DMA instructions of a step issued among its MFMAs (merged loop)
+    if (w160) launch_halo<160, 2>(gm, grid, s); else launch_halo<128, 2>(gm, grid, s);
+    return;
+  }
   if (false) {}
   else if (pp) { if (w160) launch_halo<160, 1>(g, grid, s); else launch_halo<128, 1>(g, grid, s); }
   else    { if (w160) launch_halo<160, 0>(g, grid, s); else launch_halo<128, 0>(g, grid, s); }

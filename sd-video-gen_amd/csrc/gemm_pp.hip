@@ -17,6 +17,12 @@ namespace SDNS {
 
 namespace {
 
+// MFMA (0-based, of the 2 nm in a merged segment) behind which DMA slot o sits: the first three at the middle of the first k half, the
+// second MFMA and the middle of the second k half (the placement measured best), the next three between them
+__host__ __device__ constexpr int pp_slot_at(int o, int nm) {
+  return o == 0 ? nm / 2 - 1 : o == 1 ? nm + 1 : o == 2 ? nm + nm / 2 - 1 : o == 3 ? (3 * nm) / 4 : o == 4 ? 2 * nm - 5 : 3;
+}
+
 // WIDE: the wide tile epilogue (igemm_epi.h; 16-bit output without GEGLU — the launcher decides)
 template <int BN, bool WIDE>
 __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs g) {
@@ -141,6 +147,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs g) {
     //   L(s): read slab s; DMA slab s + 2 -> stage (s + 2) % 3 (slab s - 1: drained by both groups before the barriers since);
     //         vmcnt(own issues) -> slab s + 1 landed; lgkmcnt(0).
     const int grp = wave_u >> 2;
+    const int km_cfg = __builtin_amdgcn_readfirstlane(g.pp_dma_m);
     dma_part(0, 0, 0, NW);
     dma_part(1, 1, 0, NW);
     wait_vm(NW);
@@ -153,20 +160,42 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs g) {
       h16x8 x0[MT], w0[NT], x1[MT], w1[NT];
       rd(st, 0, x0, w0);
       rd(st, 1, x1, w1);
-      if (more) dma_part(s + 2, st2, 0, NW);
-      wait_vm(more ? NW : 0);
+      // km of the slab's NW DMA instructions ride in the MFMA segment (round 6): a load segment of 18 fragment reads + 7 DMA issues
+      // (~110 cycles each with four waves issuing: profiles/r06_probe_ldsdma.txt) is longer than the 40-MFMA segment it should hide
+      // under, and every barrier interval lasts max(load, matrix).  A DMA among the MFMAs stalls that wave's matrix stream while it
+      // issues, so the optimum moves only as many as balance the two segments (g.pp_dma_m, tuned per tile width by the launcher).
+      // Order / safety: the moved instructions are issued AFTER the barrier that closes L(s) (later than before: WAR on stage
+      // (s + 2) % 3 holds a fortiori) and BEFORE L(s + 1)'s issues, whose counted wait therefore covers them (RAW unchanged).
+      const int km = more ? km_cfg : 0;
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+          if (i < NW - km_cfg) dma_part(s + 2, st2, i, i + 1);
+      }
+      wait_vm(more ? NW - km_cfg : 0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       bar();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
+      // slot o (compile-time position pp_slot_at(o)) carries DMA instruction NW - 1 - o when km > o.  (A run-time slot mask with a
+      // run-time instruction index was measured too: its address arithmetic and ten scalar slot tests per segment cost more than the
+      // move gains — profiles/r06_pp_dma_in_mfma.txt.)
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = MFMA_16x16x32(w0[j], x0[i], acc[i][j]);
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+          for (int j = 0; j < NT; ++j) {
+            acc[i][j] = h == 0 ? MFMA_16x16x32(w0[j], x0[i], acc[i][j]) : MFMA_16x16x32(w1[j], x1[i], acc[i][j]);
+            const int idx = (h * MT + i) * NT + j;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = MFMA_16x16x32(w1[j], x1[i], acc[i][j]);
+            for (int o = 0; o < 6; ++o)
+              if (idx == pp_slot_at(o, MT * NT) && o < NW) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (km > o) dma_part(s + 2, st2, NW - 1 - o, NW - o);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+          }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       bar();
@@ -255,6 +284,8 @@ void launch_gemm_pp(const GemmArgs& g0, hipStream_t s) {
   GemmArgs g = g0;
   g.group_m = gm_env;
   g.pp_merge = (int)svg_env_i64("SVG_PP_MERGE", 1);        // 0 = the two-phase loop
+  // DMA instructions of a slab that ride among the MFMAs (see the merged loop)
+  g.pp_dma_m = std::max(0, std::min(6, (int)svg_env_i64("SVG_PP_DMA_M", 3)));
   if (gemm_pp_bn(g) == 160) launch_pp<160>(g, s);
   else launch_pp<128>(g, s);
 }

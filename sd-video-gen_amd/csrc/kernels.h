@@ -76,6 +76,7 @@ struct GemmArgs {
   int tn_major = 0;                  // tile order inside an XCD's run: 0 = tiles sharing the A rows adjacent, 1 = tiles sharing the weights adjacent
   int group_m = 0;                   // gemm_pp: row tiles per group of the grouped tile order (<= 1: row-major)
   int pp_merge = 0;                  // gemm_pp: one phase per slab (both k halves between two barriers) instead of two
+  int pp_dma_m = 0;                  // merged ping-pong loops (gemm_pp, conv_halo): DMA instructions of a step issued among its MFMAs instead of in the load segment
   int dbg = 0;                       // ablation switch (SVG_GEMM_DBG): 1 no stores, 2 no MFMA, 3 no DMA, 5 LDS-staged epilogue
 };
 
