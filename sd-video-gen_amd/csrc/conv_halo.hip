@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(512, 2) conv_halo_kernel(const GemmArgs g) {
       if (i < BIT) dma16(srdB, b_voff[i], soff, dst + i * 8192);
       else dma16(srdB, b_voff_tail, soff, (wave_u < 4) ? (dst + BIT * 8192) : (lds0 + OFF_DUMMY + wave_u * 1024));
     };
-    const int km_cfg = __builtin_amdgcn_readfirstlane(g.pp_dma_m);
+    const int km_cfg = min(__builtin_amdgcn_readfirstlane(g.pp_dma_m), NW + 1);
     // DMAs this wave issues for a slab / for patch piece i
     const int nw_own = HALO_NOPAD ? BIT + (tail_w ? 1 : 0) : NW;
     auto np_own = [&](int i) { return (!HALO_NOPAD || i < NPD - 1 || wave_u == 0) ? 1 : 0; };

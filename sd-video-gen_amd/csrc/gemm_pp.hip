@@ -20,7 +20,7 @@ namespace {
 // MFMA (0-based, of the 2 nm in a merged segment) behind which DMA slot o sits: the first three at the middle of the first k half, the
 // second MFMA and the middle of the second k half (the placement measured best), the next three between them
 __host__ __device__ constexpr int pp_slot_at(int o, int nm) {
-  return o == 0 ? nm / 2 - 1 : o == 1 ? nm + 1 : o == 2 ? nm + nm / 2 - 1 : o == 3 ? (3 * nm) / 4 : o == 4 ? 2 * nm - 5 : 3;
+  return o == 0 ? nm / 2 - 1 : o == 1 ? nm + 1 : o == 2 ? nm + nm / 2 - 1 : o == 3 ? (3 * nm) / 4 : o == 4 ? 2 * nm - 5 : o == 5 ? 3 : nm + nm / 4;
 }
 
 // WIDE: the wide tile epilogue (igemm_epi.h; 16-bit output without GEGLU — the launcher decides)
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs g) {
     //   L(s): read slab s; DMA slab s + 2 -> stage (s + 2) % 3 (slab s - 1: drained by both groups before the barriers since);
     //         vmcnt(own issues) -> slab s + 1 landed; lgkmcnt(0).
     const int grp = wave_u >> 2;
-    const int km_cfg = __builtin_amdgcn_readfirstlane(g.pp_dma_m);
+    const int km_cfg = min(__builtin_amdgcn_readfirstlane(g.pp_dma_m), NW);
     dma_part(0, 0, 0, NW);
     dma_part(1, 1, 0, NW);
     wait_vm(NW);
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs g) {
             acc[i][j] = h == 0 ? MFMA_16x16x32(w0[j], x0[i], acc[i][j]) : MFMA_16x16x32(w1[j], x1[i], acc[i][j]);
             const int idx = (h * MT + i) * NT + j;
 #pragma unroll
-            for (int o = 0; o < 6; ++o)
+            for (int o = 0; o < 7; ++o)
               if (idx == pp_slot_at(o, MT * NT) && o < NW) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (km > o) dma_part(s + 2, st2, NW - 1 - o, NW - o);
@@ -285,7 +285,7 @@ void launch_gemm_pp(const GemmArgs& g0, hipStream_t s) {
   g.group_m = gm_env;
   g.pp_merge = (int)svg_env_i64("SVG_PP_MERGE", 1);        // 0 = the two-phase loop
   // DMA instructions of a slab that ride among the MFMAs (see the merged loop)
-  g.pp_dma_m = std::max(0, std::min(6, (int)svg_env_i64("SVG_PP_DMA_M", 3)));
+  g.pp_dma_m = std::max(0, std::min(7, (int)svg_env_i64("SVG_PP_DMA_M", 6)));
   if (gemm_pp_bn(g) == 160) launch_pp<160>(g, s);
   else launch_pp<128>(g, s);
 }
