@@ -119,7 +119,7 @@ def _rollout(cfg_name, g, nets, dtype="bf16"):
     return lat.cpu(), sdu
 
 
-@pytest.mark.parametrize("dtype,tol_cond,tol_forced", [("fp16", 1.4e-3, 5.5e-3), ("bf16", 1.2e-2, FORCED_TOL)])   # measured fp16: 4.5e-4, 1.8e-3; bf16: 3.6e-3, 1.45e-2
+@pytest.mark.parametrize("dtype,tol_cond,tol_forced", [("fp16", 1.4e-3, 5.5e-3), ("bf16", 1.3e-3, FORCED_TOL)])   # measured fp16: 4.5e-4, 1.8e-3; bf16 (UNet; the VAE keeps fp16 storage since round 6): 4.2e-4, 1.45e-2
 def test_config2_full_frame_50_steps(ctx, nets, dtype, tol_cond, tol_forced):
     """configs[2] end to end for one generated frame, and the 50-step DDIM loop step by step.
 
@@ -173,7 +173,7 @@ def test_config2_full_frame_50_steps(ctx, nets, dtype, tol_cond, tol_forced):
           % (table[-1][1], e_frame))
 
 
-@pytest.mark.parametrize("dtype,tol_loop,tol_frame", [("fp16", 5e-3, 1.5e-2), ("bf16", 3e-2, 6e-2), ("fp8", 1.2e-1, 1.2e-1)])
+@pytest.mark.parametrize("dtype,tol_loop,tol_frame", [("fp16", 5e-3, 1.5e-2), ("bf16", 1.5e-2, 1.8e-2), ("fp8", 1.2e-1, 1.2e-1)])   # bf16 UNet + fp16 VAE (round 6) measured 4.9e-3 / 5.7e-3 (all-bf16 was 5e-3 / 1.9e-2)
 def test_config2_free_running_contractive(ctx, nets, dtype, tol_loop, tol_frame):
     """configs[2] END TO END, free-running, at a real tolerance: the headline workload (one generated frame = VAE passes at 512 x 512 +
     all 50 DDIM steps of the full-size UNet, nothing teacher-forced) against the fp32 oracle, in the synthetic-weight regime whose
@@ -223,7 +223,7 @@ def _config2_free_running(g, cnets, dtype, tol_loop, tol_frame, ar):
     margin("cfg2 contractive regime (%s): generated frame latent (50 steps + VAE @512 + 3 uint8 round trips)" % dtype, e_frame, tol_frame)
 
 
-@pytest.mark.parametrize("dtype,tol_all,tol_worst", [("fp16", 1e-2, 1.1e-2), ("bf16", 3e-2, 3.5e-2)])   # measured fp16: 3.3e-3, 3.7e-3; bf16: 1.07e-2, 1.24e-2
+@pytest.mark.parametrize("dtype,tol_all,tol_worst", [("fp16", 1e-2, 1.1e-2), ("bf16", 2.1e-2, 2.3e-2)])   # measured fp16: 3.3e-3, 3.7e-3; bf16 UNet + fp16 VAE (round 6): 6.8e-3, 7.7e-3 (all-bf16: 1.07e-2, 1.24e-2)
 def test_config1_rollout_8_frames_start25(ctx, nets, dtype, tol_all, tol_worst):
     """configs[1]: 8 autoregressive frames, 25 DDIM steps each (200 UNet calls in the oracle fixture)."""
     g = gold("sd_cfg1_rollout.pt")
@@ -237,7 +237,7 @@ def test_config1_rollout_8_frames_start25(ctx, nets, dtype, tol_all, tol_worst):
     margin("cfg1 8-frame rollout (%s), worst frame" % dtype, max(rel_l2(lat[:, 4 + k], g["all_latents"][:, 4 + k]) for k in range(g["pred_frames"])), tol_worst)
 
 
-@pytest.mark.parametrize("dtype,tol_first", [("fp16", 2e-2), ("bf16", 7e-2)])   # measured fp16: 6.5e-3; bf16: 2.6e-2
+@pytest.mark.parametrize("dtype,tol_first", [("fp16", 2e-2), ("bf16", 2.1e-2)])   # measured fp16: 6.5e-3; bf16 UNet + fp16 VAE (round 6): 6.8e-3 (all-bf16: 2.6e-2)
 def test_config3_rollout_16_frames_f128(ctx, nets, dtype, tol_first):
     """configs[3]: 11_27_ucf_final (F=128, D_lat=1024), 16 autoregressive frames with the 512x512 round trip, on the CHAOTIC
     (unscaled) synthetic weights.  Only the first generated frame is asserted: from the second frame on the distance measures how
@@ -254,7 +254,7 @@ def test_config3_rollout_16_frames_f128(ctx, nets, dtype, tol_first):
     assert torch.isfinite(lat).all()
 
 
-@pytest.mark.parametrize("dtype,tol_first,tol_all,tol_last", [("fp16", 1.5e-2, 4e-2, 6e-2), ("bf16", 4.5e-2, 1.1e-1, 1.6e-1)])   # measured fp16: 5.1e-3, 1.8e-2, 2.8e-2; bf16: 1.6e-2, 3.7e-2, 5.3e-2
+@pytest.mark.parametrize("dtype,tol_first,tol_all,tol_last", [("fp16", 1.5e-2, 4e-2, 6e-2), ("bf16", 2.1e-2, 9e-2, 1.4e-1)])   # measured fp16: 5.1e-3, 1.7e-2, 2.4e-2; bf16 UNet + fp16 VAE (round 6): 6.8e-3, 2.9e-2, 4.6e-2 (all-bf16: 1.6e-2, 3.7e-2, 5.3e-2)
 def test_config3_full_length_contractive(ctx, nets, dtype, tol_first, tol_all, tol_last):
     """configs[3] at its FULL length: 11_27_ucf_final, 16 autoregressive frames, each with all 50 DDIM steps of the full-size UNet
     between the 512 x 512 VAE passes (800 UNet calls in the oracle fixture, oracle/gen_golden_sd.py cfg3c), free-running, in the

@@ -10,9 +10,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // mode: 0 MFMA only (4 independent accumulators) | 1 v_exp only (NV per iteration) | 2 v_fma only | 3 MFMA + NV v_exp in one stream
 //       4 MFMA + NV v_fma in one stream | 5 role split: waves 0-3 MFMA only, waves 4-7 v_exp only | 6 role split with v_fma
-template <int MODE, int NV>
+// PRIO (role-split modes 5 / 6, round 6): 0 both roles at priority 0 | 1 the MFMA waves at s_setprio 3 | 2 the VALU waves at s_setprio 3
+template <int MODE, int NV, int PRIO = 0>
 __global__ void __launch_bounds__(512) k(float* out, long long* cyc, int iters) {
   const int wid = threadIdx.x >> 6;
+  if (PRIO == 1 && wid < 4) __builtin_amdgcn_s_setprio(3);
+  if (PRIO == 2 && wid >= 4) __builtin_amdgcn_s_setprio(3);
   f32x16 acc[4];
   for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
   bf16x8 a, b;
@@ -46,7 +49,7 @@ __global__ void __launch_bounds__(512) k(float* out, long long* cyc, int iters) 
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + wid] = t1 - t0;
 }
 
-template <int MODE, int NV>
+template <int MODE, int NV, int PRIO = 0>
 void run(const char* name, int threads) {
   const int iters = 2000, grid = 256;
   float* out; long long* cyc;
@@ -54,9 +57,9 @@ void run(const char* name, int threads) {
   (void)hipMemset(cyc, 0, grid * 8 * 8);
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  hipLaunchKernelGGL((k<MODE, NV>), dim3(grid), dim3(threads), 0, 0, out, cyc, iters);
+  hipLaunchKernelGGL((k<MODE, NV, PRIO>), dim3(grid), dim3(threads), 0, 0, out, cyc, iters);
   (void)hipEventRecord(e0, 0);
-  hipLaunchKernelGGL((k<MODE, NV>), dim3(grid), dim3(threads), 0, 0, out, cyc, iters);
+  hipLaunchKernelGGL((k<MODE, NV, PRIO>), dim3(grid), dim3(threads), 0, 0, out, cyc, iters);
   (void)hipEventRecord(e1, 0);
   (void)hipDeviceSynchronize();
   float ms = 0.f;
@@ -81,5 +84,11 @@ int main() {
   }
   run<5, 4>("role split: waves 0-3 MFMA, waves 4-7 4 x 4 v_exp", 512);
   run<6, 8>("role split: waves 0-3 MFMA, waves 4-7 4 x 8 v_fma", 512);
+  run<5, 4, 1>("role split, MFMA waves at s_setprio 3: MFMA | 4 x 4 v_exp", 512);
+  run<5, 4, 2>("role split, VALU waves at s_setprio 3: MFMA | 4 x 4 v_exp", 512);
+  run<6, 8, 1>("role split, MFMA waves at s_setprio 3: MFMA | 4 x 8 v_fma", 512);
+  run<6, 8, 2>("role split, VALU waves at s_setprio 3: MFMA | 4 x 8 v_fma", 512);
+  run<5, 2, 1>("role split, MFMA waves at s_setprio 3: MFMA | 4 x 2 v_exp", 512);
+  run<5, 2, 0>("role split: MFMA | 4 x 2 v_exp", 512);
   return 0;
 }
