@@ -179,7 +179,9 @@ def _stream():
 
 
 class Context:
-    """One svg_ctx per (process, GPU)."""
+    """One svg_ctx: a set of model slots + one workspace arena on one GPU.  Calls on a context are serialised by the caller; several contexts
+    may be driven from different host threads at once (predict.sample_clips_streams) — the library's rules for that are in INTEGRATION.md
+    ("Ownership and threading")."""
 
     def __init__(self, device_index=None):
         if not torch.cuda.is_available():

@@ -5,6 +5,8 @@
 frame dropped from the emitted clip.  The clip-batched loop runs C independent clips in lock step
 (every GEMM gets C times the rows); each clip still sees PE row 0 exactly as at batch 1.
 """
+import os
+
 import torch
 
 
@@ -105,7 +107,6 @@ def sample_clips(model, sd_utils, clips_u8, pred_frames, denoise=False, start_st
         if return_frames:
             n_out = all_latents.shape[1]
             frames = ctx.vae_decode(all_latents.reshape(C * n_out, 4, L, L)).reshape(C, n_out, F, F, 3)   # :208-211
-        import os
         if not _planning and C * (T + 1) <= min(176, int(os.environ.get("SVG_XF_WALK_ROWS", "96") or 96)):
             # small batches may have taken the layer-walking Transformer launch (up to $SVG_XF_WALK_ROWS rows, default 96), which can give up
             # under contention and NaN-fill its output: surface that HERE, where the clip is handed back, not at some later call
