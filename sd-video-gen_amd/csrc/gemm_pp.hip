@@ -12,10 +12,20 @@
 #include "igemm_epi.h"
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 namespace SDNS {
 
 namespace {
+
+// In-kernel stamps (diagnostic build only: -DPP_STAMP, tools/build_variant.sh; cdna_hip_programming.md section 7): where a slab of the merged
+// ping-pong loop spends its cycles — per wave the sums over all slabs of {fragment-read + DMA issue, counted waits, barrier into the MFMA
+// segment, the MFMA segment, barrier out of it}, written to (g.slabs)[workgroup][wave][8] and printed by the launcher.
+#ifdef PP_STAMP
+#define PSTAMP(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PSTAMP(v) do { } while (0)
+#endif
 
 // MFMA (0-based, of the 2 nm in a merged segment) behind which DMA slot o sits: the first three at the middle of the first k half, the
 // second MFMA and the middle of the second k half (the placement measured best), the next three between them
@@ -148,6 +158,8 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs g) {
     //         vmcnt(own issues) -> slab s + 1 landed; lgkmcnt(0).
     const int grp = wave_u >> 2;
     const int km_cfg = min(__builtin_amdgcn_readfirstlane(g.pp_dma_m), NW);
+    unsigned long long ps_rd = 0, ps_wait = 0, ps_b1 = 0, ps_mm = 0, ps_b2 = 0, ps_n = 0, ps_t0 = 0, ps_t1 = 0;
+    PSTAMP(ps_t0);
     dma_part(0, 0, 0, NW);
     dma_part(1, 1, 0, NW);
     wait_vm(NW);
@@ -158,6 +170,8 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs g) {
       const bool more = s + 2 < KT;
       const int st2 = st == 0 ? 2 : st - 1;
       h16x8 x0[MT], w0[NT], x1[MT], w1[NT];
+      unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0;
+      PSTAMP(p0);
       rd(st, 0, x0, w0);
       rd(st, 1, x1, w1);
       // km of the slab's NW DMA instructions ride in the MFMA segment (round 6): a load segment of 18 fragment reads + 7 DMA issues
@@ -172,9 +186,12 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs g) {
         for (int i = 0; i < NW; ++i)
           if (i < NW - km_cfg) dma_part(s + 2, st2, i, i + 1);
       }
+      PSTAMP(p1);
       wait_vm(more ? NW - km_cfg : 0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PSTAMP(p2);
       bar();
+      PSTAMP(p3);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
       // slot o (compile-time position pp_slot_at(o)) carries DMA instruction NW - 1 - o when km > o.  (A run-time slot mask with a
@@ -198,10 +215,26 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const GemmArgs g) {
           }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
+#ifdef PP_STAMP
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(acc[i][j]));
+#endif
+      PSTAMP(p4);
       bar();
+      PSTAMP(p5);
+      ps_rd += p1 - p0; ps_wait += p2 - p1; ps_b1 += p3 - p2; ps_mm += p4 - p3; ps_b2 += p5 - p4; ps_n += 1;
       st = st == 2 ? 0 : st + 1;
     }
     if (grp == 0) bar();
+#ifdef PP_STAMP
+    PSTAMP(ps_t1);
+    if (g.slabs && lane == 0) {
+      unsigned long long* o = (unsigned long long*)g.slabs + ((size_t)blockIdx.x * 8 + wid) * 8;
+      o[0] = ps_rd; o[1] = ps_wait; o[2] = ps_b1; o[3] = ps_mm; o[4] = ps_b2; o[5] = ps_t1 - ps_t0; o[6] = 0; o[7] = ps_n;
+    }
+#endif
   } else {
     const int grp = wave_u >> 2;
     dma_part(0, 0, 0, NW);
@@ -286,8 +319,32 @@ void launch_gemm_pp(const GemmArgs& g0, hipStream_t s) {
   g.pp_merge = (int)svg_env_i64("SVG_PP_MERGE", 1);        // 0 = the two-phase loop
   // DMA instructions of a slab that ride among the MFMAs (see the merged loop)
   g.pp_dma_m = std::max(0, std::min(7, (int)svg_env_i64("SVG_PP_DMA_M", 6)));
+#ifdef PP_STAMP
+  const int tiles_dbg = cdiv(g.M, 256) * cdiv(g.N, gemm_pp_bn(g));
+  unsigned long long* dbg = nullptr;
+  HIP_OK(hipMalloc(&dbg, (size_t)tiles_dbg * 64 * sizeof(unsigned long long)));
+  HIP_OK(hipMemsetAsync(dbg, 0, (size_t)tiles_dbg * 64 * sizeof(unsigned long long), s));
+  g.slabs = (float*)dbg;
+#endif
   if (gemm_pp_bn(g) == 160) launch_pp<160>(g, s);
   else launch_pp<128>(g, s);
+#ifdef PP_STAMP
+  {
+    HIP_OK(hipStreamSynchronize(s));
+    std::vector<unsigned long long> h((size_t)tiles_dbg * 64);
+    HIP_OK(hipMemcpy(h.data(), dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_OK(hipFree(dbg));
+    double sum[2][8] = {{0}};
+    for (size_t w = 0; w < (size_t)tiles_dbg * 8; ++w)
+      for (int k = 0; k < 8; ++k) sum[(w & 7) >> 2][k] += (double)h[w * 8 + k];
+    for (int grp = 0; grp < 2; ++grp) {
+      const double n = sum[grp][7] > 0 ? sum[grp][7] : 1, nw = (double)tiles_dbg * 4;
+      fprintf(stderr, "[pp stamps] M%d N%d K%d BN%d dma_m %d grp %d: per slab (cycles) reads + DMA issue %.0f | waits %.0f | barrier in %.0f | MFMA segment %.0f | barrier out %.0f  = %.0f || loop per tile %.0f, slabs %.0f\n",
+              g.M, g.N, g.K, gemm_pp_bn(g), g.pp_dma_m, grp, sum[grp][0] / n, sum[grp][1] / n, sum[grp][2] / n, sum[grp][3] / n, sum[grp][4] / n,
+              (sum[grp][0] + sum[grp][1] + sum[grp][2] + sum[grp][3] + sum[grp][4]) / n, sum[grp][5] / nw, n / nw);
+    }
+  }
+#endif
 }
 
 }  // namespace SDNS
