@@ -23,7 +23,7 @@ __device__ __forceinline__ void dma16(v4i srd, unsigned voff, int soff, unsigned
 // loader: 0 none | 1 LDS-DMA | 2 global_load_dwordx4 into registers | 3 ds_read_b128 of LDS
 // n_load / n_mfma: loop counts of the loading waves (0-3, or all 8 when all8) and of the multiplying waves (4-7)
 // span: bytes of the source each workgroup walks through (<= 64 KiB: L2 / L1 resident after the first pass; large: streams from HBM)
-template <int LOADER, int INFLIGHT>
+template <int LOADER, int INFLIGHT, int AG = 0>
 __global__ void __launch_bounds__(512) k(const char* src, long long span, long long wg_stride, int n_load, int n_mfma, int all8, long long* out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -65,7 +65,10 @@ __global__ void __launch_bounds__(512) k(const char* src, long long span, long l
   } else if (!loader && n_mfma > 0) {
     for (int it = 0; it < n_mfma; ++it) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[u]) : "v"(a), "v"(b));
+      for (int u = 0; u < 8; ++u) {
+        if (AG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[u]) : "v"(a), "v"(b));
+        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[u]) : "v"(a), "v"(b));
+      }
     }
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
     t1 = __builtin_readcyclecounter();
@@ -78,14 +81,14 @@ __global__ void __launch_bounds__(512) k(const char* src, long long span, long l
 
 struct Res { double load_cyc, mfma_cyc; };
 
-template <int LOADER, int INFLIGHT>
+template <int LOADER, int INFLIGHT, int AG = 0>
 Res run(const char* src, long long span, long long wg_stride, int n_load, int n_mfma, int all8) {
   const int nwg = 256;
   long long* d;
   CK(hipMalloc(&d, nwg * 8 * sizeof(long long)));
-  CK(hipFuncSetAttribute((const void*)k<LOADER, INFLIGHT>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+  CK(hipFuncSetAttribute((const void*)k<LOADER, INFLIGHT, AG>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
   for (int rep = 0; rep < 3; ++rep) {
-    hipLaunchKernelGGL((k<LOADER, INFLIGHT>), dim3(nwg), dim3(512), 136 * 1024, 0, src, span, wg_stride, n_load, n_mfma, all8, d);
+    hipLaunchKernelGGL((k<LOADER, INFLIGHT, AG>), dim3(nwg), dim3(512), 136 * 1024, 0, src, span, wg_stride, n_load, n_mfma, all8, d);
     CK(hipDeviceSynchronize());
   }
   std::vector<long long> h(nwg * 8);
@@ -152,6 +155,13 @@ int main() {
   {
     Res lo = run<3, 8>(src, 65536, 65536, 4096, 4 * NM, 0), hi = run<3, 8>(src, 65536, 65536, 1 << 17, NM / 4, 0);
     report("ds_read_b128 (waves 0-3, 8 in flight) beside MFMA (4-7)", lo, 4096, 4, hi, NM / 4);
+  }
+  {
+    // the same with the accumulators in AGPRs (the MFMA's C / D traffic on the other half of the register file than the LDS returns)
+    Res hv = run<3, 8, 0>(src, 65536, 65536, 1 << 17, NM / 4, 0), ha = run<3, 8, 1>(src, 65536, 65536, 1 << 17, NM / 4, 0);
+    printf("MFMA beside a ds_read_b128 partner: VGPR accumulators %.2f, AGPR accumulators %.2f cycles per MFMA\n", hv.mfma_cyc / (NM / 4 * 8.0), ha.mfma_cyc / (NM / 4 * 8.0));
+    Res dv = run<1, 8, 0>(src, 49152, 65536, 1 << 16, NM / 4, 0), da = run<1, 8, 1>(src, 49152, 65536, 1 << 16, NM / 4, 0);
+    printf("MFMA beside an LDS-DMA partner:     VGPR accumulators %.2f, AGPR accumulators %.2f cycles per MFMA\n", dv.mfma_cyc / (NM / 4 * 8.0), da.mfma_cyc / (NM / 4 * 8.0));
   }
   CK(hipFree(src));
   return 0;
