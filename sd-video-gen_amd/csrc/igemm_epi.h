@@ -445,6 +445,11 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int m
         }
       }
     }
+    // the ds_writes above must have LANDED before any other wave passes the barrier: s_barrier alone does not wait for them on gfx950
+    // (back-off barrier: the compiler inserts no s_waitcnt in front of a bare __builtin_amdgcn_s_barrier).  Without this wait the last
+    // entries written — the final tile's columns — were occasionally read stale by the summing threads when the LDS was busy with a
+    // co-resident workgroup of ANOTHER context: GroupNorm statistics off in the last bits, run to run (found by tools/stress_pair.py, round 6)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     bar();
     for (int col = threadIdx.x; col < ncols; col += blockDim.x) {
       const int n = n0 + col;
@@ -481,6 +486,7 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, int z, int mr, int m
         *(float2*)(sc + ((size_t)wn * trows + rl) * 2) = make_float2(a, b);
       }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (as in the GroupNorm sums above: the writes have landed before anyone passes the barrier)
     bar();
     const int tile_n = n0 / (WN_ * NT_ * 16);
     for (int rl = threadIdx.x; rl < trows; rl += blockDim.x) {
