@@ -15,12 +15,15 @@ if FULL:
     from oracle import sd_oracle as SO
     T._set_cfg(True, "1_16_kitti_L1_64")
     usd, vsd = SO.seeded_weights(SO.unet_shapes(), 31), SO.seeded_weights(SO.vae_shapes(), 32)
+    if os.environ.get("STRESS_FP8"):                       # MX-fp8 convs (what extras.fp8_same_box runs)
+        os.environ["SVG_UNET_FP8"] = "1"
+        os.environ["SVG_HALO_MIN"] = "1"
     workers = [T._worker(vsd, usd, None, seed=7, d_model=256, layers=(2, 2)) for _ in range(2)]
     nc = 2 * int(FULL)
     clips = bouncing_ball_clips(nc, 64, 5, seed=9).cuda()
     seeds = list(range(21, 21 + nc))
     emb = workers[0][1].encode_text([""])
-    kw = dict(denoise=True, start_step=47, text_embeddings=emb)
+    kw = dict(denoise=True, start_step=47, text_embeddings=emb, guidance_scale=float(os.environ.get("STRESS_GUIDANCE", "0")))
 else:
     T._set_cfg()
     vsd, usd = T._small_nets()
