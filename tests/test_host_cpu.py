@@ -29,6 +29,23 @@ def test_library_exports_every_declared_symbol():
     assert lib.svg_version().decode().startswith("svg_hip")
 
 
+def test_committed_counter_summary_belongs_to_this_build():
+    """bench.py fills `roofline.traffic` from the newest profiles/*pmc_summary.json only when its `src_hash` is the hash of the sources the
+    library was built from (svg_version()); a kernel-source edit without re-taking tools/pmc_step.sh would silently turn the field into null.
+    Checks library == sources (the Makefile's own hash) == committed summary."""
+    import json
+    import subprocess
+    from sd_video_gen_amd import _lib
+    csrc = os.path.join(ROOT, "sd-video-gen_amd", "csrc")
+    db = subprocess.run(["make", "-pn", "-C", csrc], capture_output=True, text=True).stdout
+    of_sources = re.search(r"^SRCHASH := (\w+)", db, flags=re.M).group(1)
+    assert _lib.source_hash() == of_sources, "libsvg_hip.so is older than its sources: run __graft_entry__.build()"
+    names = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("pmc_summary.json"))
+    with open(os.path.join(ROOT, "profiles", names[-1])) as f:
+        summary = json.load(f)
+    assert summary["src_hash"] == of_sources, names[-1] + " was taken from another build of the kernels: re-run tools/pmc_step.sh"
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
 def test_product_path_fails_loudly_without_gpu():
     from sd_video_gen_amd import _lib, config as svg_config
